@@ -1,0 +1,232 @@
+/*
+ * CPU ORACLE — TEST INFRASTRUCTURE ONLY, NOT PRODUCT CODE.
+ *
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may load this file's
+ * library. The product path (softbodyunity_amd/csrc) never links, loads or calls it.
+ *
+ * PARITY UNPINNED: the reference tree is a single line (/root/reference/README.md:1,
+ * "# SoftbodyUnity") — there is no reference solver to restate, compile or import, and no
+ * reference test vector. This file is therefore a plain-C restatement of SPEC.md (the
+ * builder-defined semantics derived from BASELINE.json:5), pinned by the closed-form
+ * known-answer tests in tests/test_oracle_kat.py.
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off, no fast-math: every operation is a
+ * single correctly-rounded binary32 operation in the order SPEC.md parenthesises).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+typedef struct {
+    float gravity[3];
+    float damping;
+    float compliance[3]; /* distance, volume, bending */
+} orc_params;
+
+typedef struct {
+    float h, inv_h, hg[3], kd, at_d, at_v, at_b;
+} orc_scalars;
+
+/* SPEC.md §2 host-side scalars. */
+void orc_scalars_for(const orc_params *p, float dt, int substeps, orc_scalars *s) {
+    float S = (float)substeps;
+    s->h = dt / S;
+    s->inv_h = 1.0f / s->h;
+    for (int c = 0; c < 3; ++c) s->hg[c] = s->h * p->gravity[c];
+    float t = p->damping * s->h;
+    s->kd = 1.0f - t;
+    if (s->kd < 0.0f) s->kd = 0.0f;
+    float h2 = s->h * s->h;
+    s->at_d = p->compliance[0] / h2;
+    float av = p->compliance[1] / h2;
+    s->at_v = 36.0f * av;
+    s->at_b = p->compliance[2] / h2;
+}
+
+/* SPEC.md §2 step 1. */
+void orc_integrate(float *x, float *xprev, float *v, const float *w, int n, const orc_scalars *s) {
+    for (int p = 0; p < n; ++p) {
+        float *xp = x + 3 * p, *vp = v + 3 * p, *pp = xprev + 3 * p;
+        pp[0] = xp[0]; pp[1] = xp[1]; pp[2] = xp[2];
+        if (w[p] > 0.0f) {
+            for (int c = 0; c < 3; ++c) {
+                vp[c] = vp[c] + s->hg[c];
+                float hv = s->h * vp[c];
+                xp[c] = xp[c] + hv;
+            }
+        }
+    }
+}
+
+/* SPEC.md §2 step 3. */
+void orc_velocity(const float *x, const float *xprev, float *v, int n, const orc_scalars *s) {
+    for (int k = 0; k < 3 * n; ++k) {
+        float dx = x[k] - xprev[k];
+        float q = dx * s->inv_h;
+        v[k] = q * s->kd;
+    }
+}
+
+/* SPEC.md §4. */
+void orc_project_distance(float *x, const float *w, int i, int j, float L0, float at) {
+    float *xi = x + 3 * i, *xj = x + 3 * j;
+    float wi = w[i], wj = w[j];
+    float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
+    float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    float L2 = (xx + yy) + zz;
+    float L = sqrtf(L2);
+    float ws = (wi + wj) + at;
+    if (!(L > 0.0f) || !(ws > 0.0f)) return;
+    float C = L - L0;
+    float dl = (-C) / ws;
+    float s = dl / L;
+    float si = wi * s, sj = wj * s;
+    float ax = si * dx, ay = si * dy, az = si * dz;
+    float bx = sj * dx, by = sj * dy, bz = sj * dz;
+    xi[0] = xi[0] + ax; xi[1] = xi[1] + ay; xi[2] = xi[2] + az;
+    xj[0] = xj[0] - bx; xj[1] = xj[1] - by; xj[2] = xj[2] - bz;
+}
+
+static inline void sub3(const float *a, const float *b, float *o) {
+    o[0] = a[0] - b[0]; o[1] = a[1] - b[1]; o[2] = a[2] - b[2];
+}
+static inline void cross3(const float *a, const float *b, float *o) {
+    float t0 = a[1] * b[2], t1 = a[2] * b[1];
+    float t2 = a[2] * b[0], t3 = a[0] * b[2];
+    float t4 = a[0] * b[1], t5 = a[1] * b[0];
+    o[0] = t0 - t1; o[1] = t2 - t3; o[2] = t4 - t5;
+}
+static inline float dot3(const float *a, const float *b) {
+    float xx = a[0] * b[0], yy = a[1] * b[1], zz = a[2] * b[2];
+    return (xx + yy) + zz;
+}
+static inline void addscaled3(float *x, float s, const float *g) {
+    float a = s * g[0], b = s * g[1], c = s * g[2];
+    x[0] = x[0] + a; x[1] = x[1] + b; x[2] = x[2] + c;
+}
+
+/* SPEC.md §5. R6 = 6*V0. */
+void orc_project_volume(float *x, const float *w, const int32_t *id, float R6, float at_v) {
+    float *x0 = x + 3 * id[0], *x1 = x + 3 * id[1], *x2 = x + 3 * id[2], *x3 = x + 3 * id[3];
+    float w0 = w[id[0]], w1 = w[id[1]], w2 = w[id[2]], w3 = w[id[3]];
+    float e1[3], e2[3], e3[3], g0[3], g1[3], g2[3], g3[3];
+    sub3(x1, x0, e1); sub3(x2, x0, e2); sub3(x3, x0, e3);
+    cross3(e2, e3, g1); cross3(e3, e1, g2); cross3(e1, e2, g3);
+    for (int c = 0; c < 3; ++c) { float t = g1[c] + g2[c]; t = t + g3[c]; g0[c] = -t; }
+    float C6 = dot3(e1, g1) - R6;
+    float a0 = w0 * dot3(g0, g0), a1 = w1 * dot3(g1, g1), a2 = w2 * dot3(g2, g2), a3 = w3 * dot3(g3, g3);
+    float den = (((a0 + a1) + a2) + a3) + at_v;
+    if (!(den > 0.0f)) return;
+    float s = (-C6) / den;
+    addscaled3(x0, w0 * s, g0); addscaled3(x1, w1 * s, g1);
+    addscaled3(x2, w2 * s, g2); addscaled3(x3, w3 * s, g3);
+}
+
+/* SPEC.md §6. rest = (cos phi0, sin phi0). */
+void orc_project_bending(float *x, const float *w, const int32_t *id, const float *rest, float at_b) {
+    float *xa = x + 3 * id[0], *xb = x + 3 * id[1], *xc = x + 3 * id[2], *xd = x + 3 * id[3];
+    float w0 = w[id[0]], w1 = w[id[1]], w2 = w[id[2]], w3 = w[id[3]];
+    float e[3], ac[3], bc[3], bd[3], ad[3], n1[3], n2[3], m1[3], m2[3];
+    sub3(xb, xa, e);
+    float el2 = dot3(e, e);
+    float el = sqrtf(el2);
+    sub3(xa, xc, ac); sub3(xb, xc, bc); sub3(xb, xd, bd); sub3(xa, xd, ad);
+    cross3(ac, bc, n1); cross3(bd, ad, n2);
+    float q1 = dot3(n1, n1), q2 = dot3(n2, n2);
+    if (!(el > 0.0f) || !(q1 > 0.0f) || !(q2 > 0.0f)) return;
+    for (int c = 0; c < 3; ++c) { m1[c] = n1[c] / q1; m2[c] = n2[c] / q2; }
+    float gc[3], gd[3], ga[3], gb[3], cb[3], db[3], u1[3], u2[3], cr[3];
+    for (int c = 0; c < 3; ++c) { gc[c] = el * m1[c]; gd[c] = el * m2[c]; }
+    sub3(xc, xb, cb); sub3(xd, xb, db);
+    float ta1 = dot3(cb, e) / el, ta2 = dot3(db, e) / el;
+    float tb1 = dot3(ac, e) / el, tb2 = dot3(ad, e) / el;
+    for (int c = 0; c < 3; ++c) {
+        float p = ta1 * m1[c], q = ta2 * m2[c]; ga[c] = p + q;
+        float r = tb1 * m1[c], t = tb2 * m2[c]; gb[c] = r + t;
+    }
+    float s1 = sqrtf(q1), s2 = sqrtf(q2);
+    for (int c = 0; c < 3; ++c) { u1[c] = n1[c] / s1; u2[c] = n2[c] / s2; }
+    float cs = dot3(u1, u2);
+    cross3(u1, u2, cr);
+    float sn = -(dot3(cr, e) / el);
+    float t0 = sn * rest[0], t1 = cs * rest[1];
+    float C = t0 - t1;
+    float a0 = w0 * dot3(ga, ga), a1 = w1 * dot3(gb, gb), a2 = w2 * dot3(gc, gc), a3 = w3 * dot3(gd, gd);
+    float den = (((a0 + a1) + a2) + a3) + at_b;
+    if (!(den > 0.0f)) return;
+    float s = (-C) / den;
+    addscaled3(xa, w0 * s, ga); addscaled3(xb, w1 * s, gb);
+    addscaled3(xc, w2 * s, gc); addscaled3(xd, w3 * s, gd);
+}
+
+/*
+ * One projection sweep over `count` schedule entries (SPEC.md §3). order_type[k] in {0,1,2} =
+ * distance/volume/bending, order_id[k] = index into that type's arrays. order_* == NULL means
+ * natural order: all distance, then all volume, then all bending.
+ */
+typedef struct {
+    const int32_t *dist_ij; const float *dist_rest; int32_t m_d;
+    const int32_t *vol_ijkl; const float *vol_rest6; int32_t m_v;
+    const int32_t *bend_ijkl; const float *bend_rest; int32_t m_b;
+} orc_constraints;
+
+void orc_project_range(float *x, const float *w, const orc_constraints *c, const uint8_t *order_type,
+                       const int32_t *order_id, int64_t begin, int64_t end, const orc_scalars *s) {
+    for (int64_t k = begin; k < end; ++k) {
+        int t; int32_t id;
+        if (order_id) { t = order_type[k]; id = order_id[k]; }
+        else if (k < c->m_d) { t = 0; id = (int32_t)k; }
+        else if (k < (int64_t)c->m_d + c->m_v) { t = 1; id = (int32_t)(k - c->m_d); }
+        else { t = 2; id = (int32_t)(k - c->m_d - c->m_v); }
+        if (t == 0) orc_project_distance(x, w, c->dist_ij[2 * id], c->dist_ij[2 * id + 1], c->dist_rest[id], s->at_d);
+        else if (t == 1) orc_project_volume(x, w, c->vol_ijkl + 4 * (int64_t)id, c->vol_rest6[id], s->at_v);
+        else orc_project_bending(x, w, c->bend_ijkl + 4 * (int64_t)id, c->bend_rest + 2 * (int64_t)id, s->at_b);
+    }
+}
+
+/* One tick (SPEC.md §2), sequential — the semantics of a Unity FixedUpdate loop. xprev: scratch 3n. */
+void orc_step(float *x, float *v, const float *w, float *xprev, int n, const orc_constraints *c,
+              const uint8_t *order_type, const int32_t *order_id, const orc_params *p, float dt, int substeps) {
+    orc_scalars s;
+    orc_scalars_for(p, dt, substeps, &s);
+    int64_t total = (int64_t)c->m_d + c->m_v + c->m_b;
+    for (int it = 0; it < substeps; ++it) {
+        orc_integrate(x, xprev, v, w, n, &s);
+        orc_project_range(x, w, c, order_type, order_id, 0, total, &s);
+        orc_velocity(x, xprev, v, n, &s);
+    }
+}
+
+/*
+ * Task-parallel variant for the all-cores CPU baseline: the schedule is cut into phases; a phase
+ * is a list of tasks (contiguous ranges of the order) that touch pairwise disjoint particles, so
+ * they may run concurrently and give bit-identical results to orc_step. phase_task_off has
+ * n_phases+1 entries indexing task_off; task_off has n_tasks+1 entries indexing the order.
+ */
+void orc_step_tasks(float *x, float *v, const float *w, float *xprev, int n, const orc_constraints *c,
+                    const uint8_t *order_type, const int32_t *order_id, const int64_t *phase_task_off,
+                    int32_t n_phases, const int64_t *task_off, const orc_params *p, float dt, int substeps) {
+    orc_scalars s;
+    orc_scalars_for(p, dt, substeps, &s);
+    for (int it = 0; it < substeps; ++it) {
+#pragma omp parallel
+        {
+#pragma omp for schedule(static)
+            for (int blk = 0; blk < (n + 4095) / 4096; ++blk) {
+                int b = blk * 4096, e = b + 4096 > n ? n : b + 4096;
+                orc_integrate(x + 3 * (int64_t)b, xprev + 3 * (int64_t)b, v + 3 * (int64_t)b, w + b, e - b, &s);
+            }
+            for (int ph = 0; ph < n_phases; ++ph) {
+#pragma omp for schedule(dynamic, 16)
+                for (int64_t t = phase_task_off[ph]; t < phase_task_off[ph + 1]; ++t)
+                    orc_project_range(x, w, c, order_type, order_id, task_off[t], task_off[t + 1], &s);
+            }
+#pragma omp for schedule(static)
+            for (int blk = 0; blk < (n + 4095) / 4096; ++blk) {
+                int b = blk * 4096, e = b + 4096 > n ? n : b + 4096;
+                orc_velocity(x + 3 * (int64_t)b, xprev + 3 * (int64_t)b, v + 3 * (int64_t)b, e - b, &s);
+            }
+        }
+    }
+}

@@ -1,0 +1,161 @@
+"""Synthetic mesh + constraint-graph generators (SPEC.md §7; BASELINE.json:7-11).
+
+The reference ships no meshes (/root/reference/README.md:1 is the whole tree), so these are the
+builder-defined workloads of SURVEY.md §8d: the n^3 "jelly cube" with structural springs and an
+irregular tetrahedral surrogate for the Stanford-bunny config (no mesh asset exists offline).
+"""
+from dataclasses import dataclass, field
+
+import numpy as np
+
+
+@dataclass
+class SoftbodyMesh:
+    """Host-side authoring data, in the layouts the C ABI takes (AoS xyz float32, int32 indices)."""
+    rest_pos: np.ndarray            # (N,3) f32 rest positions
+    pos: np.ndarray                 # (N,3) f32 initial positions
+    vel: np.ndarray                 # (N,3) f32
+    inv_mass: np.ndarray            # (N,)  f32
+    dist_ij: np.ndarray             # (Md,2) i32
+    dist_rest: np.ndarray           # (Md,) f32
+    vol_ijkl: np.ndarray = field(default_factory=lambda: np.zeros((0, 4), np.int32))
+    vol_rest: np.ndarray = field(default_factory=lambda: np.zeros(0, np.float32))
+    bend_ijkl: np.ndarray = field(default_factory=lambda: np.zeros((0, 4), np.int32))
+    bend_rest: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.float32))  # (cos,sin) of rest dihedral
+    label: str = ""
+
+    @property
+    def n(self):
+        return self.pos.shape[0]
+
+
+def jelly_cube(n, spacing=1.0, perturb=0.05, seed=1234, pin_top=False, stencil="structural"):
+    """n^3 lattice, index (iz*n+iy)*n+ix, structural springs x-dir then y then z (SPEC.md §7)."""
+    assert n >= 2
+    ix, iy, iz = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
+    # index order: ix fastest
+    idx = ((iz * n + iy) * n + ix)
+    rest = np.zeros((n ** 3, 3), np.float32)
+    rest[idx.ravel(), 0] = (ix.ravel() * spacing)
+    rest[idx.ravel(), 1] = (iy.ravel() * spacing)
+    rest[idx.ravel(), 2] = (iz.ravel() * spacing)
+    rng = np.random.default_rng(seed)
+    jitter = rng.uniform(-perturb, perturb, size=(n ** 3, 3)) * spacing
+    pos = (rest.astype(np.float64) + jitter).astype(np.float32)
+    lin = np.arange(n ** 3, dtype=np.int64)
+    cx = lin % n
+    cy = (lin // n) % n
+    cz = lin // (n * n)
+    edges = []
+    for mask, off in ((cx < n - 1, 1), (cy < n - 1, n), (cz < n - 1, n * n)):
+        lo = lin[mask]
+        edges.append(np.stack([lo, lo + off], axis=1))
+    if stencil == "full":
+        # face + body diagonals (26-neighbour stencil), for colouring stress tests
+        for dx in (-1, 0, 1):
+            for dy in (-1, 0, 1):
+                for dz in (0, 1):
+                    if (dx, dy, dz) in ((0, 0, 0), (1, 0, 0), (0, 1, 0), (0, 0, 1)) or abs(dx) + abs(dy) + abs(dz) < 2:
+                        continue
+                    if dz == 0 and (dy < 0 or (dy == 0 and dx < 0)):
+                        continue
+                    m = ((cx + dx >= 0) & (cx + dx < n) & (cy + dy >= 0) & (cy + dy < n) & (cz + dz < n))
+                    lo = lin[m]
+                    edges.append(np.stack([lo, lo + dx + dy * n + dz * n * n], axis=1))
+    ij = np.concatenate(edges).astype(np.int32)
+    rest_len = np.linalg.norm(rest[ij[:, 0]].astype(np.float64) - rest[ij[:, 1]].astype(np.float64), axis=1).astype(np.float32)
+    w = np.ones(n ** 3, np.float32)
+    if pin_top:
+        w[cy == n - 1] = 0.0
+    return SoftbodyMesh(rest_pos=rest, pos=pos, vel=np.zeros_like(pos), inv_mass=w, dist_ij=ij,
+                        dist_rest=rest_len, label=f"jelly_cube_{n}^3_{stencil}")
+
+
+def _blob_inside(p):
+    """Implicit 'bunny-ish' blob: union of a body ellipsoid, a head sphere and two ear ellipsoids."""
+    x, y, z = p[:, 0], p[:, 1], p[:, 2]
+    body = (x / 1.0) ** 2 + ((y + 0.2) / 0.8) ** 2 + (z / 0.75) ** 2 < 1.0
+    head = ((x - 0.85) / 0.5) ** 2 + ((y - 0.55) / 0.5) ** 2 + (z / 0.45) ** 2 < 1.0
+    ear1 = ((x - 0.8) / 0.16) ** 2 + ((y - 1.25) / 0.5) ** 2 + ((z - 0.2) / 0.12) ** 2 < 1.0
+    ear2 = ((x - 0.8) / 0.16) ** 2 + ((y - 1.25) / 0.5) ** 2 + ((z + 0.2) / 0.12) ** 2 < 1.0
+    return body | head | ear1 | ear2
+
+
+def bunny_surrogate(target_verts=100_000, seed=1234, perturb=0.01):
+    """Irregular tet mesh SURROGATE for BASELINE.json:11 (no Stanford-bunny asset is available).
+
+    Jittered-grid points inside an implicit blob -> scipy Delaunay -> keep tets whose centroid is
+    inside. Constraints: every tet edge (distance), every tet (volume), every pair of boundary
+    triangles sharing an edge (cosine-dihedral bending, SPEC.md §6).
+    """
+    from scipy.spatial import Delaunay
+    rng = np.random.default_rng(seed)
+    lo = np.array([-1.1, -1.1, -0.85]); hi = np.array([1.45, 1.85, 0.85])
+    # choose the grid pitch so that roughly target_verts points land inside
+    probe = rng.uniform(lo, hi, size=(200_000, 3))
+    frac = _blob_inside(probe).mean()
+    vol = np.prod(hi - lo) * frac
+    pitch = (vol / target_verts) ** (1.0 / 3.0)
+    g = [np.arange(lo[a], hi[a], pitch) for a in range(3)]
+    P = np.stack(np.meshgrid(*g, indexing="ij"), axis=-1).reshape(-1, 3)
+    P = P + rng.uniform(-0.35, 0.35, size=P.shape) * pitch
+    P = P[_blob_inside(P)]
+    tri = Delaunay(P)
+    T = tri.simplices.astype(np.int64)
+    cen = P[T].mean(axis=1)
+    e = P[T]
+    vol6 = np.einsum("ij,ij->i", e[:, 1] - e[:, 0], np.cross(e[:, 2] - e[:, 0], e[:, 3] - e[:, 0]))
+    # drop outside + sliver tets
+    lens = np.linalg.norm(e[:, [0, 0, 0, 1, 1, 2]] - e[:, [1, 2, 3, 2, 3, 3]], axis=2).max(axis=1)
+    keep = _blob_inside(cen) & (np.abs(vol6) > 1e-3 * pitch ** 3) & (lens < 2.5 * pitch)
+    T = T[keep]; vol6 = vol6[keep]
+    # orient positively
+    neg = vol6 < 0
+    T[neg] = T[neg][:, [0, 2, 1, 3]]
+    vol6 = np.abs(vol6)
+    # compact vertices
+    used = np.unique(T)
+    remap = -np.ones(P.shape[0], np.int64); remap[used] = np.arange(used.size)
+    P = P[used]; T = remap[T]
+    rest = P.astype(np.float32)
+    # edges
+    pairs = np.concatenate([T[:, [a, b]] for a, b in ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))])
+    pairs.sort(axis=1)
+    ij = np.unique(pairs, axis=0).astype(np.int32)
+    r64 = rest.astype(np.float64)
+    dist_rest = np.linalg.norm(r64[ij[:, 0]] - r64[ij[:, 1]], axis=1).astype(np.float32)
+    vol_rest = (np.einsum("ij,ij->i", r64[T[:, 1]] - r64[T[:, 0]],
+                          np.cross(r64[T[:, 2]] - r64[T[:, 0]], r64[T[:, 3]] - r64[T[:, 0]])) / 6.0).astype(np.float32)
+    # boundary triangles = faces seen once
+    faces = np.concatenate([T[:, [1, 2, 3]], T[:, [0, 3, 2]], T[:, [0, 1, 3]], T[:, [0, 2, 1]]])
+    key = np.sort(faces, axis=1)
+    _, inv, cnt = np.unique(key, axis=0, return_inverse=True, return_counts=True)
+    bfaces = faces[cnt[inv] == 1]
+    # hinges: boundary edges shared by two boundary triangles
+    he = np.concatenate([bfaces[:, [0, 1, 2]], bfaces[:, [1, 2, 0]], bfaces[:, [2, 0, 1]]])  # (a,b,opp)
+    ek = np.sort(he[:, :2], axis=1)
+    order = np.lexsort((ek[:, 1], ek[:, 0]))
+    ek = ek[order]; he = he[order]
+    same = (ek[1:] == ek[:-1]).all(axis=1)
+    first = np.nonzero(same)[0]
+    # keep only manifold pairs (edge seen exactly twice)
+    ok = np.ones(first.size, bool)
+    if first.size > 1:
+        ok[1:] &= first[1:] != first[:-1] + 1
+        ok[:-1] &= first[1:] != first[:-1] + 1
+    first = first[ok]
+    bend = np.stack([ek[first, 0], ek[first, 1], he[first, 2], he[first + 1, 2]], axis=1).astype(np.int32)
+    A, B, Cw, D = (r64[bend[:, k]] for k in range(4))
+    e = B - A
+    n1 = np.cross(A - Cw, B - Cw); n2 = np.cross(B - D, A - D)
+    l1 = np.linalg.norm(n1, axis=1); l2 = np.linalg.norm(n2, axis=1); le = np.linalg.norm(e, axis=1)
+    good = (l1 > 1e-12) & (l2 > 1e-12) & (le > 1e-12)
+    bend = bend[good]; n1 = n1[good] / l1[good, None]; n2 = n2[good] / l2[good, None]; e = e[good] / le[good, None]
+    cs = np.einsum("ij,ij->i", n1, n2)
+    sn = -np.einsum("ij,ij->i", np.cross(n1, n2), e)
+    c0 = np.stack([cs, sn], axis=1).astype(np.float32)   # SPEC.md §6 rest pair (cos phi0, sin phi0)
+    jitter = rng.uniform(-perturb, perturb, size=rest.shape) * pitch
+    pos = (r64 + jitter).astype(np.float32)
+    return SoftbodyMesh(rest_pos=rest, pos=pos, vel=np.zeros_like(pos), inv_mass=np.ones(rest.shape[0], np.float32),
+                        dist_ij=ij, dist_rest=dist_rest, vol_ijkl=T.astype(np.int32), vol_rest=vol_rest,
+                        bend_ijkl=bend, bend_rest=c0, label=f"bunny_SURROGATE_{rest.shape[0]}v")
