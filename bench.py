@@ -1,0 +1,232 @@
+#!/usr/bin/env python3
+"""bench.py — particle-substeps/s of the soft-body hot path on MI355X (BASELINE.json:2).
+
+A "step" is one tick (= one FixedUpdate = `--substeps` substeps) over the whole synthetic jelly cube.
+Workload: the 256^3 structural lattice x 20 substeps (BASELINE.json:9, the configuration the metric's
+"achieved HBM GB/s vs 8 TB/s" and the >=10M-particle target are quoted on; it fits one GPU). With
+--gpus N > 1 the SAME 256^3 mesh is split spatially over N ranks (BASELINE.json:10) => strong scaling.
+`--n 64` runs config[1] instead.
+
+Launch: `python bench.py` (N=1) or
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P
+ bench.py --gpus N --steps K --warmup W` — one process per GPU. torch.distributed (gloo) carries only the
+control plane (unique-id broadcast, barriers, max-over-ranks); the ghost exchange itself is RCCL
+send/recv inside the plugin on its own HIP stream.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK = 8.0e12  # B/s, MI355X_MICROARCH.md chip-level parameters
+
+
+def b_alg(n_particles, n_constraints):
+    """SURVEY.md §8d algorithmic bytes per substep: 52 integrate + 68/constraint + 36 velocity."""
+    return 52.0 * n_particles + 68.0 * n_constraints + 36.0 * n_particles
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=256, help="cube edge (particles = n^3)")
+    ap.add_argument("--substeps", type=int, default=20)
+    ap.add_argument("--tile", type=int, default=512, help="target particles per LDS tile, -1 = global colours only")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-n", type=int, default=0, help="cube edge for the CPU baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        args.gpus = world
+
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+
+    from softbodyunity_amd import Softbody, comm_unique_id, jelly_cube
+
+    t_setup = time.time()
+    mesh = jelly_cube(args.n)
+    N = mesh.n
+    M = len(mesh.dist_rest)
+    uid = None
+    if world > 1:
+        buf = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = torch.tensor(list(comm_unique_id()), dtype=torch.uint8)
+        dist.broadcast(buf, src=0)
+        uid = bytes(buf.tolist())
+    dt = 0.02
+    sb = Softbody(mesh, substeps=args.substeps, fixed_delta_time=dt, device=local_rank, rank=rank, world=world,
+                  tile_particles=args.tile, use_graph=not args.no_graph, unique_id=uid).Start()
+    stats = sb.stats()
+    setup_s = time.time() - t_setup
+
+    def barrier():
+        sb.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    for _ in range(args.warmup):
+        sb.step()
+    barrier()
+    t0 = time.perf_counter()
+    sb.profile_begin()
+    for _ in range(args.steps):
+        sb.step()
+    ev_ms = sb.profile_end()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # per-kernel HIP-event timing on the solver's stream: a few extra eager ticks, outside the timed region
+    prof_ticks = 2
+    slot_ms = None
+    for _ in range(prof_ticks):
+        ms, cnt = sb.step_profiled()
+        slot_ms = ms.astype(np.float64) if slot_ms is None else slot_ms + ms
+        slot_cnt = cnt
+    slot_ms /= prof_ticks
+    finite = bool(np.isfinite(sb.get_positions()[sb.owner() == rank]).all())
+
+    value = N * args.substeps * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+    out = None
+    if rank == 0:
+        plan = sb.plan()
+        phases = plan.phases()
+        # dominant kernel = the slot with the most time; its ALGORITHMIC bytes per launch
+        k_dom = int(np.argmax(slot_ms))
+        names = []
+        alg_bytes = []
+        owned = stats["n_particles_owned"]
+        for k, ph in enumerate(phases):
+            if ph["kind"] == 1 and k == 0:
+                names.append("tile_kernel<1> (P1: velocity+integrate fused, in-cell springs)")
+            elif ph["kind"] == 1:
+                names.append("tile_kernel<2> (P2: shifted tiles, cut springs)")
+            else:
+                names.append(f"global_colour_kernel type {ph['type']}")
+        # constraints this rank executes per phase
+        mask = plan.local_order_mask().astype(bool)
+        for k, ph in enumerate(phases):
+            mk = int(mask[ph["order_begin"]:ph["order_end"]].sum())
+            extra = (52.0 + 36.0) * owned if k == 0 else 0.0   # phase 0 carries integrate + velocity
+            alg_bytes.append(68.0 * mk + extra)
+        names.append("velocity_kernel (tick end)")
+        alg_bytes.append(36.0 * owned)
+        launches = max(int(slot_cnt[k_dom]), 1)
+        dom_ms = float(slot_ms[k_dom]) / launches
+        achieved = alg_bytes[k_dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                key = f"n{args.n}_tile{args.tile}_gpus{world}"
+                if key in tj and str(k_dom) in tj[key]:
+                    traffic = tj[key][str(k_dom)]
+            except Exception:
+                traffic = None
+        job_alg = b_alg(N, M) * value / N   # algorithmic B/s of the whole job
+        out = {
+            "metric": "particle-substeps/sec", "value": value, "unit": "particle-substeps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{args.n}^3 jelly cube, structural springs (N={N}, M={M}), {args.substeps} substeps/tick, "
+                                   f"dt=0.02, explicit index-array graph, tile_particles={args.tile}",
+                       "partition": "x".join(str(d) for d in _dims(world)), "graph_replay": (not args.no_graph) and world == 1,
+                       "phases": [n for n in names[:-1]], "finite": finite},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
+                         "kernel": names[k_dom], "kernel_avg_ms": dom_ms, "kernel_launches_per_tick": launches,
+                         "algorithmic_bytes_per_launch": alg_bytes[k_dom],
+                         "job_algorithmic_GBps": job_alg / 1e9, "job_frac": job_alg / (HBM_PEAK * world),
+                         "B_alg_per_particle_substep": b_alg(N, M) / N,
+                         "tick_ms_hip_events": ev_ms / args.steps,
+                         "per_slot_ms_per_tick": {names[k]: float(slot_ms[k]) for k in range(len(names))}},
+            "setup_seconds": setup_s, "plan": {k: stats[k] for k in ("n_phases", "n_tile_phases", "n_global_colours",
+                                                                     "n_clusters", "constraints_in_tiles",
+                                                                     "constraints_in_global", "halo_bytes_per_substep",
+                                                                     "device_bytes")},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(mesh, sb, args)
+    sb.OnDestroy()
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(out))
+
+
+def _dims(world):
+    return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(world, (world, 1, 1))
+
+
+def cpu_baseline(mesh, sb, args):
+    """The CPU oracle (kind "port": the reference has no CPU path to time, /root/reference/README.md:1),
+    on this box's host cores, over a bounded sample of the same workload."""
+    from oracle import oracle
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from helpers import build_plan, make_oracle
+    from softbodyunity_amd import jelly_cube
+    n_s = args.cpu_sample_n or min(args.n, 128)
+    m = mesh if n_s == args.n else jelly_cube(n_s)
+    plan = sb.plan() if n_s == args.n else build_plan(m, tile_particles=args.tile)
+    o = make_oracle(oracle, m, plan)
+    S = args.substeps
+    t0 = time.perf_counter(); ticks = 0
+    while True:
+        o.step(0.02, S); ticks += 1
+        if time.perf_counter() - t0 > 8.0 or ticks >= 50:
+            break
+    t1 = time.perf_counter() - t0
+    v1 = m.n * S * ticks / t1
+    cores = len(os.sched_getaffinity(0))
+    os.environ.setdefault("OMP_NUM_THREADS", str(cores))
+    t0 = time.perf_counter(); pt = 0
+    while True:
+        o.step(0.02, S, parallel=True); pt += 1
+        if time.perf_counter() - t0 > 5.0 or pt >= 200:
+            break
+    tp = time.perf_counter() - t0
+    vp = m.n * S * pt / tp
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    return {"value": v1, "unit": "particle-substeps/s", "cores": 1, "kind": "port",
+            "sample": f"{ticks} tick(s) x {S} substeps of the {n_s}^3 cube, sequential oracle (Unity FixedUpdate semantics), "
+                      f"same published schedule",
+            "all_cores": {"value": vp, "cores": cores, "sample": f"{pt} tick(s), task-parallel oracle (OpenMP)"},
+            "cpu_model": model}
+
+
+if __name__ == "__main__":
+    main()

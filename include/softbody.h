@@ -1,0 +1,173 @@
+/*
+ * softbody.h — C ABI of libsoftbody_mi355x.so, the MI355X-native plugin behind the Unity
+ * `Softbody : MonoBehaviour` component (Start -> sb_create/sb_set_x/sb_finalize, FixedUpdate -> sb_step +
+ * sb_get_positions, OnDestroy -> sb_destroy).
+ *
+ * Reference interface replaced: NONE EXISTS. The reference tree is one line
+ * (/root/reference/README.md:1, "# SoftbodyUnity"); it holds no C#, no plugin and no FFI. The export
+ * set below is therefore the [BUILDER-DEFINED] boundary of SURVEY.md §8b, fixed only in kind by
+ * BASELINE.json:5 ("host code in C# ... calling into a thin C-ABI native plugin"). The C# side that
+ * binds it is csharp/SoftbodyNative.cs ([DllImport("softbody_mi355x", CallingConvention = Cdecl)]);
+ * softbodyunity_amd/native.py is the ctypes mirror used by the tests.
+ *
+ * Conventions:
+ *  - Host arrays are AoS: positions/velocities float xyz with 12-byte stride (Unity Vector3[] pins
+ *    directly), indices int32. The caller owns every array argument; the plugin copies before returning
+ *    and never retains a pointer.
+ *  - Every function returns 0 (SB_OK) or a negative sb_status; no exception or abort crosses the
+ *    boundary; sb_last_error() gives a thread-local, plugin-owned message for the last failure.
+ *  - One handle is single-threaded; distinct handles are independent. sb_step is synchronous w.r.t.
+ *    sb_get_*. There is NO CPU fallback: without a usable gfx950 device sb_create fails with
+ *    SB_ERR_NO_DEVICE.
+ *  - Semantics of one tick: SPEC.md.
+ */
+#ifndef SOFTBODY_MI355X_H
+#define SOFTBODY_MI355X_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SB_ABI_VERSION 1
+
+typedef enum {
+    SB_OK = 0,
+    SB_ERR_INVALID_ARG = -1,   /* null pointer, negative count, index out of range, bad enum */
+    SB_ERR_STATE = -2,         /* call out of order (e.g. sb_step before sb_finalize) */
+    SB_ERR_NO_DEVICE = -3,     /* no HIP device / not gfx950 / device index out of range */
+    SB_ERR_HIP = -4,           /* a HIP runtime call failed; message has the hipError string */
+    SB_ERR_RCCL = -5,          /* an RCCL call failed */
+    SB_ERR_NOMEM = -6,
+    SB_ERR_UNSUPPORTED = -7
+} sb_status;
+
+typedef struct sb_solver sb_solver; /* opaque, plugin-owned */
+typedef struct sb_plan sb_plan;     /* opaque, plugin-owned */
+
+/* Mirrors the [SerializeField] block of csharp/Softbody.cs. Zero-initialise, then set fields. */
+typedef struct {
+    int32_t device;          /* HIP device ordinal for this rank (LOCAL_RANK in a multi-process job) */
+    int32_t rank;            /* this process' part of the spatial partition, 0..world-1 */
+    int32_t world;           /* number of partitions == number of GPUs (1,2,4,8); 0 is read as 1 */
+    int32_t part_dims[3];    /* blocks per axis, product == world; {0,0,0} = auto (2x2x2 for 8, ...) */
+    float   gravity[3];
+    float   damping;
+    int32_t tile_particles;  /* target particles per LDS tile; 0 = default (512); -1 = no tiling:
+                                every constraint goes through the global-colour kernels */
+    int32_t use_graph;       /* 1 = replay the substep loop as a hipGraph (default 1 via sb_desc_default) */
+} sb_desc;
+
+void sb_desc_default(sb_desc *d);
+
+/* ---- lifecycle (Start / OnDestroy) ---------------------------------------------------------- */
+int sb_create(const sb_desc *desc, sb_solver **out);
+int sb_destroy(sb_solver *s);
+
+/* ---- authoring (Start), all before sb_finalize ----------------------------------------------- */
+int sb_set_particles(sb_solver *s, const float *pos_xyz, const float *vel_xyz /* may be NULL = 0 */,
+                     const float *inv_mass, int32_t n);
+/* Optional: rest pose used only to group particles into tiles (default: the sb_set_particles pose). */
+int sb_set_rest_positions(sb_solver *s, const float *rest_xyz, int32_t n);
+int sb_set_distance_constraints(sb_solver *s, const int32_t *ij, const float *rest_len, int32_t m, float compliance);
+int sb_set_volume_constraints(sb_solver *s, const int32_t *ijkl, const float *rest_vol, int32_t m, float compliance);
+/* rest_cs: 2 floats per hinge = (cos, sin) of the rest dihedral angle (SPEC.md §6). */
+int sb_set_bending_constraints(sb_solver *s, const int32_t *ijkl, const float *rest_cs, int32_t m, float compliance);
+/* Plan (colour + tile + partition), upload, capture. After this the authoring calls are rejected. */
+int sb_finalize(sb_solver *s);
+
+/* ---- multi-GPU: one process per GPU; RCCL communicator over xGMI ------------------------------ */
+/* Rank 0 calls sb_comm_unique_id, the host broadcasts the 128 bytes (any channel it likes), every
+ * rank passes them to sb_comm_init before sb_finalize. world == 1 needs neither call. */
+#define SB_UNIQUE_ID_BYTES 128
+int sb_comm_unique_id(uint8_t out_id[SB_UNIQUE_ID_BYTES]);
+int sb_comm_init(sb_solver *s, const uint8_t id[SB_UNIQUE_ID_BYTES]);
+
+/* ---- the hot path (FixedUpdate) -------------------------------------------------------------- */
+int sb_step(sb_solver *s, float dt, int32_t substeps);
+
+/* ---- readback / state round trip ------------------------------------------------------------- */
+/* Arrays are full size n in the caller's particle numbering. With world > 1 only entries of particles
+ * this rank owns are written; the rest are left untouched (see sb_get_owner). */
+int sb_get_positions(sb_solver *s, float *pos_xyz_out, int32_t n);
+int sb_get_velocities(sb_solver *s, float *vel_xyz_out, int32_t n);
+int sb_set_state(sb_solver *s, const float *pos_xyz, const float *vel_xyz, int32_t n); /* after finalize */
+int sb_get_owner(sb_solver *s, int32_t *owner_rank_out, int32_t n);
+
+/* ---- measurement ----------------------------------------------------------------------------- */
+/* HIP-event timing on the solver's own stream (torch.cuda.Event cannot see it). */
+int sb_profile_begin(sb_solver *s);
+int sb_profile_end(sb_solver *s, float *elapsed_ms_out);
+int sb_synchronize(sb_solver *s);
+/* One tick launched eagerly with a HIP-event pair around every kernel launch on the solver's stream.
+ * slot k < n_phases accumulates phase k's launches, slot n_phases the tick-end velocity kernel.
+ * n_slots must be n_phases + 1 (sb_get_stats). Same results as sb_step. */
+int sb_step_profiled(sb_solver *s, float dt, int32_t substeps, float *slot_ms_out, int32_t *slot_launches_out,
+                     int32_t n_slots);
+typedef struct {
+    int64_t n_particles_owned, n_particles_local;   /* local = owned + ghost */
+    int64_t n_constraints_local[3];                 /* distance, volume, bending (incl. redundant cut copies) */
+    int32_t n_phases, n_tile_phases, n_global_colours;
+    int64_t n_clusters;
+    int64_t constraints_in_tiles, constraints_in_global;
+    int64_t kernel_launches_per_substep;
+    int64_t halo_bytes_per_substep;                 /* bytes this rank sends per substep */
+    int64_t device_bytes;                           /* device memory held by the solver */
+} sb_stats;
+int sb_get_stats(sb_solver *s, sb_stats *out);
+
+/* ---- plan inspection (pure host code; works without a GPU) ------------------------------------ */
+typedef struct {
+    int32_t rank, world;
+    int32_t part_dims[3];
+    int32_t tile_particles;
+} sb_plan_opts;
+typedef struct {
+    int32_t kind;               /* 0 = global colour (one constraint type), 1 = tile phase */
+    int32_t type;               /* kind 0: constraint type 0/1/2; kind 1: -1 */
+    int64_t order_begin, order_end; /* slice of the published order */
+    int64_t task_begin, task_end;   /* slice of the task table: tasks of one phase touch disjoint particles */
+    int32_t needs_halo;         /* 1 = ghosts are refreshed before this phase when world > 1 */
+} sb_phase_info;
+
+int sb_plan_build(const float *rest_xyz, int32_t n,
+                  const int32_t *dist_ij, int32_t m_d,
+                  const int32_t *vol_ijkl, int32_t m_v,
+                  const int32_t *bend_ijkl, int32_t m_b,
+                  const sb_plan_opts *opts, sb_plan **out);
+int sb_plan_destroy(sb_plan *p);
+/* Borrowed view of a finalized solver's plan (valid until sb_destroy). */
+int sb_get_plan(sb_solver *s, const sb_plan **out);
+
+int64_t sb_plan_order_count(const sb_plan *p);
+/* The published sequential order (SPEC.md §3): type 0/1/2 + index into that type's input arrays. */
+int sb_plan_get_order(const sb_plan *p, uint8_t *type_out, int32_t *id_out);
+int32_t sb_plan_phase_count(const sb_plan *p);
+int sb_plan_get_phases(const sb_plan *p, sb_phase_info *out);
+int64_t sb_plan_task_count(const sb_plan *p);
+int sb_plan_get_tasks(const sb_plan *p, int64_t *task_off_out /* task_count+1 */);
+/* Finest independent sets (one colour class of one tile / one chunk of a global colour): constraints of
+ * one group share no particle; the GPU runs a group's constraints concurrently. */
+int64_t sb_plan_group_count(const sb_plan *p);
+int sb_plan_get_groups(const sb_plan *p, int64_t *group_off_out /* group_count+1 */);
+int sb_plan_get_owner(const sb_plan *p, int32_t *owner_rank_out /* n */);
+/* Per-rank view: particles this rank keeps (owned first, then ghosts), in device order. */
+int64_t sb_plan_local_count(const sb_plan *p, int64_t *owned_out);
+int sb_plan_get_local_particles(const sb_plan *p, int32_t *global_id_out);
+/* Halo schedule of this rank for phase `phase`: for every peer, which of its own particles it sends and
+ * which ghosts it receives (global ids, identical order on both sides). Returns counts via *_count. */
+int sb_plan_halo_counts(const sb_plan *p, int32_t phase, int32_t *send_count_per_rank /* world */,
+                        int32_t *recv_count_per_rank /* world */);
+int sb_plan_get_halo(const sb_plan *p, int32_t phase, int32_t peer, int32_t *send_ids, int32_t *recv_ids);
+/* Which order entries this rank executes (1) or skips (0) — cut constraints run on every rank that owns
+ * one of their particles. */
+int sb_plan_get_local_order_mask(const sb_plan *p, uint8_t *mask_out);
+
+const char *sb_last_error(void);
+int sb_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SOFTBODY_MI355X_H */

@@ -1,0 +1,255 @@
+// kernels.hip.hpp — gfx950 device code of the soft-body hot path (SPEC.md §2, §4-§6).
+//
+// No reference counterpart exists (/root/reference/README.md:1 is the whole reference tree).
+// Every arithmetic statement mirrors oracle/oracle.c one operation at a time; the file is compiled
+// with -ffp-contract=off and correctly-rounded fp32 divide/sqrt so results are bit-identical to the
+// oracle. MFMA is not used: the path is a bandwidth-bound gather/scatter (BASELINE.json:5).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sbk {
+
+struct TickParams {           // SPEC.md §2 host-side scalars, uploaded once per (dt, S)
+    float h, inv_h, hgx, hgy, hgz, kd, at_d, at_v, at_b;
+    float pad[7];
+};
+
+struct ClusterDesc {          // one LDS tile
+    int32_t run_begin, run_count, n_local, col_begin;
+    int32_t col_count, pad0, pad1, pad2;
+};
+struct ColourDesc {           // one colour class inside a tile
+    int32_t type;             // 0 distance, 1 volume, 2 bending
+    uint32_t begin;           // into the phase's constraint arrays of that arity
+    int32_t count, pad;
+};
+
+struct TileArgs {
+    float4 *pos;              // (x,y,z,w) per local particle
+    float *prev;              // packed xyz
+    const float *vel;         // packed xyz (MODE 0 only)
+    const ClusterDesc *cl;
+    const int2 *runs;         // {global start, local start}
+    const ColourDesc *cols;
+    const uint32_t *d_idx;    // distance: lo16 = i, hi16 = j (tile-local)
+    const float *d_rest;
+    const uint2 *q_idx;       // 4-vertex: {i0|i1<<16, i2|i3<<16}
+    const float2 *q_rest;     // volume: (6*V0, -), bending: (cos, sin)
+    const TickParams *tp;
+};
+
+constexpr int kTileThreads = 256;
+constexpr int kMaxRuns = 64;
+
+struct V3 { float x, y, z; };
+__device__ __forceinline__ V3 sub3(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
+__device__ __forceinline__ V3 cross3(V3 a, V3 b) {
+    float t0 = a.y * b.z, t1 = a.z * b.y, t2 = a.z * b.x, t3 = a.x * b.z, t4 = a.x * b.y, t5 = a.y * b.x;
+    return {t0 - t1, t2 - t3, t4 - t5};
+}
+__device__ __forceinline__ float dot3(V3 a, V3 b) {
+    float xx = a.x * b.x, yy = a.y * b.y, zz = a.z * b.z;
+    return (xx + yy) + zz;
+}
+__device__ __forceinline__ V3 addscaled3(V3 x, float s, V3 g) {
+    float a = s * g.x, b = s * g.y, c = s * g.z;
+    return {x.x + a, x.y + b, x.z + c};
+}
+__device__ __forceinline__ V3 xyz(float4 p) { return {p.x, p.y, p.z}; }
+
+// SPEC.md §4. Returns false when the constraint is skipped.
+__device__ __forceinline__ bool project_distance(float4 &a, float4 &b, float L0, float at) {
+    float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    float L2 = (xx + yy) + zz;
+    float L = sqrtf(L2);
+    float ws = (a.w + b.w) + at;
+    if (!(L > 0.0f) || !(ws > 0.0f)) return false;
+    float C = L - L0;
+    float dl = (-C) / ws;
+    float s = dl / L;
+    float si = a.w * s, sj = b.w * s;
+    float ax = si * dx, ay = si * dy, az = si * dz;
+    float bx = sj * dx, by = sj * dy, bz = sj * dz;
+    a.x = a.x + ax; a.y = a.y + ay; a.z = a.z + az;
+    b.x = b.x - bx; b.y = b.y - by; b.z = b.z - bz;
+    return true;
+}
+
+// SPEC.md §5.
+__device__ __forceinline__ bool project_volume(float4 &p0, float4 &p1, float4 &p2, float4 &p3, float R6, float at_v) {
+    V3 x0 = xyz(p0), x1 = xyz(p1), x2 = xyz(p2), x3 = xyz(p3);
+    V3 e1 = sub3(x1, x0), e2 = sub3(x2, x0), e3 = sub3(x3, x0);
+    V3 g1 = cross3(e2, e3), g2 = cross3(e3, e1), g3 = cross3(e1, e2);
+    V3 g0;
+    { float t = g1.x + g2.x; t = t + g3.x; g0.x = -t; }
+    { float t = g1.y + g2.y; t = t + g3.y; g0.y = -t; }
+    { float t = g1.z + g2.z; t = t + g3.z; g0.z = -t; }
+    float C6 = dot3(e1, g1) - R6;
+    float a0 = p0.w * dot3(g0, g0), a1 = p1.w * dot3(g1, g1), a2 = p2.w * dot3(g2, g2), a3 = p3.w * dot3(g3, g3);
+    float den = (((a0 + a1) + a2) + a3) + at_v;
+    if (!(den > 0.0f)) return false;
+    float s = (-C6) / den;
+    x0 = addscaled3(x0, p0.w * s, g0); x1 = addscaled3(x1, p1.w * s, g1);
+    x2 = addscaled3(x2, p2.w * s, g2); x3 = addscaled3(x3, p3.w * s, g3);
+    p0.x = x0.x; p0.y = x0.y; p0.z = x0.z; p1.x = x1.x; p1.y = x1.y; p1.z = x1.z;
+    p2.x = x2.x; p2.y = x2.y; p2.z = x2.z; p3.x = x3.x; p3.y = x3.y; p3.z = x3.z;
+    return true;
+}
+
+// SPEC.md §6. rest = (cos phi0, sin phi0).
+__device__ __forceinline__ bool project_bending(float4 &pa, float4 &pb, float4 &pc, float4 &pd, float2 rest, float at_b) {
+    V3 xa = xyz(pa), xb = xyz(pb), xc = xyz(pc), xd = xyz(pd);
+    V3 e = sub3(xb, xa);
+    float el2 = dot3(e, e);
+    float el = sqrtf(el2);
+    V3 ac = sub3(xa, xc), bc = sub3(xb, xc), bd = sub3(xb, xd), ad = sub3(xa, xd);
+    V3 n1 = cross3(ac, bc), n2 = cross3(bd, ad);
+    float q1 = dot3(n1, n1), q2 = dot3(n2, n2);
+    if (!(el > 0.0f) || !(q1 > 0.0f) || !(q2 > 0.0f)) return false;
+    V3 m1 = {n1.x / q1, n1.y / q1, n1.z / q1}, m2 = {n2.x / q2, n2.y / q2, n2.z / q2};
+    V3 gc = {el * m1.x, el * m1.y, el * m1.z}, gd = {el * m2.x, el * m2.y, el * m2.z};
+    V3 cb = sub3(xc, xb), db = sub3(xd, xb);
+    float ta1 = dot3(cb, e) / el, ta2 = dot3(db, e) / el;
+    float tb1 = dot3(ac, e) / el, tb2 = dot3(ad, e) / el;
+    V3 ga, gb;
+    { float p = ta1 * m1.x, q = ta2 * m2.x; ga.x = p + q; float r = tb1 * m1.x, t = tb2 * m2.x; gb.x = r + t; }
+    { float p = ta1 * m1.y, q = ta2 * m2.y; ga.y = p + q; float r = tb1 * m1.y, t = tb2 * m2.y; gb.y = r + t; }
+    { float p = ta1 * m1.z, q = ta2 * m2.z; ga.z = p + q; float r = tb1 * m1.z, t = tb2 * m2.z; gb.z = r + t; }
+    float s1 = sqrtf(q1), s2 = sqrtf(q2);
+    V3 u1 = {n1.x / s1, n1.y / s1, n1.z / s1}, u2 = {n2.x / s2, n2.y / s2, n2.z / s2};
+    float cs = dot3(u1, u2);
+    V3 cr = cross3(u1, u2);
+    float sn = -(dot3(cr, e) / el);
+    float t0 = sn * rest.x, t1 = cs * rest.y;
+    float C = t0 - t1;
+    float a0 = pa.w * dot3(ga, ga), a1 = pb.w * dot3(gb, gb), a2 = pc.w * dot3(gc, gc), a3 = pd.w * dot3(gd, gd);
+    float den = (((a0 + a1) + a2) + a3) + at_b;
+    if (!(den > 0.0f)) return false;
+    float s = (-C) / den;
+    xa = addscaled3(xa, pa.w * s, ga); xb = addscaled3(xb, pb.w * s, gb);
+    xc = addscaled3(xc, pc.w * s, gc); xd = addscaled3(xd, pd.w * s, gd);
+    pa.x = xa.x; pa.y = xa.y; pa.z = xa.z; pb.x = xb.x; pb.y = xb.y; pb.z = xb.z;
+    pc.x = xc.x; pc.y = xc.y; pc.z = xc.z; pd.x = xd.x; pd.y = xd.y; pd.z = xd.z;
+    return true;
+}
+
+// SPEC.md §2 steps 3+1 for one particle. MODE 0: v comes from the velocity array (first substep of a
+// tick); MODE 1: v is re-derived from (x - xprev) (velocity update of the previous substep fused in).
+template <int MODE>
+__device__ __forceinline__ void integrate_one(float4 &X, float *prev, const float *vel, int g, const TickParams &tp) {
+    float vx, vy, vz;
+    if (MODE == 0) {
+        vx = vel[3 * (size_t)g + 0]; vy = vel[3 * (size_t)g + 1]; vz = vel[3 * (size_t)g + 2];
+    } else {
+        float px = prev[3 * (size_t)g + 0], py = prev[3 * (size_t)g + 1], pz = prev[3 * (size_t)g + 2];
+        float dx = X.x - px, dy = X.y - py, dz = X.z - pz;
+        float qx = dx * tp.inv_h, qy = dy * tp.inv_h, qz = dz * tp.inv_h;
+        vx = qx * tp.kd; vy = qy * tp.kd; vz = qz * tp.kd;
+    }
+    prev[3 * (size_t)g + 0] = X.x; prev[3 * (size_t)g + 1] = X.y; prev[3 * (size_t)g + 2] = X.z;
+    if (X.w > 0.0f) {
+        vx = vx + tp.hgx; vy = vy + tp.hgy; vz = vz + tp.hgz;
+        float hx = tp.h * vx, hy = tp.h * vy, hz = tp.h * vz;
+        X.x = X.x + hx; X.y = X.y + hy; X.z = X.z + hz;
+    }
+}
+
+// One workgroup = one tile: stage its particles in LDS, run its colour classes with a barrier between
+// them, write the tile back. MODE 0/1: phase P1 with integrate fused into the load; MODE 2: plain tile.
+template <int MODE>
+__global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs A) {
+    extern __shared__ float4 lds_pos[];
+    __shared__ int2 s_runs[kMaxRuns + 1];
+    const ClusterDesc cd = A.cl[blockIdx.x];
+    const int tid = threadIdx.x;
+    if (tid < cd.run_count) s_runs[tid] = A.runs[cd.run_begin + tid];
+    if (tid == 0) s_runs[cd.run_count] = make_int2(0, cd.n_local);
+    __syncthreads();
+    const TickParams tp = *A.tp;
+    for (int l = tid; l < cd.n_local; l += kTileThreads) {
+        int r = 0;
+        while (s_runs[r + 1].y <= l) ++r;
+        const int g = s_runs[r].x + (l - s_runs[r].y);
+        float4 X = A.pos[g];
+        if (MODE < 2) integrate_one<MODE>(X, A.prev, A.vel, g, tp);
+        lds_pos[l] = X;
+    }
+    __syncthreads();
+    for (int c = 0; c < cd.col_count; ++c) {
+        const ColourDesc ce = A.cols[cd.col_begin + c];
+        if (ce.type == 0) {
+            for (int k = tid; k < ce.count; k += kTileThreads) {
+                const uint32_t pr = A.d_idx[ce.begin + k];
+                const float L0 = A.d_rest[ce.begin + k];
+                const int i = pr & 0xffffu, j = pr >> 16;
+                float4 a = lds_pos[i], b = lds_pos[j];
+                if (project_distance(a, b, L0, tp.at_d)) { lds_pos[i] = a; lds_pos[j] = b; }
+            }
+        } else {
+            for (int k = tid; k < ce.count; k += kTileThreads) {
+                const uint2 pr = A.q_idx[ce.begin + k];
+                const float2 rest = A.q_rest[ce.begin + k];
+                const int i0 = pr.x & 0xffffu, i1 = pr.x >> 16, i2 = pr.y & 0xffffu, i3 = pr.y >> 16;
+                float4 p0 = lds_pos[i0], p1 = lds_pos[i1], p2 = lds_pos[i2], p3 = lds_pos[i3];
+                bool ok = ce.type == 1 ? project_volume(p0, p1, p2, p3, rest.x, tp.at_v)
+                                       : project_bending(p0, p1, p2, p3, rest, tp.at_b);
+                if (ok) { lds_pos[i0] = p0; lds_pos[i1] = p1; lds_pos[i2] = p2; lds_pos[i3] = p3; }
+            }
+        }
+        __syncthreads();
+    }
+    for (int l = tid; l < cd.n_local; l += kTileThreads) {
+        int r = 0;
+        while (s_runs[r + 1].y <= l) ++r;
+        const int g = s_runs[r].x + (l - s_runs[r].y);
+        A.pos[g] = lds_pos[l];
+    }
+}
+
+// Global-colour kernels: one constraint per lane, gather/scatter straight on HBM.
+__global__ __launch_bounds__(256) void global_distance_kernel(float4 *pos, const int2 *ij, const float *rest, int count,
+                                                              const TickParams *tpp) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
+    const float at = tpp->at_d;
+    const int2 e = ij[k];
+    float4 a = pos[e.x], b = pos[e.y];
+    if (project_distance(a, b, rest[k], at)) { pos[e.x] = a; pos[e.y] = b; }
+}
+
+__global__ __launch_bounds__(256) void global_quad_kernel(float4 *pos, const int4 *idx, const float2 *rest, int count,
+                                                          int type, const TickParams *tpp) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
+    const int4 e = idx[k];
+    float4 p0 = pos[e.x], p1 = pos[e.y], p2 = pos[e.z], p3 = pos[e.w];
+    const float2 r = rest[k];
+    bool ok = type == 1 ? project_volume(p0, p1, p2, p3, r.x, tpp->at_v) : project_bending(p0, p1, p2, p3, r, tpp->at_b);
+    if (ok) { pos[e.x] = p0; pos[e.y] = p1; pos[e.z] = p2; pos[e.w] = p3; }
+}
+
+// SPEC.md §2 step 3 at the end of a tick (inside the tick it is fused into the next P1 load).
+__global__ __launch_bounds__(256) void velocity_kernel(const float4 *pos, const float *prev, float *vel, int n_owned,
+                                                       const TickParams *tpp) {
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= n_owned) return;
+    const float inv_h = tpp->inv_h, kd = tpp->kd;
+    const float4 X = pos[g];
+    float dx = X.x - prev[3 * (size_t)g + 0], dy = X.y - prev[3 * (size_t)g + 1], dz = X.z - prev[3 * (size_t)g + 2];
+    float qx = dx * inv_h, qy = dy * inv_h, qz = dz * inv_h;
+    vel[3 * (size_t)g + 0] = qx * kd; vel[3 * (size_t)g + 1] = qy * kd; vel[3 * (size_t)g + 2] = qz * kd;
+}
+
+// Halo pack / unpack: ghost positions travel as float4.
+__global__ __launch_bounds__(256) void halo_pack_kernel(const float4 *pos, const int32_t *idx, float4 *buf, int count) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < count) buf[k] = pos[idx[k]];
+}
+__global__ __launch_bounds__(256) void halo_unpack_kernel(float4 *pos, const int32_t *idx, const float4 *buf, int count) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k < count) pos[idx[k]] = buf[k];
+}
+
+}  // namespace sbk

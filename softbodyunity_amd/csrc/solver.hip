@@ -1,0 +1,825 @@
+// solver.hip — solver runtime + C ABI of libsoftbody_mi355x.so (include/softbody.h).
+//
+// No reference counterpart exists (/root/reference/README.md:1 is the whole reference tree); the
+// exported functions are the [BUILDER-DEFINED] boundary of SURVEY.md §8b. This file owns device
+// memory, the substep loop (hipGraph replay), the RCCL ghost exchange and the plan inspection API.
+// There is deliberately no CPU execution path: without a gfx950 device sb_create fails.
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/softbody.h"
+#include "kernels.hip.hpp"
+#include "plan.hpp"
+
+namespace {
+
+thread_local std::string g_err;
+int fail(int code, const std::string &msg) { g_err = msg; return code; }
+
+struct HipError : std::runtime_error {
+    int code;
+    HipError(int c, const std::string &m) : std::runtime_error(m), code(c) {}
+};
+#define HIP_CHECK(expr)                                                                                   \
+    do {                                                                                                  \
+        hipError_t e_ = (expr);                                                                           \
+        if (e_ != hipSuccess)                                                                             \
+            throw HipError(SB_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
+    } while (0)
+#define NCCL_CHECK(expr)                                                                                  \
+    do {                                                                                                  \
+        ncclResult_t r_ = (expr);                                                                         \
+        if (r_ != ncclSuccess)                                                                            \
+            throw HipError(SB_ERR_RCCL, std::string(#expr) + ": " + ncclGetErrorString(r_));              \
+    } while (0)
+
+template <class T>
+struct DevBuf {
+    T *p = nullptr;
+    size_t count = 0;
+    void alloc(size_t n, int64_t &acct) {
+        free();
+        count = n;
+        if (n) { HIP_CHECK(hipMalloc((void **)&p, n * sizeof(T))); acct += (int64_t)(n * sizeof(T)); }
+    }
+    void upload(const std::vector<T> &h, int64_t &acct) {
+        alloc(h.size(), acct);
+        if (!h.empty()) HIP_CHECK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
+    }
+    void free() { if (p) { (void)hipFree(p); p = nullptr; } count = 0; }
+    ~DevBuf() { free(); }
+};
+
+struct DevPhase {
+    int kind = 0, type = 0;
+    bool fused_integrate = false, needs_halo = false;
+    // tile phase
+    int32_t n_clusters = 0;
+    size_t lds_bytes = 0;
+    DevBuf<sbk::ClusterDesc> cl;
+    DevBuf<int2> runs;
+    DevBuf<sbk::ColourDesc> cols;
+    DevBuf<uint32_t> d_idx;
+    DevBuf<float> d_rest;
+    DevBuf<uint2> q_idx;
+    DevBuf<float2> q_rest;
+    // global phase
+    int32_t g_count = 0;
+    DevBuf<int2> g_ij;
+    DevBuf<int4> g_quad;
+    DevBuf<float> g_rest;
+    DevBuf<float2> g_rest2;
+    // halo
+    std::vector<int> peers;
+    std::vector<int32_t> send_off, recv_off;  // per peer (+1), in particles
+    DevBuf<int32_t> send_idx, recv_idx;
+    int64_t n_cons = 0;
+};
+
+}  // namespace
+
+struct sb_plan {
+    sbp::Plan plan;
+    sbp::LocalPlan local;
+    // keep inputs needed by inspection calls
+    bool owns_local = true;
+};
+
+struct sb_solver {
+    sb_desc desc;
+    bool finalized = false;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    ncclComm_t comm = nullptr;
+    // authoring copies
+    int32_t n = 0;
+    std::vector<float> pos, vel, invm, rest;
+    std::vector<int32_t> dist_ij, vol_ijkl, bend_ijkl;
+    std::vector<float> dist_rest, vol_rest, bend_rest;
+    float compliance[3] = {0, 0, 0};
+    // plan
+    std::unique_ptr<sb_plan> plan;
+    // device state
+    int64_t dev_bytes = 0;
+    int64_t n_owned = 0, n_local = 0;
+    DevBuf<float4> d_pos;
+    DevBuf<float> d_prev, d_vel;
+    DevBuf<sbk::TickParams> d_tp;
+    DevBuf<float4> d_sendbuf, d_recvbuf;
+    std::vector<std::unique_ptr<DevPhase>> phases;
+    sbk::TickParams tp_host{};
+    bool tp_valid = false;
+    std::map<int, hipGraphExec_t> graphs;
+    int64_t launches_per_substep = 0, halo_bytes_per_substep = 0;
+    std::vector<float4> h_stage;
+
+    ~sb_solver() {
+        for (auto &g : graphs) (void)hipGraphExecDestroy(g.second);
+        if (comm) (void)ncclCommDestroy(comm);
+        phases.clear();
+        if (ev0) (void)hipEventDestroy(ev0);
+        if (ev1) (void)hipEventDestroy(ev1);
+        if (stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+namespace {
+
+sbp::Input make_input(const float *rest, int32_t n, const int32_t *d, int64_t md, const int32_t *v, int64_t mv,
+                      const int32_t *b, int64_t mb) {
+    sbp::Input in;
+    in.rest = rest; in.n = n; in.dist_ij = d; in.m_d = md; in.vol = v; in.m_v = mv; in.bend = b; in.m_b = mb;
+    return in;
+}
+
+// SPEC.md §2 host-side scalars (same operation order as oracle.c orc_scalars_for).
+sbk::TickParams tick_params(const sb_solver *s, float dt, int substeps) {
+    sbk::TickParams t{};
+    volatile float S = (float)substeps;
+    volatile float h = dt / S;
+    t.h = h;
+    volatile float inv_h = 1.0f / h;
+    t.inv_h = inv_h;
+    volatile float hx = h * s->desc.gravity[0], hy = h * s->desc.gravity[1], hz = h * s->desc.gravity[2];
+    t.hgx = hx; t.hgy = hy; t.hgz = hz;
+    volatile float td = s->desc.damping * h;
+    volatile float kd = 1.0f - td;
+    t.kd = kd < 0.0f ? 0.0f : (float)kd;
+    volatile float h2 = h * h;
+    volatile float ad = s->compliance[0] / h2;
+    volatile float av = s->compliance[1] / h2;
+    volatile float av36 = 36.0f * av;
+    volatile float ab = s->compliance[2] / h2;
+    t.at_d = ad; t.at_v = av36; t.at_b = ab;
+    return t;
+}
+
+void build_device(sb_solver *s) {
+    const sbp::Plan &P = s->plan->plan;
+    const sbp::LocalPlan &L = s->plan->local;
+    s->n_owned = L.n_owned;
+    s->n_local = (int64_t)L.local_to_old.size();
+    // particle state
+    std::vector<float4> hp((size_t)s->n_local);
+    std::vector<float> hv((size_t)s->n_local * 3, 0.0f);
+    for (int64_t l = 0; l < s->n_local; ++l) {
+        int32_t o = L.local_to_old[l];
+        hp[l] = make_float4(s->pos[3 * (size_t)o], s->pos[3 * (size_t)o + 1], s->pos[3 * (size_t)o + 2], s->invm[o]);
+        for (int c = 0; c < 3; ++c) hv[3 * (size_t)l + c] = s->vel[3 * (size_t)o + c];
+    }
+    s->d_pos.upload(hp, s->dev_bytes);
+    s->d_vel.upload(hv, s->dev_bytes);
+    s->d_prev.alloc((size_t)s->n_local * 3, s->dev_bytes);
+    HIP_CHECK(hipMemset(s->d_prev.p, 0, (size_t)s->n_local * 3 * sizeof(float)));
+    s->d_tp.alloc(1, s->dev_bytes);
+    size_t max_send = 0, max_recv = 0;
+    s->launches_per_substep = 0;
+    s->halo_bytes_per_substep = 0;
+    for (size_t ph = 0; ph < L.phases.size(); ++ph) {
+        const sbp::LocalPhase &LP = L.phases[ph];
+        auto D = std::make_unique<DevPhase>();
+        D->kind = LP.kind; D->type = LP.type; D->fused_integrate = LP.fused_integrate;
+        if (LP.kind == 1) {
+            std::vector<sbk::ClusterDesc> cl;
+            std::vector<int2> runs;
+            std::vector<sbk::ColourDesc> cols;
+            std::vector<uint32_t> d_idx; std::vector<float> d_rest;
+            std::vector<uint2> q_idx; std::vector<float2> q_rest;
+            int32_t max_local = 0;
+            for (size_t ci = 0; ci < LP.cluster_ids.size(); ++ci) {
+                const sbp::Cluster &G = P.clusters[LP.cluster_ids[ci]];
+                sbk::ClusterDesc cd{};
+                cd.run_begin = (int32_t)runs.size();
+                cd.run_count = LP.run_begin[ci + 1] - LP.run_begin[ci];
+                int32_t lstart = 0;
+                for (int32_t r = LP.run_begin[ci]; r < LP.run_begin[ci + 1]; ++r) {
+                    runs.push_back(make_int2(LP.runs[r].start, lstart));
+                    lstart += LP.runs[r].len;
+                }
+                cd.n_local = lstart;
+                max_local = std::max(max_local, lstart);
+                cd.col_begin = (int32_t)cols.size();
+                cd.col_count = G.col_count;
+                for (int32_t c = 0; c < G.col_count; ++c) {
+                    const sbp::ColourEntry &ce = P.colours[G.col_begin + c];
+                    sbk::ColourDesc dc{};
+                    dc.type = ce.type; dc.count = ce.count;
+                    if (ce.type == 0) {
+                        dc.begin = (uint32_t)d_idx.size();
+                        for (int32_t k = 0; k < ce.count; ++k) {
+                            d_idx.push_back(P.t_dist[ce.begin + k]);
+                            d_rest.push_back(s->dist_rest[P.t_dist_id[ce.begin + k]]);
+                        }
+                    } else {
+                        dc.begin = (uint32_t)q_idx.size();
+                        for (int32_t k = 0; k < ce.count; ++k) {
+                            q_idx.push_back(make_uint2(P.t_quad[2 * (ce.begin + k)], P.t_quad[2 * (ce.begin + k) + 1]));
+                            int32_t id = P.t_quad_id[ce.begin + k];
+                            if (ce.type == 1) {
+                                volatile float r6 = 6.0f * s->vol_rest[id];
+                                q_rest.push_back(make_float2(r6, 0.0f));
+                            } else {
+                                q_rest.push_back(make_float2(s->bend_rest[2 * (size_t)id], s->bend_rest[2 * (size_t)id + 1]));
+                            }
+                        }
+                    }
+                    D->n_cons += ce.count;
+                    cols.push_back(dc);
+                }
+                cl.push_back(cd);
+            }
+            if (d_idx.size() > 0xffffffffull || q_idx.size() > 0xffffffffull) throw std::runtime_error("tile constraint offsets overflow");
+            D->n_clusters = (int32_t)cl.size();
+            D->lds_bytes = (size_t)std::max(max_local, 1) * sizeof(float4);
+            D->cl.upload(cl, s->dev_bytes); D->runs.upload(runs, s->dev_bytes); D->cols.upload(cols, s->dev_bytes);
+            D->d_idx.upload(d_idx, s->dev_bytes); D->d_rest.upload(d_rest, s->dev_bytes);
+            D->q_idx.upload(q_idx, s->dev_bytes); D->q_rest.upload(q_rest, s->dev_bytes);
+        } else {
+            D->g_count = (int32_t)LP.g_id.size();
+            D->n_cons = D->g_count;
+            if (LP.type == 0) {
+                std::vector<int2> ij(LP.g_id.size()); std::vector<float> rest(LP.g_id.size());
+                for (size_t k = 0; k < LP.g_id.size(); ++k) {
+                    ij[k] = make_int2(LP.g_idx[2 * k], LP.g_idx[2 * k + 1]);
+                    rest[k] = s->dist_rest[LP.g_id[k]];
+                }
+                D->g_ij.upload(ij, s->dev_bytes); D->g_rest.upload(rest, s->dev_bytes);
+            } else {
+                std::vector<int4> q(LP.g_id.size()); std::vector<float2> rest(LP.g_id.size());
+                for (size_t k = 0; k < LP.g_id.size(); ++k) {
+                    q[k] = make_int4(LP.g_idx[4 * k], LP.g_idx[4 * k + 1], LP.g_idx[4 * k + 2], LP.g_idx[4 * k + 3]);
+                    int32_t id = LP.g_id[k];
+                    if (LP.type == 1) { volatile float r6 = 6.0f * s->vol_rest[id]; rest[k] = make_float2(r6, 0.0f); }
+                    else rest[k] = make_float2(s->bend_rest[2 * (size_t)id], s->bend_rest[2 * (size_t)id + 1]);
+                }
+                D->g_quad.upload(q, s->dev_bytes); D->g_rest2.upload(rest, s->dev_bytes);
+            }
+        }
+        // halo lists
+        std::vector<int32_t> sidx, ridx;
+        D->send_off.push_back(0); D->recv_off.push_back(0);
+        for (int peer = 0; peer < L.world; ++peer) {
+            if (LP.send_idx[peer].empty() && LP.recv_idx[peer].empty()) continue;
+            D->peers.push_back(peer);
+            sidx.insert(sidx.end(), LP.send_idx[peer].begin(), LP.send_idx[peer].end());
+            ridx.insert(ridx.end(), LP.recv_idx[peer].begin(), LP.recv_idx[peer].end());
+            D->send_off.push_back((int32_t)sidx.size()); D->recv_off.push_back((int32_t)ridx.size());
+        }
+        D->needs_halo = !D->peers.empty();
+        D->send_idx.upload(sidx, s->dev_bytes); D->recv_idx.upload(ridx, s->dev_bytes);
+        max_send = std::max(max_send, sidx.size()); max_recv = std::max(max_recv, ridx.size());
+        s->halo_bytes_per_substep += (int64_t)sidx.size() * 16;
+        if (D->kind == 1 ? D->n_clusters > 0 : D->g_count > 0) ++s->launches_per_substep;
+        if (D->needs_halo) s->launches_per_substep += 2;
+        s->phases.push_back(std::move(D));
+    }
+    s->d_sendbuf.alloc(max_send, s->dev_bytes);
+    s->d_recvbuf.alloc(max_recv, s->dev_bytes);
+}
+
+void halo_exchange(sb_solver *s, DevPhase &D) {
+    if (!D.needs_halo) return;
+    if (!s->comm) throw HipError(SB_ERR_STATE, "world > 1 needs sb_comm_init before sb_finalize");
+    const int ns = D.send_off.back(), nr = D.recv_off.back();
+    if (ns) hipLaunchKernelGGL(sbk::halo_pack_kernel, dim3((ns + 255) / 256), dim3(256), 0, s->stream, s->d_pos.p,
+                               D.send_idx.p, s->d_sendbuf.p, ns);
+    NCCL_CHECK(ncclGroupStart());
+    for (size_t k = 0; k < D.peers.size(); ++k) {
+        int cs = D.send_off[k + 1] - D.send_off[k], cr = D.recv_off[k + 1] - D.recv_off[k];
+        if (cs) NCCL_CHECK(ncclSend(s->d_sendbuf.p + D.send_off[k], (size_t)cs * 4, ncclFloat, D.peers[k], s->comm, s->stream));
+        if (cr) NCCL_CHECK(ncclRecv(s->d_recvbuf.p + D.recv_off[k], (size_t)cr * 4, ncclFloat, D.peers[k], s->comm, s->stream));
+    }
+    NCCL_CHECK(ncclGroupEnd());
+    if (nr) hipLaunchKernelGGL(sbk::halo_unpack_kernel, dim3((nr + 255) / 256), dim3(256), 0, s->stream, s->d_pos.p,
+                               D.recv_idx.p, s->d_recvbuf.p, nr);
+}
+
+template <int MODE>
+void launch_tile(sb_solver *s, DevPhase &D) {
+    if (D.n_clusters == 0) return;
+    sbk::TileArgs A{};
+    A.pos = s->d_pos.p; A.prev = s->d_prev.p; A.vel = s->d_vel.p;
+    A.cl = D.cl.p; A.runs = D.runs.p; A.cols = D.cols.p;
+    A.d_idx = D.d_idx.p; A.d_rest = D.d_rest.p; A.q_idx = D.q_idx.p; A.q_rest = D.q_rest.p;
+    A.tp = s->d_tp.p;
+    hipLaunchKernelGGL(sbk::tile_kernel<MODE>, dim3(D.n_clusters), dim3(sbk::kTileThreads), D.lds_bytes, s->stream, A);
+}
+
+struct LaunchTimer {            // optional HIP-event pair around every launch of one tick (sb_step_profiled)
+    std::vector<hipEvent_t> ev;
+    std::vector<int> slot;      // phase index per pair; n_phases = velocity kernel
+    hipStream_t stream;
+    void begin(int phase_slot) {
+        hipEvent_t a, b;
+        HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
+        ev.push_back(a); ev.push_back(b); slot.push_back(phase_slot);
+        HIP_CHECK(hipEventRecord(a, stream));
+    }
+    void end() { HIP_CHECK(hipEventRecord(ev.back(), stream)); }
+    ~LaunchTimer() { for (auto e : ev) (void)hipEventDestroy(e); }
+};
+
+void enqueue_substeps(sb_solver *s, int substeps, LaunchTimer *lt = nullptr) {
+    for (int it = 0; it < substeps; ++it) {
+        int pi = -1;
+        for (auto &Dp : s->phases) {
+            DevPhase &D = *Dp;
+            ++pi;
+            halo_exchange(s, D);
+            const bool has_work = D.kind == 1 ? D.n_clusters > 0 : D.g_count > 0;
+            if (lt && has_work) lt->begin(pi);
+            if (D.kind == 1) {
+                if (D.fused_integrate) { if (it == 0) launch_tile<0>(s, D); else launch_tile<1>(s, D); }
+                else launch_tile<2>(s, D);
+            } else if (D.g_count > 0) {
+                dim3 grid((D.g_count + 255) / 256);
+                if (D.type == 0)
+                    hipLaunchKernelGGL(sbk::global_distance_kernel, grid, dim3(256), 0, s->stream, s->d_pos.p, D.g_ij.p,
+                                       D.g_rest.p, D.g_count, s->d_tp.p);
+                else
+                    hipLaunchKernelGGL(sbk::global_quad_kernel, grid, dim3(256), 0, s->stream, s->d_pos.p, D.g_quad.p,
+                                       D.g_rest2.p, D.g_count, D.type, s->d_tp.p);
+            }
+            if (lt && has_work) lt->end();
+        }
+    }
+    if (s->n_owned) {
+        if (lt) lt->begin((int)s->phases.size());
+        hipLaunchKernelGGL(sbk::velocity_kernel, dim3((unsigned)((s->n_owned + 255) / 256)), dim3(256), 0, s->stream,
+                           s->d_pos.p, s->d_prev.p, s->d_vel.p, (int)s->n_owned, s->d_tp.p);
+        if (lt) lt->end();
+    }
+    HIP_CHECK(hipGetLastError());
+}
+
+void upload_tick_params(sb_solver *s, float dt, int substeps) {
+    sbk::TickParams tp = tick_params(s, dt, substeps);
+    if (!s->tp_valid || std::memcmp(&tp, &s->tp_host, sizeof(tp)) != 0) {
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        HIP_CHECK(hipMemcpyAsync(s->d_tp.p, &tp, sizeof(tp), hipMemcpyHostToDevice, s->stream));
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        s->tp_host = tp; s->tp_valid = true;
+    }
+}
+
+template <class F>
+int guarded(F &&f) {
+    try {
+        return f();
+    } catch (const HipError &e) {
+        return fail(e.code, e.what());
+    } catch (const std::bad_alloc &) {
+        return fail(SB_ERR_NOMEM, "out of host memory");
+    } catch (const std::exception &e) {
+        return fail(SB_ERR_INVALID_ARG, e.what());
+    }
+}
+
+int set_device(const sb_solver *s) {
+    hipError_t e = hipSetDevice(s->desc.device);
+    if (e != hipSuccess) return fail(SB_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return SB_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char *sb_last_error(void) { return g_err.c_str(); }
+int sb_abi_version(void) { return SB_ABI_VERSION; }
+
+void sb_desc_default(sb_desc *d) {
+    if (!d) return;
+    std::memset(d, 0, sizeof(*d));
+    d->world = 1;
+    d->gravity[1] = -9.81f;
+    d->tile_particles = 512;
+    d->use_graph = 1;
+}
+
+int sb_create(const sb_desc *desc, sb_solver **out) {
+    if (!desc || !out) return fail(SB_ERR_INVALID_ARG, "sb_create: null argument");
+    *out = nullptr;
+    return guarded([&]() -> int {
+        sb_desc d = *desc;
+        if (d.world <= 0) d.world = 1;
+        if (d.rank < 0 || d.rank >= d.world) return fail(SB_ERR_INVALID_ARG, "sb_create: rank out of range");
+        if (!(d.damping >= 0.0f)) return fail(SB_ERR_INVALID_ARG, "sb_create: damping must be >= 0");
+        if (d.tile_particles == 0) d.tile_particles = 512;
+        if (d.tile_particles > sbp::kMaxTileLocal) return fail(SB_ERR_INVALID_ARG, "sb_create: tile_particles too large");
+        int ndev = 0;
+        hipError_t e = hipGetDeviceCount(&ndev);
+        if (e != hipSuccess || ndev <= 0)
+            return fail(SB_ERR_NO_DEVICE, "sb_create: no HIP device (this plugin has no CPU path)");
+        if (d.device < 0 || d.device >= ndev) return fail(SB_ERR_NO_DEVICE, "sb_create: device ordinal out of range");
+        hipDeviceProp_t prop;
+        HIP_CHECK(hipGetDeviceProperties(&prop, d.device));
+        if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+            return fail(SB_ERR_NO_DEVICE, std::string("sb_create: device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+        HIP_CHECK(hipSetDevice(d.device));
+        auto s = std::make_unique<sb_solver>();
+        s->desc = d;
+        HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
+        HIP_CHECK(hipEventCreate(&s->ev0));
+        HIP_CHECK(hipEventCreate(&s->ev1));
+        *out = s.release();
+        return SB_OK;
+    });
+}
+
+int sb_destroy(sb_solver *s) {
+    if (!s) return fail(SB_ERR_INVALID_ARG, "sb_destroy: null handle");
+    (void)hipSetDevice(s->desc.device);
+    if (s->stream) (void)hipStreamSynchronize(s->stream);
+    delete s;
+    return SB_OK;
+}
+
+int sb_set_particles(sb_solver *s, const float *pos, const float *vel, const float *inv_mass, int32_t n) {
+    if (!s || !pos || !inv_mass || n <= 0) return fail(SB_ERR_INVALID_ARG, "sb_set_particles: bad argument");
+    if (s->finalized) return fail(SB_ERR_STATE, "sb_set_particles after sb_finalize");
+    return guarded([&]() -> int {
+        for (int32_t p = 0; p < n; ++p) if (!(inv_mass[p] >= 0.0f)) return fail(SB_ERR_INVALID_ARG, "sb_set_particles: inverse mass must be >= 0");
+        s->n = n;
+        s->pos.assign(pos, pos + 3 * (size_t)n);
+        if (vel) s->vel.assign(vel, vel + 3 * (size_t)n); else s->vel.assign(3 * (size_t)n, 0.0f);
+        s->invm.assign(inv_mass, inv_mass + n);
+        return SB_OK;
+    });
+}
+
+int sb_set_rest_positions(sb_solver *s, const float *rest, int32_t n) {
+    if (!s || !rest) return fail(SB_ERR_INVALID_ARG, "sb_set_rest_positions: bad argument");
+    if (s->finalized) return fail(SB_ERR_STATE, "sb_set_rest_positions after sb_finalize");
+    if (n != s->n) return fail(SB_ERR_INVALID_ARG, "sb_set_rest_positions: n differs from sb_set_particles");
+    return guarded([&]() -> int { s->rest.assign(rest, rest + 3 * (size_t)n); return SB_OK; });
+}
+
+static int set_cons(sb_solver *s, const char *who, const int32_t *idx, const float *rest, int32_t m, float compliance,
+                    int type, int nv, int nrest) {
+    if (!s || m < 0 || (m > 0 && (!idx || !rest))) return fail(SB_ERR_INVALID_ARG, std::string(who) + ": bad argument");
+    if (s->finalized) return fail(SB_ERR_STATE, std::string(who) + " after sb_finalize");
+    if (s->n <= 0) return fail(SB_ERR_STATE, std::string(who) + " before sb_set_particles");
+    if (!(compliance >= 0.0f)) return fail(SB_ERR_INVALID_ARG, std::string(who) + ": compliance must be >= 0");
+    return guarded([&]() -> int {
+        for (int64_t k = 0; k < (int64_t)m * nv; ++k)
+            if (idx[k] < 0 || idx[k] >= s->n) return fail(SB_ERR_INVALID_ARG, std::string(who) + ": particle index out of range");
+        std::vector<int32_t> &I = type == 0 ? s->dist_ij : (type == 1 ? s->vol_ijkl : s->bend_ijkl);
+        std::vector<float> &R = type == 0 ? s->dist_rest : (type == 1 ? s->vol_rest : s->bend_rest);
+        I.assign(idx, idx + (size_t)m * nv);
+        R.assign(rest, rest + (size_t)m * nrest);
+        s->compliance[type] = compliance;
+        return SB_OK;
+    });
+}
+
+int sb_set_distance_constraints(sb_solver *s, const int32_t *ij, const float *rest_len, int32_t m, float compliance) {
+    return set_cons(s, "sb_set_distance_constraints", ij, rest_len, m, compliance, 0, 2, 1);
+}
+int sb_set_volume_constraints(sb_solver *s, const int32_t *ijkl, const float *rest_vol, int32_t m, float compliance) {
+    return set_cons(s, "sb_set_volume_constraints", ijkl, rest_vol, m, compliance, 1, 4, 1);
+}
+int sb_set_bending_constraints(sb_solver *s, const int32_t *ijkl, const float *rest_cs, int32_t m, float compliance) {
+    return set_cons(s, "sb_set_bending_constraints", ijkl, rest_cs, m, compliance, 2, 4, 2);
+}
+
+int sb_comm_unique_id(uint8_t out_id[SB_UNIQUE_ID_BYTES]) {
+    if (!out_id) return fail(SB_ERR_INVALID_ARG, "sb_comm_unique_id: null");
+    static_assert(sizeof(ncclUniqueId) <= SB_UNIQUE_ID_BYTES, "unique id size");
+    return guarded([&]() -> int {
+        ncclUniqueId id;
+        NCCL_CHECK(ncclGetUniqueId(&id));
+        std::memset(out_id, 0, SB_UNIQUE_ID_BYTES);
+        std::memcpy(out_id, &id, sizeof(id));
+        return SB_OK;
+    });
+}
+
+int sb_comm_init(sb_solver *s, const uint8_t id_bytes[SB_UNIQUE_ID_BYTES]) {
+    if (!s || !id_bytes) return fail(SB_ERR_INVALID_ARG, "sb_comm_init: null");
+    if (s->finalized) return fail(SB_ERR_STATE, "sb_comm_init after sb_finalize");
+    if (s->comm) return fail(SB_ERR_STATE, "sb_comm_init called twice");
+    return guarded([&]() -> int {
+        int rc = set_device(s); if (rc) return rc;
+        ncclUniqueId id;
+        std::memcpy(&id, id_bytes, sizeof(id));
+        NCCL_CHECK(ncclCommInitRank(&s->comm, s->desc.world, id, s->desc.rank));
+        return SB_OK;
+    });
+}
+
+int sb_finalize(sb_solver *s) {
+    if (!s) return fail(SB_ERR_INVALID_ARG, "sb_finalize: null handle");
+    if (s->finalized) return fail(SB_ERR_STATE, "sb_finalize called twice");
+    if (s->n <= 0) return fail(SB_ERR_STATE, "sb_finalize before sb_set_particles");
+    if (s->desc.world > 1 && !s->comm) return fail(SB_ERR_STATE, "sb_finalize: world > 1 needs sb_comm_init first");
+    return guarded([&]() -> int {
+        int rc = set_device(s); if (rc) return rc;
+        const std::vector<float> &rest = s->rest.empty() ? s->pos : s->rest;
+        sbp::Input in = make_input(rest.data(), s->n, s->dist_ij.data(), (int64_t)s->dist_rest.size(), s->vol_ijkl.data(),
+                                   (int64_t)s->vol_rest.size(), s->bend_ijkl.data(), (int64_t)s->bend_rest.size() / 2);
+        sbp::Opts o;
+        o.rank = s->desc.rank; o.world = s->desc.world;
+        for (int a = 0; a < 3; ++a) o.dims[a] = s->desc.part_dims[a];
+        o.tile_particles = s->desc.tile_particles;
+        s->plan = std::make_unique<sb_plan>();
+        sbp::build_plan(in, o, s->plan->plan);
+        sbp::extract_local(s->plan->plan, in, o.rank, s->plan->local);
+        build_device(s);
+        // opt in to the LDS size the largest tile needs
+        size_t max_lds = 0;
+        for (auto &D : s->phases) if (D->kind == 1) max_lds = std::max(max_lds, D->lds_bytes);
+        if (max_lds > 48 * 1024) {
+            HIP_CHECK(hipFuncSetAttribute((const void *)sbk::tile_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));
+            HIP_CHECK(hipFuncSetAttribute((const void *)sbk::tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));
+            HIP_CHECK(hipFuncSetAttribute((const void *)sbk::tile_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));
+        }
+        HIP_CHECK(hipDeviceSynchronize());
+        // authoring copies are no longer needed (keep rest values out of memory for 50M-constraint meshes)
+        std::vector<float>().swap(s->pos); std::vector<float>().swap(s->vel); std::vector<float>().swap(s->rest);
+        std::vector<int32_t>().swap(s->dist_ij); std::vector<int32_t>().swap(s->vol_ijkl); std::vector<int32_t>().swap(s->bend_ijkl);
+        std::vector<float>().swap(s->dist_rest); std::vector<float>().swap(s->vol_rest); std::vector<float>().swap(s->bend_rest);
+        s->finalized = true;
+        return SB_OK;
+    });
+}
+
+int sb_step(sb_solver *s, float dt, int32_t substeps) {
+    if (!s) return fail(SB_ERR_INVALID_ARG, "sb_step: null handle");
+    if (!s->finalized) return fail(SB_ERR_STATE, "sb_step before sb_finalize");
+    if (!(dt > 0.0f) || substeps <= 0) return fail(SB_ERR_INVALID_ARG, "sb_step: dt and substeps must be positive");
+    return guarded([&]() -> int {
+        int rc = set_device(s); if (rc) return rc;
+        upload_tick_params(s, dt, substeps);
+        const bool graph_ok = s->desc.use_graph && s->desc.world == 1;
+        if (!graph_ok) { enqueue_substeps(s, substeps); return SB_OK; }
+        auto it = s->graphs.find(substeps);
+        if (it == s->graphs.end()) {
+            hipGraph_t g = nullptr;
+            HIP_CHECK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+            try {
+                enqueue_substeps(s, substeps);
+            } catch (...) {
+                (void)hipStreamEndCapture(s->stream, &g);
+                if (g) (void)hipGraphDestroy(g);
+                throw;
+            }
+            HIP_CHECK(hipStreamEndCapture(s->stream, &g));
+            hipGraphExec_t ge = nullptr;
+            hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+            (void)hipGraphDestroy(g);
+            if (e != hipSuccess) throw HipError(SB_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+            it = s->graphs.emplace(substeps, ge).first;
+        }
+        HIP_CHECK(hipGraphLaunch(it->second, s->stream));
+        return SB_OK;
+    });
+}
+
+int sb_step_profiled(sb_solver *s, float dt, int32_t substeps, float *slot_ms, int32_t *slot_launches, int32_t n_slots) {
+    if (!s || !slot_ms || !slot_launches) return fail(SB_ERR_INVALID_ARG, "sb_step_profiled: null argument");
+    if (!s->finalized) return fail(SB_ERR_STATE, "sb_step_profiled before sb_finalize");
+    if (!(dt > 0.0f) || substeps <= 0) return fail(SB_ERR_INVALID_ARG, "sb_step_profiled: dt and substeps must be positive");
+    if (n_slots != (int32_t)s->phases.size() + 1) return fail(SB_ERR_INVALID_ARG, "sb_step_profiled: n_slots must be n_phases + 1");
+    return guarded([&]() -> int {
+        int rc = set_device(s); if (rc) return rc;
+        upload_tick_params(s, dt, substeps);
+        LaunchTimer lt; lt.stream = s->stream;
+        enqueue_substeps(s, substeps, &lt);
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        for (int k = 0; k < n_slots; ++k) { slot_ms[k] = 0.0f; slot_launches[k] = 0; }
+        for (size_t k = 0; k < lt.slot.size(); ++k) {
+            float ms = 0.0f;
+            HIP_CHECK(hipEventElapsedTime(&ms, lt.ev[2 * k], lt.ev[2 * k + 1]));
+            slot_ms[lt.slot[k]] += ms; ++slot_launches[lt.slot[k]];
+        }
+        return SB_OK;
+    });
+}
+
+int sb_synchronize(sb_solver *s) {
+    if (!s) return fail(SB_ERR_INVALID_ARG, "sb_synchronize: null handle");
+    return guarded([&]() -> int {
+        int rc = set_device(s); if (rc) return rc;
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        return SB_OK;
+    });
+}
+
+static int get_state(sb_solver *s, float *out, int32_t n, bool velocity) {
+    if (!s || !out) return fail(SB_ERR_INVALID_ARG, "sb_get_*: null argument");
+    if (!s->finalized) return fail(SB_ERR_STATE, "sb_get_* before sb_finalize");
+    if (n != s->n) return fail(SB_ERR_INVALID_ARG, "sb_get_*: n differs from sb_set_particles");
+    return guarded([&]() -> int {
+        int rc = set_device(s); if (rc) return rc;
+        const sbp::LocalPlan &L = s->plan->local;
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        if (velocity) {
+            std::vector<float> h((size_t)s->n_owned * 3);
+            if (s->n_owned) HIP_CHECK(hipMemcpy(h.data(), s->d_vel.p, h.size() * sizeof(float), hipMemcpyDeviceToHost));
+            for (int64_t l = 0; l < s->n_owned; ++l) {
+                int32_t o = L.local_to_old[l];
+                out[3 * (size_t)o] = h[3 * l]; out[3 * (size_t)o + 1] = h[3 * l + 1]; out[3 * (size_t)o + 2] = h[3 * l + 2];
+            }
+        } else {
+            s->h_stage.resize((size_t)s->n_owned);
+            if (s->n_owned) HIP_CHECK(hipMemcpy(s->h_stage.data(), s->d_pos.p, (size_t)s->n_owned * sizeof(float4), hipMemcpyDeviceToHost));
+            for (int64_t l = 0; l < s->n_owned; ++l) {
+                int32_t o = L.local_to_old[l];
+                const float4 v = s->h_stage[l];
+                out[3 * (size_t)o] = v.x; out[3 * (size_t)o + 1] = v.y; out[3 * (size_t)o + 2] = v.z;
+            }
+        }
+        return SB_OK;
+    });
+}
+
+int sb_get_positions(sb_solver *s, float *out, int32_t n) { return get_state(s, out, n, false); }
+int sb_get_velocities(sb_solver *s, float *out, int32_t n) { return get_state(s, out, n, true); }
+
+int sb_set_state(sb_solver *s, const float *pos, const float *vel, int32_t n) {
+    if (!s || !pos || !vel) return fail(SB_ERR_INVALID_ARG, "sb_set_state: null argument");
+    if (!s->finalized) return fail(SB_ERR_STATE, "sb_set_state before sb_finalize");
+    if (n != s->n) return fail(SB_ERR_INVALID_ARG, "sb_set_state: n differs from sb_set_particles");
+    return guarded([&]() -> int {
+        int rc = set_device(s); if (rc) return rc;
+        const sbp::LocalPlan &L = s->plan->local;
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        std::vector<float4> hp((size_t)s->n_local);
+        HIP_CHECK(hipMemcpy(hp.data(), s->d_pos.p, hp.size() * sizeof(float4), hipMemcpyDeviceToHost));
+        std::vector<float> hv((size_t)s->n_local * 3);
+        for (int64_t l = 0; l < s->n_local; ++l) {
+            int32_t o = L.local_to_old[l];
+            hp[l].x = pos[3 * (size_t)o]; hp[l].y = pos[3 * (size_t)o + 1]; hp[l].z = pos[3 * (size_t)o + 2];
+            for (int c = 0; c < 3; ++c) hv[3 * (size_t)l + c] = vel[3 * (size_t)o + c];
+        }
+        HIP_CHECK(hipMemcpy(s->d_pos.p, hp.data(), hp.size() * sizeof(float4), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(s->d_vel.p, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice));
+        return SB_OK;
+    });
+}
+
+int sb_get_owner(sb_solver *s, int32_t *owner, int32_t n) {
+    if (!s || !owner) return fail(SB_ERR_INVALID_ARG, "sb_get_owner: null argument");
+    if (!s->finalized) return fail(SB_ERR_STATE, "sb_get_owner before sb_finalize");
+    if (n != s->n) return fail(SB_ERR_INVALID_ARG, "sb_get_owner: n mismatch");
+    std::memcpy(owner, s->plan->plan.owner_of_old.data(), (size_t)n * sizeof(int32_t));
+    return SB_OK;
+}
+
+int sb_profile_begin(sb_solver *s) {
+    if (!s) return fail(SB_ERR_INVALID_ARG, "sb_profile_begin: null handle");
+    return guarded([&]() -> int {
+        int rc = set_device(s); if (rc) return rc;
+        HIP_CHECK(hipEventRecord(s->ev0, s->stream));
+        return SB_OK;
+    });
+}
+int sb_profile_end(sb_solver *s, float *ms) {
+    if (!s || !ms) return fail(SB_ERR_INVALID_ARG, "sb_profile_end: null argument");
+    return guarded([&]() -> int {
+        int rc = set_device(s); if (rc) return rc;
+        HIP_CHECK(hipEventRecord(s->ev1, s->stream));
+        HIP_CHECK(hipEventSynchronize(s->ev1));
+        HIP_CHECK(hipEventElapsedTime(ms, s->ev0, s->ev1));
+        return SB_OK;
+    });
+}
+
+int sb_get_stats(sb_solver *s, sb_stats *out) {
+    if (!s || !out) return fail(SB_ERR_INVALID_ARG, "sb_get_stats: null argument");
+    if (!s->finalized) return fail(SB_ERR_STATE, "sb_get_stats before sb_finalize");
+    std::memset(out, 0, sizeof(*out));
+    const sbp::Plan &P = s->plan->plan;
+    out->n_particles_owned = s->n_owned;
+    out->n_particles_local = s->n_local;
+    for (auto &D : s->phases) {
+        if (D->kind == 1) out->n_clusters += D->n_clusters;
+    }
+    const sbp::LocalPlan &L = s->plan->local;
+    for (size_t k = 0; k < L.order_mask.size(); ++k) if (L.order_mask[k]) ++out->n_constraints_local[P.order_type[k]];
+    out->n_phases = (int32_t)P.phases.size();
+    out->n_tile_phases = P.n_tile_phases;
+    out->n_global_colours = P.n_global_colours;
+    out->constraints_in_tiles = P.cons_in_tiles;
+    out->constraints_in_global = P.cons_in_global;
+    out->kernel_launches_per_substep = s->launches_per_substep;
+    out->halo_bytes_per_substep = s->halo_bytes_per_substep;
+    out->device_bytes = s->dev_bytes;
+    return SB_OK;
+}
+
+/* ---- plan inspection (host only) ---------------------------------------------------------------- */
+
+int sb_plan_build(const float *rest, int32_t n, const int32_t *dist_ij, int32_t m_d, const int32_t *vol, int32_t m_v,
+                  const int32_t *bend, int32_t m_b, const sb_plan_opts *opts, sb_plan **out) {
+    if (!rest || !out || n <= 0 || m_d < 0 || m_v < 0 || m_b < 0) return fail(SB_ERR_INVALID_ARG, "sb_plan_build: bad argument");
+    *out = nullptr;
+    return guarded([&]() -> int {
+        sbp::Opts o;
+        if (opts) {
+            o.rank = opts->rank; o.world = opts->world <= 0 ? 1 : opts->world;
+            for (int a = 0; a < 3; ++a) o.dims[a] = opts->part_dims[a];
+            o.tile_particles = opts->tile_particles == 0 ? 512 : opts->tile_particles;
+        }
+        sbp::Input in = make_input(rest, n, dist_ij, m_d, vol, m_v, bend, m_b);
+        auto p = std::make_unique<sb_plan>();
+        sbp::build_plan(in, o, p->plan);
+        sbp::extract_local(p->plan, in, o.rank, p->local);
+        *out = p.release();
+        return SB_OK;
+    });
+}
+int sb_plan_destroy(sb_plan *p) {
+    if (!p) return fail(SB_ERR_INVALID_ARG, "sb_plan_destroy: null");
+    delete p;
+    return SB_OK;
+}
+int sb_get_plan(sb_solver *s, const sb_plan **out) {
+    if (!s || !out) return fail(SB_ERR_INVALID_ARG, "sb_get_plan: null");
+    if (!s->finalized) return fail(SB_ERR_STATE, "sb_get_plan before sb_finalize");
+    *out = s->plan.get();
+    return SB_OK;
+}
+int64_t sb_plan_order_count(const sb_plan *p) { return p ? (int64_t)p->plan.order_id.size() : -1; }
+int sb_plan_get_order(const sb_plan *p, uint8_t *type_out, int32_t *id_out) {
+    if (!p || !type_out || !id_out) return fail(SB_ERR_INVALID_ARG, "sb_plan_get_order: null");
+    std::memcpy(type_out, p->plan.order_type.data(), p->plan.order_type.size());
+    std::memcpy(id_out, p->plan.order_id.data(), p->plan.order_id.size() * sizeof(int32_t));
+    return SB_OK;
+}
+int32_t sb_plan_phase_count(const sb_plan *p) { return p ? (int32_t)p->plan.phases.size() : -1; }
+int sb_plan_get_phases(const sb_plan *p, sb_phase_info *out) {
+    if (!p || !out) return fail(SB_ERR_INVALID_ARG, "sb_plan_get_phases: null");
+    for (size_t k = 0; k < p->plan.phases.size(); ++k) {
+        const sbp::Phase &F = p->plan.phases[k];
+        out[k].kind = F.kind; out[k].type = F.type;
+        out[k].order_begin = F.order_begin; out[k].order_end = F.order_end;
+        out[k].task_begin = F.task_begin; out[k].task_end = F.task_end;
+        out[k].needs_halo = F.needs_halo ? 1 : 0;
+    }
+    return SB_OK;
+}
+int64_t sb_plan_task_count(const sb_plan *p) { return p ? (int64_t)p->plan.task_off.size() - 1 : -1; }
+int sb_plan_get_tasks(const sb_plan *p, int64_t *out) {
+    if (!p || !out) return fail(SB_ERR_INVALID_ARG, "sb_plan_get_tasks: null");
+    std::memcpy(out, p->plan.task_off.data(), p->plan.task_off.size() * sizeof(int64_t));
+    return SB_OK;
+}
+int64_t sb_plan_group_count(const sb_plan *p) { return p ? (int64_t)p->plan.group_off.size() - 1 : -1; }
+int sb_plan_get_groups(const sb_plan *p, int64_t *out) {
+    if (!p || !out) return fail(SB_ERR_INVALID_ARG, "sb_plan_get_groups: null");
+    std::memcpy(out, p->plan.group_off.data(), p->plan.group_off.size() * sizeof(int64_t));
+    return SB_OK;
+}
+int sb_plan_get_owner(const sb_plan *p, int32_t *out) {
+    if (!p || !out) return fail(SB_ERR_INVALID_ARG, "sb_plan_get_owner: null");
+    std::memcpy(out, p->plan.owner_of_old.data(), p->plan.owner_of_old.size() * sizeof(int32_t));
+    return SB_OK;
+}
+int64_t sb_plan_local_count(const sb_plan *p, int64_t *owned_out) {
+    if (!p) return -1;
+    if (owned_out) *owned_out = p->local.n_owned;
+    return (int64_t)p->local.local_to_old.size();
+}
+int sb_plan_get_local_particles(const sb_plan *p, int32_t *out) {
+    if (!p || !out) return fail(SB_ERR_INVALID_ARG, "sb_plan_get_local_particles: null");
+    std::memcpy(out, p->local.local_to_old.data(), p->local.local_to_old.size() * sizeof(int32_t));
+    return SB_OK;
+}
+int sb_plan_halo_counts(const sb_plan *p, int32_t phase, int32_t *send_cnt, int32_t *recv_cnt) {
+    if (!p || !send_cnt || !recv_cnt) return fail(SB_ERR_INVALID_ARG, "sb_plan_halo_counts: null");
+    if (phase < 0 || phase >= (int32_t)p->local.phases.size()) return fail(SB_ERR_INVALID_ARG, "sb_plan_halo_counts: bad phase");
+    const sbp::LocalPhase &LP = p->local.phases[phase];
+    for (int r = 0; r < p->local.world; ++r) {
+        send_cnt[r] = (int32_t)LP.send_idx[r].size();
+        recv_cnt[r] = (int32_t)LP.recv_idx[r].size();
+    }
+    return SB_OK;
+}
+int sb_plan_get_halo(const sb_plan *p, int32_t phase, int32_t peer, int32_t *send_ids, int32_t *recv_ids) {
+    if (!p) return fail(SB_ERR_INVALID_ARG, "sb_plan_get_halo: null");
+    if (phase < 0 || phase >= (int32_t)p->local.phases.size() || peer < 0 || peer >= p->local.world)
+        return fail(SB_ERR_INVALID_ARG, "sb_plan_get_halo: bad phase/peer");
+    const sbp::LocalPhase &LP = p->local.phases[phase];
+    // published as caller-numbering (global) particle ids
+    if (send_ids) for (size_t k = 0; k < LP.send_idx[peer].size(); ++k) send_ids[k] = p->local.local_to_old[LP.send_idx[peer][k]];
+    if (recv_ids) for (size_t k = 0; k < LP.recv_idx[peer].size(); ++k) recv_ids[k] = p->local.local_to_old[LP.recv_idx[peer][k]];
+    return SB_OK;
+}
+int sb_plan_get_local_order_mask(const sb_plan *p, uint8_t *out) {
+    if (!p || !out) return fail(SB_ERR_INVALID_ARG, "sb_plan_get_local_order_mask: null");
+    std::memcpy(out, p->local.order_mask.data(), p->local.order_mask.size());
+    return SB_OK;
+}
+
+}  // extern "C"

@@ -32,20 +32,15 @@ class SoftbodyMesh:
 def jelly_cube(n, spacing=1.0, perturb=0.05, seed=1234, pin_top=False, stencil="structural"):
     """n^3 lattice, index (iz*n+iy)*n+ix, structural springs x-dir then y then z (SPEC.md §7)."""
     assert n >= 2
-    ix, iy, iz = np.meshgrid(np.arange(n), np.arange(n), np.arange(n), indexing="ij")
-    # index order: ix fastest
-    idx = ((iz * n + iy) * n + ix)
-    rest = np.zeros((n ** 3, 3), np.float32)
-    rest[idx.ravel(), 0] = (ix.ravel() * spacing)
-    rest[idx.ravel(), 1] = (iy.ravel() * spacing)
-    rest[idx.ravel(), 2] = (iz.ravel() * spacing)
-    rng = np.random.default_rng(seed)
-    jitter = rng.uniform(-perturb, perturb, size=(n ** 3, 3)) * spacing
-    pos = (rest.astype(np.float64) + jitter).astype(np.float32)
     lin = np.arange(n ** 3, dtype=np.int64)
     cx = lin % n
     cy = (lin // n) % n
     cz = lin // (n * n)
+    rest = np.stack([cx, cy, cz], axis=1).astype(np.float32) * np.float32(spacing)
+    rng = np.random.default_rng(seed)
+    jitter = rng.uniform(-perturb, perturb, size=(n ** 3, 3)) * spacing
+    pos = (rest.astype(np.float64) + jitter).astype(np.float32)
+    del jitter
     edges = []
     for mask, off in ((cx < n - 1, 1), (cy < n - 1, n), (cz < n - 1, n * n)):
         lo = lin[mask]
@@ -63,7 +58,10 @@ def jelly_cube(n, spacing=1.0, perturb=0.05, seed=1234, pin_top=False, stencil="
                     lo = lin[m]
                     edges.append(np.stack([lo, lo + dx + dy * n + dz * n * n], axis=1))
     ij = np.concatenate(edges).astype(np.int32)
-    rest_len = np.linalg.norm(rest[ij[:, 0]].astype(np.float64) - rest[ij[:, 1]].astype(np.float64), axis=1).astype(np.float32)
+    if stencil == "full":
+        rest_len = np.linalg.norm(rest[ij[:, 0]].astype(np.float64) - rest[ij[:, 1]].astype(np.float64), axis=1).astype(np.float32)
+    else:
+        rest_len = np.full(ij.shape[0], spacing, np.float32)   # axis springs: L0 = spacing (SPEC.md §7)
     w = np.ones(n ** 3, np.float32)
     if pin_top:
         w[cy == n - 1] = 0.0

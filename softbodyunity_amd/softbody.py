@@ -1,0 +1,150 @@
+"""Host-side mirror of the Unity `Softbody : MonoBehaviour` component (csharp/Softbody.cs).
+
+Same member names and call order as the C# component the north star asks for (BASELINE.json:5):
+Start() -> sb_create + sb_set_* + sb_finalize, FixedUpdate() -> sb_step + sb_get_positions,
+OnDestroy() -> sb_destroy. No reference component exists to copy (/root/reference/README.md:1 is
+the whole reference tree). All compute happens in the HIP plugin; there is no CPU path here.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import native
+from .native import check, f32, i32, ptr
+
+
+class Softbody:
+    # [SerializeField] block of csharp/Softbody.cs
+    def __init__(self, mesh, substeps=20, fixed_delta_time=0.02, gravity=(0.0, -9.81, 0.0), damping=0.0,
+                 distance_compliance=0.0, volume_compliance=0.0, bending_compliance=0.0, device=0, rank=0, world=1,
+                 part_dims=(0, 0, 0), tile_particles=512, use_graph=True, unique_id=None):
+        self.mesh = mesh
+        self.substeps = int(substeps)
+        self.fixed_delta_time = float(fixed_delta_time)
+        self.gravity = tuple(float(g) for g in gravity)
+        self.damping = float(damping)
+        self.compliance = (float(distance_compliance), float(volume_compliance), float(bending_compliance))
+        self.device, self.rank, self.world = int(device), int(rank), int(world)
+        self.part_dims = tuple(int(d) for d in part_dims)
+        self.tile_particles = int(tile_particles)
+        self.use_graph = bool(use_graph)
+        self.unique_id = unique_id
+        self._h = None
+        self.vertices = None  # what the C# component assigns to mesh.vertices after each FixedUpdate
+
+    # ---- MonoBehaviour surface ------------------------------------------------------------------
+    def Start(self):
+        L = native.lib()
+        d = native.SbDesc()
+        L.sb_desc_default(C.byref(d))
+        d.device, d.rank, d.world = self.device, self.rank, self.world
+        d.part_dims[:] = self.part_dims
+        d.gravity[:] = self.gravity
+        d.damping = self.damping
+        d.tile_particles = self.tile_particles
+        d.use_graph = 1 if self.use_graph else 0
+        h = C.c_void_p()
+        check(L.sb_create(C.byref(d), C.byref(h)))
+        self._h = h
+        m = self.mesh
+        pos = f32(m.pos, (-1, 3)); vel = f32(m.vel, (-1, 3)); w = f32(m.inv_mass, (-1,))
+        self.n = pos.shape[0]
+        check(L.sb_set_particles(h, ptr(pos), ptr(vel), ptr(w), self.n))
+        if m.rest_pos is not None:
+            rest = f32(m.rest_pos, (-1, 3))
+            check(L.sb_set_rest_positions(h, ptr(rest), self.n))
+        if len(m.dist_rest):
+            ij = i32(m.dist_ij, (-1, 2)); r = f32(m.dist_rest, (-1,))
+            check(L.sb_set_distance_constraints(h, ptr(ij), ptr(r), r.shape[0], self.compliance[0]))
+        if len(m.vol_rest):
+            q = i32(m.vol_ijkl, (-1, 4)); r = f32(m.vol_rest, (-1,))
+            check(L.sb_set_volume_constraints(h, ptr(q), ptr(r), r.shape[0], self.compliance[1]))
+        if len(m.bend_rest):
+            q = i32(m.bend_ijkl, (-1, 4)); r = f32(m.bend_rest, (-1, 2))
+            check(L.sb_set_bending_constraints(h, ptr(q), ptr(r), r.shape[0], self.compliance[2]))
+        if self.world > 1:
+            assert self.unique_id is not None and len(self.unique_id) == native.SB_UNIQUE_ID_BYTES
+            buf = (C.c_uint8 * native.SB_UNIQUE_ID_BYTES)(*self.unique_id)
+            check(L.sb_comm_init(h, buf))
+        check(L.sb_finalize(h))
+        self.vertices = pos.copy()
+        return self
+
+    def FixedUpdate(self, readback=True):
+        check(native.lib().sb_step(self._h, self.fixed_delta_time, self.substeps))
+        if readback:
+            self.get_positions(self.vertices)
+        return self.vertices
+
+    def OnDestroy(self):
+        if self._h is not None:
+            native.lib().sb_destroy(self._h)
+            self._h = None
+
+    # ---- plumbing ---------------------------------------------------------------------------------
+    def __enter__(self):
+        return self.Start()
+
+    def __exit__(self, *a):
+        self.OnDestroy()
+
+    def step(self, dt=None, substeps=None):
+        check(native.lib().sb_step(self._h, self.fixed_delta_time if dt is None else dt,
+                                   self.substeps if substeps is None else substeps))
+
+    def synchronize(self):
+        check(native.lib().sb_synchronize(self._h))
+
+    def get_positions(self, out=None):
+        out = np.zeros((self.n, 3), np.float32) if out is None else out
+        check(native.lib().sb_get_positions(self._h, ptr(out), self.n))
+        return out
+
+    def get_velocities(self, out=None):
+        out = np.zeros((self.n, 3), np.float32) if out is None else out
+        check(native.lib().sb_get_velocities(self._h, ptr(out), self.n))
+        return out
+
+    def set_state(self, pos, vel):
+        pos = f32(pos, (-1, 3)); vel = f32(vel, (-1, 3))
+        check(native.lib().sb_set_state(self._h, ptr(pos), ptr(vel), self.n))
+
+    def owner(self):
+        out = np.zeros(self.n, np.int32)
+        check(native.lib().sb_get_owner(self._h, ptr(out), self.n))
+        return out
+
+    def stats(self):
+        st = native.SbStats()
+        check(native.lib().sb_get_stats(self._h, C.byref(st)))
+        return st.as_dict()
+
+    def plan(self):
+        h = C.c_void_p()
+        check(native.lib().sb_get_plan(self._h, C.byref(h)))
+        p = native.Plan(h.value, False)
+        p.n = self.n
+        p.world = self.world
+        return p
+
+    def step_profiled(self, dt=None, substeps=None):
+        """One eager tick with HIP events around every launch -> (ms per slot, launches per slot)."""
+        k = self.stats()["n_phases"] + 1
+        ms = np.zeros(k, np.float32); cnt = np.zeros(k, np.int32)
+        check(native.lib().sb_step_profiled(self._h, self.fixed_delta_time if dt is None else dt,
+                                            self.substeps if substeps is None else substeps, ptr(ms), ptr(cnt), k))
+        return ms, cnt
+
+    def profile_begin(self):
+        check(native.lib().sb_profile_begin(self._h))
+
+    def profile_end(self):
+        ms = C.c_float()
+        check(native.lib().sb_profile_end(self._h, C.byref(ms)))
+        return ms.value
+
+
+def comm_unique_id():
+    buf = (C.c_uint8 * native.SB_UNIQUE_ID_BYTES)()
+    check(native.lib().sb_comm_unique_id(buf))
+    return bytes(buf)

@@ -1,0 +1,176 @@
+"""GPU parity: the HIP plugin, called through the C ABI, against the CPU oracle on identical meshes and
+the published schedule. Stated tolerance (BASELINE.json:5): max_i |x_i - x_i^oracle|_2 / diag(bbox0) <= 1e-4;
+SPEC.md §1 additionally makes bit-for-bit agreement the expected outcome, which is asserted where noted."""
+import numpy as np
+import pytest
+
+from softbodyunity_amd import Softbody, native
+from softbodyunity_amd.mesh import bunny_surrogate, jelly_cube
+from helpers import make_oracle
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-4
+
+
+def _run_pair(oracle_mod, mesh, ticks, substeps, dt=0.02, compliance=(0.0, 0.0, 0.0), damping=0.0, **kw):
+    sb = Softbody(mesh, substeps=substeps, fixed_delta_time=dt, damping=damping, distance_compliance=compliance[0],
+                  volume_compliance=compliance[1], bending_compliance=compliance[2], **kw).Start()
+    try:
+        o = make_oracle(oracle_mod, mesh, sb.plan(), damping=damping, compliance=compliance)
+        for _ in range(ticks):
+            sb.FixedUpdate(readback=False)
+            o.step(dt, substeps)
+        x = sb.get_positions(); v = sb.get_velocities()
+        st = sb.stats()
+    finally:
+        sb.OnDestroy()
+    rel, mabs, bit = oracle_mod.parity_error(x, o.x, mesh.pos)
+    return rel, mabs, bit, x, v, o, st
+
+
+@pytest.mark.parametrize("tile", [512, 64, -1])
+def test_cfg1_cube8_10substeps(oracle_mod, tile):
+    # BASELINE.json:7 — 8x8x8 jelly cube, 512 particles, 1344 springs, 10 substeps
+    mesh = jelly_cube(8)
+    rel, mabs, bit, x, v, o, st = _run_pair(oracle_mod, mesh, ticks=20, substeps=10, tile_particles=tile)
+    assert rel <= TOL, (rel, mabs)
+    assert bit, f"expected bit-exact positions (SPEC.md §1), max abs diff {mabs}"
+    assert np.array_equal(v.view(np.uint32), o.v.view(np.uint32))
+
+
+def test_cfg1_golden_fixture(oracle_mod):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cube8_s10_t5.npz"))
+    mesh = jelly_cube(8)
+    sb = Softbody(mesh, substeps=10).Start()
+    try:
+        t, ids = sb.plan().order()
+        assert np.array_equal(ids, g["order_id"]), "schedule changed: regenerate tests/golden (see make_golden.py)"
+        for _ in range(5):
+            sb.FixedUpdate(readback=False)
+        x = sb.get_positions()
+    finally:
+        sb.OnDestroy()
+    rel, mabs, bit = oracle_mod.parity_error(x, g["x"], mesh.pos)
+    assert rel <= TOL and bit
+
+
+@pytest.mark.parametrize("tile,graph", [(512, True), (512, False), (-1, True)])
+def test_cfg2_cube64_20substeps(oracle_mod, tile, graph):
+    # BASELINE.json:8 — 64^3 jelly cube, 20 substeps, 1 GPU, fp32
+    mesh = jelly_cube(64)
+    rel, mabs, bit, x, v, o, st = _run_pair(oracle_mod, mesh, ticks=3, substeps=20, tile_particles=tile, use_graph=graph)
+    assert rel <= TOL, (rel, mabs)
+    assert bit, f"max abs diff {mabs}"
+    if tile > 0:
+        assert st["n_tile_phases"] == 2 and st["n_global_colours"] == 0
+
+
+def test_pinned_top_layer_and_damping_and_compliance(oracle_mod):
+    mesh = jelly_cube(20, pin_top=True)
+    rel, mabs, bit, x, v, o, st = _run_pair(oracle_mod, mesh, ticks=10, substeps=8, compliance=(1e-6, 0, 0), damping=0.5,
+                                            tile_particles=128)
+    assert rel <= TOL and bit
+    top = mesh.inv_mass == 0
+    assert np.array_equal(x[top], mesh.pos[top])
+
+
+def test_full_stencil_mixed_tile_and_global(oracle_mod):
+    mesh = jelly_cube(14, stencil="full")
+    rel, mabs, bit, x, v, o, st = _run_pair(oracle_mod, mesh, ticks=5, substeps=10, tile_particles=64, compliance=(1e-7, 0, 0))
+    assert st["n_global_colours"] > 0 and st["constraints_in_tiles"] > 0
+    assert rel <= TOL and bit
+
+
+def test_changing_dt_and_substeps_between_ticks(oracle_mod):
+    mesh = jelly_cube(10)
+    sb = Softbody(mesh).Start()
+    try:
+        o = make_oracle(oracle_mod, mesh, sb.plan())
+        for dt, S in ((0.02, 10), (0.01, 4), (0.02, 10), (1 / 60, 7)):
+            sb.step(dt, S); o.step(dt, S)
+        x = sb.get_positions()
+    finally:
+        sb.OnDestroy()
+    rel, mabs, bit = oracle_mod.parity_error(x, o.x, mesh.pos)
+    assert rel <= TOL and bit
+
+
+def test_state_round_trip(oracle_mod):
+    # download -> upload -> step == step
+    mesh = jelly_cube(12)
+    a = Softbody(mesh, substeps=10).Start(); b = Softbody(mesh, substeps=10).Start()
+    try:
+        a.step(); b.step()
+        b.set_state(b.get_positions(), b.get_velocities())
+        a.step(); b.step()
+        assert np.array_equal(a.get_positions().view(np.uint32), b.get_positions().view(np.uint32))
+    finally:
+        a.OnDestroy(); b.OnDestroy()
+
+
+@pytest.fixture(scope="module")
+def bunny20k():
+    return bunny_surrogate(target_verts=20000, seed=1234)
+
+
+@pytest.mark.parametrize("tile", [256, -1])
+def test_cfg5_surrogate_volume_bending(oracle_mod, bunny20k, tile):
+    # BASELINE.json:11 (single-GPU part): irregular tet mesh SURROGATE with distance+volume+bending
+    mesh = bunny20k
+    comp = (1e-7, 1e-7, 1e-4)
+    rel, mabs, bit, x, v, o, st = _run_pair(oracle_mod, mesh, ticks=5, substeps=10, compliance=comp, tile_particles=tile)
+    assert st["n_constraints_local"][1] == len(mesh.vol_rest) and st["n_constraints_local"][2] == len(mesh.bend_rest)
+    assert np.isfinite(x).all()
+    assert rel <= TOL, (rel, mabs)
+    assert bit, f"max abs diff {mabs}"
+
+
+def test_rest_lattice_is_a_bitwise_fixed_point_on_gpu():
+    mesh = jelly_cube(16, perturb=0.0)
+    sb = Softbody(mesh, gravity=(0, 0, 0), substeps=10).Start()
+    try:
+        for _ in range(5):
+            sb.step()
+        assert np.array_equal(sb.get_positions().view(np.uint32), mesh.pos.view(np.uint32))
+        assert not sb.get_velocities().any()
+    finally:
+        sb.OnDestroy()
+
+
+def test_error_paths_through_the_abi():
+    import ctypes as C
+    L = native.lib()
+    d = native.SbDesc(); L.sb_desc_default(C.byref(d))
+    h = C.c_void_p()
+    assert L.sb_create(C.byref(d), C.byref(h)) == 0
+    assert L.sb_step(h, 0.02, 10) == native.SB_ERR_STATE
+    assert L.sb_finalize(h) == native.SB_ERR_STATE
+    pos = np.zeros((4, 3), np.float32); w = np.ones(4, np.float32)
+    assert L.sb_set_particles(h, native.ptr(pos), None, native.ptr(w), 4) == 0
+    ij = np.array([[0, 9]], np.int32); r = np.ones(1, np.float32)
+    assert L.sb_set_distance_constraints(h, native.ptr(ij), native.ptr(r), 1, 0.0) == native.SB_ERR_INVALID_ARG
+    assert b"out of range" in L.sb_last_error()
+    assert L.sb_destroy(h) == 0
+    d.device = 99
+    assert L.sb_create(C.byref(d), C.byref(h)) == native.SB_ERR_NO_DEVICE
+
+
+def test_large_cube_properties():
+    # 128^3 (2.1M particles): size-independent properties instead of an oracle run —
+    # momentum: with g=0 and equal masses the centre of mass stays put; pinned lattice at rest is a fixed point
+    mesh = jelly_cube(128)
+    sb = Softbody(mesh, gravity=(0, 0, 0), substeps=20).Start()
+    try:
+        c0 = mesh.pos.astype(np.float64).mean(0)
+        for _ in range(3):
+            sb.step()
+        x = sb.get_positions()
+        assert np.isfinite(x).all()
+        assert np.abs(x.astype(np.float64).mean(0) - c0).max() < 1e-4
+        # springs relax towards rest length
+        d0 = np.linalg.norm(mesh.pos[mesh.dist_ij[:, 0]] - mesh.pos[mesh.dist_ij[:, 1]], axis=1) - 1.0
+        d1 = np.linalg.norm(x[mesh.dist_ij[:, 0]] - x[mesh.dist_ij[:, 1]], axis=1) - 1.0
+        assert np.abs(d1).mean() < 0.5 * np.abs(d0).mean()
+    finally:
+        sb.OnDestroy()

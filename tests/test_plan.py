@@ -1,0 +1,117 @@
+"""Planner invariants the GPU execution relies on (SPEC.md §3) — pure host code, runs without a GPU."""
+import numpy as np
+import pytest
+
+from softbodyunity_amd.mesh import bunny_surrogate, jelly_cube
+from helpers import build_plan, cons_vertices, make_oracle, run_partitioned
+
+
+def _check_plan(mesh, plan):
+    t, ids = plan.order()
+    m = [len(mesh.dist_rest), len(mesh.vol_rest), len(mesh.bend_rest)]
+    assert len(ids) == sum(m)
+    for ty in range(3):   # a permutation of every type's constraints
+        assert np.array_equal(np.sort(ids[t == ty]), np.arange(m[ty]))
+    arr = [mesh.dist_ij, mesh.vol_ijkl, mesh.bend_ijkl]
+    # groups are vertex-disjoint (the GPU runs a group's constraints concurrently)
+    g = plan.groups()
+    assert g[0] == 0 and g[-1] == len(ids) and np.all(np.diff(g) > 0)
+    for a, b in zip(g[:-1], g[1:]):
+        assert len(set(t[a:b])) == 1
+        vs = arr[t[a]][ids[a:b]].ravel()
+        assert len(np.unique(vs)) == len(vs), "colour class is not a matching"
+    # tasks of one phase touch disjoint particles (the GPU runs tiles of a phase concurrently)
+    tasks = plan.tasks()
+    for ph in plan.phases():
+        seen = np.zeros(mesh.n, np.int64) - 1
+        for tk in range(ph["task_begin"], ph["task_end"]):
+            a, b = tasks[tk], tasks[tk + 1]
+            vs = np.unique(np.concatenate([arr[ty][ids[a:b][t[a:b] == ty]].ravel() for ty in range(3)]))
+            assert np.all((seen[vs] == -1)), "two tasks of one phase share a particle"
+            seen[vs] = tk
+
+
+@pytest.mark.parametrize("n,tile", [(8, 512), (12, 64), (17, 512), (20, -1)])
+def test_cube_plan_invariants(n, tile):
+    mesh = jelly_cube(n)
+    _check_plan(mesh, build_plan(mesh, tile_particles=tile))
+
+
+def test_cube_64_structure():
+    mesh = jelly_cube(64)
+    plan = build_plan(mesh)
+    ph = plan.phases()
+    assert [p["kind"] for p in ph] == [1, 1]                     # two tile phases, nothing left for global colours
+    assert ph[0]["task_end"] - ph[0]["task_begin"] == 512        # 8^3 cells of 8^3 particles
+    assert ph[0]["order_end"] == 512 * 1344                      # all in-cell springs
+    assert ph[1]["order_end"] == 3 * 64 * 64 * 63
+
+
+def test_full_stencil_cube_uses_global_colours_and_stays_valid():
+    mesh = jelly_cube(10, stencil="full")
+    plan = build_plan(mesh, tile_particles=64)
+    _check_plan(mesh, plan)
+    assert any(p["kind"] == 0 for p in plan.phases())            # diagonal springs crossing two cut planes
+
+
+@pytest.fixture(scope="module")
+def small_bunny():
+    return bunny_surrogate(target_verts=1500, seed=5)
+
+
+def test_irregular_mesh_plan_invariants(small_bunny):
+    assert len(small_bunny.vol_rest) and len(small_bunny.bend_rest)
+    _check_plan(small_bunny, build_plan(small_bunny, tile_particles=128))
+    _check_plan(small_bunny, build_plan(small_bunny, tile_particles=-1))
+
+
+def test_parallel_oracle_equals_sequential(oracle_mod, small_bunny):
+    for mesh, tile in ((jelly_cube(12), 64), (small_bunny, 128)):
+        plan = build_plan(mesh, tile_particles=tile)
+        a = make_oracle(oracle_mod, mesh, plan); b = make_oracle(oracle_mod, mesh, plan)
+        for _ in range(2):
+            a.step(0.02, 10); b.step(0.02, 10, parallel=True)
+        assert np.array_equal(a.x.view(np.uint32), b.x.view(np.uint32))
+
+
+@pytest.mark.parametrize("world,dims,tile", [(2, (0, 0, 0), 64), (4, (2, 2, 1), 64), (8, (2, 2, 2), 64), (8, (0, 0, 0), -1),
+                                             (2, (1, 2, 1), 512)])
+def test_kat9_partition_invariance_cube(oracle_mod, world, dims, tile):
+    mesh = jelly_cube(16, pin_top=True)
+    plan = build_plan(mesh, tile_particles=tile)
+    ref = make_oracle(oracle_mod, mesh, plan)
+    ref.step(0.02, 5)
+    x, v, ranks = run_partitioned(oracle_mod, mesh, world, dims, ticks=1, substeps=5, tile=tile)
+    assert np.array_equal(x.view(np.uint32), ref.x.view(np.uint32))
+    assert np.array_equal(v.view(np.uint32), ref.v.view(np.uint32))
+    # every particle has exactly one owner and ranks' owned sets partition the mesh
+    owned = np.stack([r.owned for r in ranks])
+    assert np.all(owned.sum(0) == 1)
+    # published order is rank independent
+    t0, i0 = ranks[0].plan.order()
+    for r in ranks[1:]:
+        t1, i1 = r.plan.order()
+        assert np.array_equal(t0, t1) and np.array_equal(i0, i1)
+
+
+def test_kat9_partition_invariance_irregular(oracle_mod, small_bunny):
+    mesh = small_bunny
+    for tile in (128, -1):
+        plan = build_plan(mesh, tile_particles=tile)
+        ref = make_oracle(oracle_mod, mesh, plan, compliance=(1e-7, 1e-7, 1e-5))
+        ref.step(0.02, 4)
+        x, v, _ = run_partitioned(oracle_mod, mesh, 4, (0, 0, 0), ticks=1, substeps=4, tile=tile, compliance=(1e-7, 1e-7, 1e-5))
+        assert np.array_equal(x.view(np.uint32), ref.x.view(np.uint32))
+
+
+def test_plan_rejects_bad_input():
+    from softbodyunity_amd import native
+    mesh = jelly_cube(4)
+    bad = mesh.dist_ij.copy(); bad[3, 1] = 4 ** 3
+    with pytest.raises(native.SoftbodyError):
+        native.Plan.build(mesh.rest_pos, bad)
+    bad = mesh.dist_ij.copy(); bad[3, 1] = bad[3, 0]
+    with pytest.raises(native.SoftbodyError):
+        native.Plan.build(mesh.rest_pos, bad)
+    with pytest.raises(native.SoftbodyError):
+        native.Plan.build(mesh.rest_pos, mesh.dist_ij, world=3, part_dims=(2, 2, 1))
