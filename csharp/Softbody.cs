@@ -1,0 +1,126 @@
+// Softbody.cs — the Unity component whose FixedUpdate path this repository accelerates.
+//
+// Start()       -> sb_create + sb_set_particles/sb_set_*_constraints + sb_finalize   (plan, upload, capture)
+// FixedUpdate() -> sb_step(Time.fixedDeltaTime, substeps) + sb_get_positions         (one tick, SPEC.md §2)
+// OnDestroy()   -> sb_destroy
+//
+// `useGpu = false` runs the same tick on the CPU through SoftbodyCpuSolver (the C# restatement of
+// SPEC.md, in the schedule the plugin publishes) — the "reference C# CPU FixedUpdate path" that
+// BASELINE.json:5 compares against. The reference repository ships no such component
+// (/root/reference/README.md:1 is its only line); names follow Unity conventions.
+//
+// NOT COMPILED IN THIS ENVIRONMENT (no C# toolchain, no UnityEngine.dll). softbodyunity_amd/softbody.py
+// is the line-for-line Python mirror the tests drive.
+using System;
+using System.Runtime.InteropServices;
+using UnityEngine;
+
+namespace SoftbodyMI355X
+{
+    [RequireComponent(typeof(MeshFilter))]
+    public class Softbody : MonoBehaviour
+    {
+        [Header("Solver")]
+        [SerializeField] int substeps = 20;
+        [SerializeField] Vector3 gravity = new Vector3(0f, -9.81f, 0f);
+        [SerializeField] float damping = 0f;
+        [SerializeField] float distanceCompliance = 0f;
+        [SerializeField] float volumeCompliance = 0f;
+        [SerializeField] float bendingCompliance = 0f;
+        [Header("Device")]
+        [SerializeField] bool useGpu = true;
+        [SerializeField] int device = 0;
+        [SerializeField] int tileParticles = 512;
+
+        // constraint graph (filled by an authoring script or SoftbodyMeshBuilder before Start)
+        public Vector3[] restPositions;
+        public Vector3[] positions;
+        public Vector3[] velocities;
+        public float[] inverseMass;
+        public int[] distanceIJ; public float[] distanceRest;
+        public int[] volumeIJKL; public float[] volumeRest;
+        public int[] bendingIJKL; public float[] bendingRestCosSin;
+
+        IntPtr handle = IntPtr.Zero;
+        SoftbodyCpuSolver cpu;
+        Mesh mesh;
+        GCHandle posPin;
+
+        void Start()
+        {
+            mesh = GetComponent<MeshFilter>().mesh;
+            if (positions == null) { positions = mesh.vertices; restPositions = mesh.vertices; }
+            int n = positions.Length;
+            if (velocities == null) velocities = new Vector3[n];
+            if (inverseMass == null) { inverseMass = new float[n]; for (int i = 0; i < n; ++i) inverseMass[i] = 1f; }
+
+            var d = new SbDesc();
+            SoftbodyNative.sb_desc_default(ref d);
+            d.device = device; d.rank = 0; d.world = 1;
+            d.gravityX = gravity.x; d.gravityY = gravity.y; d.gravityZ = gravity.z;
+            d.damping = damping; d.tileParticles = tileParticles;
+            SoftbodyNative.Check(SoftbodyNative.sb_create(ref d, out handle), "sb_create");
+
+            // Vector3 is a blittable sequential struct of 3 floats: Vector3[] pins directly to float xyz
+            Pin(positions, p => Pin(velocities, v => Pin(inverseMass, w =>
+                SoftbodyNative.Check(SoftbodyNative.sb_set_particles(handle, p, v, w, n), "sb_set_particles"))));
+            if (restPositions != null)
+                Pin(restPositions, r => SoftbodyNative.Check(SoftbodyNative.sb_set_rest_positions(handle, r, n), "sb_set_rest_positions"));
+            if (distanceRest != null && distanceRest.Length > 0)
+                Pin(distanceIJ, i => Pin(distanceRest, r => SoftbodyNative.Check(
+                    SoftbodyNative.sb_set_distance_constraints(handle, i, r, distanceRest.Length, distanceCompliance), "sb_set_distance_constraints")));
+            if (volumeRest != null && volumeRest.Length > 0)
+                Pin(volumeIJKL, i => Pin(volumeRest, r => SoftbodyNative.Check(
+                    SoftbodyNative.sb_set_volume_constraints(handle, i, r, volumeRest.Length, volumeCompliance), "sb_set_volume_constraints")));
+            if (bendingRestCosSin != null && bendingRestCosSin.Length > 0)
+                Pin(bendingIJKL, i => Pin(bendingRestCosSin, r => SoftbodyNative.Check(
+                    SoftbodyNative.sb_set_bending_constraints(handle, i, r, bendingRestCosSin.Length / 2, bendingCompliance), "sb_set_bending_constraints")));
+            SoftbodyNative.Check(SoftbodyNative.sb_finalize(handle), "sb_finalize");
+
+            if (!useGpu)
+            {
+                // CPU path walks the order the plugin's planner published (SPEC.md §3)
+                SoftbodyNative.Check(SoftbodyNative.sb_get_plan(handle, out IntPtr plan), "sb_get_plan");
+                long m = SoftbodyNative.sb_plan_order_count(plan);
+                var type = new byte[m]; var id = new int[m];
+                Pin(type, t => Pin(id, i => SoftbodyNative.Check(SoftbodyNative.sb_plan_get_order(plan, t, i), "sb_plan_get_order")));
+                cpu = new SoftbodyCpuSolver(this, type, id);
+            }
+            posPin = GCHandle.Alloc(positions, GCHandleType.Pinned);
+        }
+
+        void FixedUpdate()
+        {
+            if (useGpu)
+            {
+                SoftbodyNative.Check(SoftbodyNative.sb_step(handle, Time.fixedDeltaTime, substeps), "sb_step");
+                SoftbodyNative.Check(SoftbodyNative.sb_get_positions(handle, posPin.AddrOfPinnedObject(), positions.Length), "sb_get_positions");
+            }
+            else
+            {
+                cpu.Step(Time.fixedDeltaTime, substeps);
+            }
+            mesh.vertices = positions;
+            mesh.RecalculateNormals();
+        }
+
+        void OnDestroy()
+        {
+            if (posPin.IsAllocated) posPin.Free();
+            if (handle != IntPtr.Zero) { SoftbodyNative.sb_destroy(handle); handle = IntPtr.Zero; }
+        }
+
+        // accessors for SoftbodyCpuSolver
+        internal Vector3 Gravity => gravity;
+        internal float Damping => damping;
+        internal float ComplianceD => distanceCompliance;
+        internal float ComplianceV => volumeCompliance;
+        internal float ComplianceB => bendingCompliance;
+
+        static void Pin<T>(T[] a, Action<IntPtr> f)
+        {
+            var h = GCHandle.Alloc(a, GCHandleType.Pinned);
+            try { f(h.AddrOfPinnedObject()); } finally { h.Free(); }
+        }
+    }
+}

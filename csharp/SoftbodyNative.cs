@@ -1,0 +1,108 @@
+// SoftbodyNative.cs — P/Invoke layer over libsoftbody_mi355x.so (include/softbody.h, ABI version 1).
+//
+// One [DllImport] per exported function, same name and argument order as the header; the Python twin
+// used by the test-suite is softbodyunity_amd/native.py (tests/test_abi.py keeps the three in sync).
+// The reference repository holds no C# to mirror (/root/reference/README.md:1 is its only line), so
+// this file is the builder-defined binding SURVEY.md §8b calls for.
+//
+// NOT COMPILED IN THIS ENVIRONMENT: no C# toolchain (dotnet/mono/mcs/csc) and no UnityEngine.dll exist
+// in the build image; see INTEGRATION.md.
+using System;
+using System.Runtime.InteropServices;
+
+namespace SoftbodyMI355X
+{
+    [StructLayout(LayoutKind.Sequential)]
+    public struct SbDesc
+    {
+        public int device;
+        public int rank;
+        public int world;
+        public int partDimX, partDimY, partDimZ;
+        public float gravityX, gravityY, gravityZ;
+        public float damping;
+        public int tileParticles;
+        public int useGraph;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct SbStats
+    {
+        public long nParticlesOwned, nParticlesLocal;
+        public long nDistanceLocal, nVolumeLocal, nBendingLocal;
+        public int nPhases, nTilePhases, nGlobalColours;
+        public long nClusters, constraintsInTiles, constraintsInGlobal;
+        public long kernelLaunchesPerSubstep, haloBytesPerSubstep, deviceBytes;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct SbPlanOpts
+    {
+        public int rank, world;
+        public int partDimX, partDimY, partDimZ;
+        public int tileParticles;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct SbPhaseInfo
+    {
+        public int kind, type;
+        public long orderBegin, orderEnd, taskBegin, taskEnd;
+        public int needsHalo;
+    }
+
+    public static class SoftbodyNative
+    {
+        const string Lib = "softbody_mi355x";
+        const CallingConvention CC = CallingConvention.Cdecl;
+        public const int UniqueIdBytes = 128;
+
+        [DllImport(Lib, CallingConvention = CC)] public static extern void sb_desc_default(ref SbDesc d);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_create(ref SbDesc desc, out IntPtr solver);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_destroy(IntPtr s);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_particles(IntPtr s, IntPtr posXyz, IntPtr velXyz, IntPtr invMass, int n);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_rest_positions(IntPtr s, IntPtr restXyz, int n);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_distance_constraints(IntPtr s, IntPtr ij, IntPtr restLen, int m, float compliance);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_volume_constraints(IntPtr s, IntPtr ijkl, IntPtr restVol, int m, float compliance);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_bending_constraints(IntPtr s, IntPtr ijkl, IntPtr restCosSin, int m, float compliance);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_finalize(IntPtr s);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_comm_unique_id(IntPtr outId128);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_comm_init(IntPtr s, IntPtr id128);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_step(IntPtr s, float dt, int substeps);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_get_positions(IntPtr s, IntPtr posXyzOut, int n);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_get_velocities(IntPtr s, IntPtr velXyzOut, int n);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_state(IntPtr s, IntPtr posXyz, IntPtr velXyz, int n);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_get_owner(IntPtr s, IntPtr ownerRankOut, int n);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_profile_begin(IntPtr s);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_profile_end(IntPtr s, out float elapsedMs);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_synchronize(IntPtr s);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_step_profiled(IntPtr s, float dt, int substeps, IntPtr slotMsOut, IntPtr slotLaunchesOut, int nSlots);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_get_stats(IntPtr s, out SbStats stats);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_build(IntPtr restXyz, int n, IntPtr distIj, int mD, IntPtr volIjkl, int mV, IntPtr bendIjkl, int mB, ref SbPlanOpts opts, out IntPtr plan);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_destroy(IntPtr plan);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_get_plan(IntPtr s, out IntPtr plan);
+        [DllImport(Lib, CallingConvention = CC)] public static extern long sb_plan_order_count(IntPtr plan);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_order(IntPtr plan, IntPtr typeOut, IntPtr idOut);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_phase_count(IntPtr plan);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_phases(IntPtr plan, [Out] SbPhaseInfo[] phases);
+        [DllImport(Lib, CallingConvention = CC)] public static extern long sb_plan_task_count(IntPtr plan);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_tasks(IntPtr plan, IntPtr taskOffOut);
+        [DllImport(Lib, CallingConvention = CC)] public static extern long sb_plan_group_count(IntPtr plan);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_groups(IntPtr plan, IntPtr groupOffOut);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_owner(IntPtr plan, IntPtr ownerRankOut);
+        [DllImport(Lib, CallingConvention = CC)] public static extern long sb_plan_local_count(IntPtr plan, out long owned);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_local_particles(IntPtr plan, IntPtr globalIdOut);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_halo_counts(IntPtr plan, int phase, IntPtr sendCountPerRank, IntPtr recvCountPerRank);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_halo(IntPtr plan, int phase, int peer, IntPtr sendIds, IntPtr recvIds);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_local_order_mask(IntPtr plan, IntPtr maskOut);
+        [DllImport(Lib, CallingConvention = CC)] public static extern IntPtr sb_last_error();
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_abi_version();
+
+        public static string LastError() => Marshal.PtrToStringAnsi(sb_last_error());
+
+        public static void Check(int rc, string what)
+        {
+            if (rc != 0) throw new InvalidOperationException($"{what} failed ({rc}): {LastError()}");
+        }
+    }
+}
