@@ -115,28 +115,22 @@ def main():
     ms_per_step = 1e3 * elapsed / args.steps
     out = None
     if rank == 0:
-        plan = sb.plan()
-        phases = plan.phases()
-        # dominant kernel = the slot with the most time; its ALGORITHMIC bytes per launch
-        k_dom = int(np.argmax(slot_ms))
-        names = []
-        alg_bytes = []
+        G = stats["n_global_colours"]
         owned = stats["n_particles_owned"]
-        for k, ph in enumerate(phases):
-            if ph["kind"] == 1 and k == 0:
-                names.append("tile_kernel<1> (P1: velocity+integrate fused, in-cell springs)")
-            elif ph["kind"] == 1:
-                names.append("tile_kernel<2> (P2: shifted tiles, cut springs)")
-            else:
-                names.append(f"global_colour_kernel type {ph['type']}")
-        # constraints this rank executes per phase
-        mask = plan.local_order_mask().astype(bool)
-        for k, ph in enumerate(phases):
-            mk = int(mask[ph["order_begin"]:ph["order_end"]].sum())
-            extra = (52.0 + 36.0) * owned if k == 0 else 0.0   # phase 0 carries integrate + velocity
-            alg_bytes.append(68.0 * mk + extra)
-        names.append("velocity_kernel (tick end)")
-        alg_bytes.append(36.0 * owned)
+        names = ["tile_kernel<1> on T0 (cross + velocity/integrate + full)",
+                 "tile_kernel<1> on T1 (cross + velocity/integrate + full)"]
+        names += [f"global colour {c}" for c in range(G)]
+        names += ["tile_kernel<0> (first kernel of a tick)", "tile_kernel<2> (last kernel of a tick)"]
+        # ALGORITHMIC bytes per launch: a mid-tick tile kernel does one velocity update (36 B)
+        # + one integrate (52 B) per particle and 68 B per constraint slot it stores (cross + full parts)
+        alg_bytes = [88.0 * owned + 68.0 * stats["tile_constraints"][t] for t in (0, 1)]
+        mask0 = None
+        for c in range(G):
+            if mask0 is None:
+                plan = sb.plan(); mask0 = plan.local_order_mask(0).astype(bool); ph0 = [p for p in plan.phases(0) if p["kind"] == 0]
+            alg_bytes.append(68.0 * int(mask0[ph0[c]["order_begin"]:ph0[c]["order_end"]].sum()))
+        alg_bytes += [52.0 * owned + 68.0 * stats["tile_constraints"][0], 36.0 * owned + 68.0 * stats["tile_constraints"][0]]
+        k_dom = int(np.argmax(slot_ms))
         launches = max(int(slot_cnt[k_dom]), 1)
         dom_ms = float(slot_ms[k_dom]) / launches
         achieved = alg_bytes[k_dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
@@ -158,19 +152,18 @@ def main():
             "config": {"workload": f"{args.n}^3 jelly cube, structural springs (N={N}, M={M}), {args.substeps} substeps/tick, "
                                    f"dt=0.02, explicit index-array graph, tile_particles={args.tile}",
                        "partition": "x".join(str(d) for d in _dims(world)), "graph_replay": (not args.no_graph) and world == 1,
-                       "phases": [n for n in names[:-1]], "finite": finite},
+                       "finite": finite},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
                          "kernel": names[k_dom], "kernel_avg_ms": dom_ms, "kernel_launches_per_tick": launches,
                          "algorithmic_bytes_per_launch": alg_bytes[k_dom],
+                         "traffic_GBps": (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
                          "job_algorithmic_GBps": job_alg / 1e9, "job_frac": job_alg / (HBM_PEAK * world),
                          "B_alg_per_particle_substep": b_alg(N, M) / N,
                          "tick_ms_hip_events": ev_ms / args.steps,
-                         "per_slot_ms_per_tick": {names[k]: float(slot_ms[k]) for k in range(len(names))}},
-            "setup_seconds": setup_s, "plan": {k: stats[k] for k in ("n_phases", "n_tile_phases", "n_global_colours",
-                                                                     "n_clusters", "constraints_in_tiles",
-                                                                     "constraints_in_global", "halo_bytes_per_substep",
-                                                                     "device_bytes")},
+                         "per_slot_ms_per_tick": {names[k]: float(slot_ms[k]) for k in range(len(names))},
+                         "per_slot_launches_per_tick": {names[k]: int(slot_cnt[k]) for k in range(len(names))}},
+            "setup_seconds": setup_s, "plan": stats,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(mesh, sb, args)

@@ -82,8 +82,13 @@ namespace SoftbodyMI355X
                 // CPU path walks the order the plugin's planner published (SPEC.md §3)
                 SoftbodyNative.Check(SoftbodyNative.sb_get_plan(handle, out IntPtr plan), "sb_get_plan");
                 long m = SoftbodyNative.sb_plan_order_count(plan);
-                var type = new byte[m]; var id = new int[m];
-                Pin(type, t => Pin(id, i => SoftbodyNative.Check(SoftbodyNative.sb_plan_get_order(plan, t, i), "sb_plan_get_order")));
+                var type = new byte[2][]; var id = new int[2][];
+                for (int parity = 0; parity < 2; ++parity)
+                {
+                    type[parity] = new byte[m]; id[parity] = new int[m];
+                    int par = parity;
+                    Pin(type[par], t => Pin(id[par], i => SoftbodyNative.Check(SoftbodyNative.sb_plan_get_order(plan, par, t, i), "sb_plan_get_order")));
+                }
                 cpu = new SoftbodyCpuSolver(this, type, id);
             }
             posPin = GCHandle.Alloc(positions, GCHandleType.Pinned);

@@ -14,13 +14,13 @@ namespace SoftbodyMI355X
     public sealed class SoftbodyCpuSolver
     {
         readonly Softbody sb;
-        readonly byte[] orderType;
-        readonly int[] orderId;
+        readonly byte[][] orderTypeByParity;   // SPEC.md §3: substep k of a tick walks the order of parity k & 1
+        readonly int[][] orderIdByParity;
         readonly Vector3[] prev;
 
-        public SoftbodyCpuSolver(Softbody owner, byte[] type, int[] id)
+        public SoftbodyCpuSolver(Softbody owner, byte[][] type, int[][] id)
         {
-            sb = owner; orderType = type; orderId = id;
+            sb = owner; orderTypeByParity = type; orderIdByParity = id;
             prev = new Vector3[owner.positions.Length];
         }
 
@@ -43,6 +43,8 @@ namespace SoftbodyMI355X
             int n = x.Length;
             for (int it = 0; it < substeps; ++it)
             {
+                byte[] orderType = orderTypeByParity[it & 1];
+                int[] orderId = orderIdByParity[it & 1];
                 for (int p = 0; p < n; ++p)
                 {
                     prev[p] = x[p];

@@ -1,4 +1,4 @@
-// SoftbodyNative.cs — P/Invoke layer over libsoftbody_mi355x.so (include/softbody.h, ABI version 1).
+// SoftbodyNative.cs — P/Invoke layer over libsoftbody_mi355x.so (include/softbody.h, ABI version 2).
 //
 // One [DllImport] per exported function, same name and argument order as the header; the Python twin
 // used by the test-suite is softbodyunity_amd/native.py (tests/test_abi.py keeps the three in sync).
@@ -30,9 +30,10 @@ namespace SoftbodyMI355X
     {
         public long nParticlesOwned, nParticlesLocal;
         public long nDistanceLocal, nVolumeLocal, nBendingLocal;
-        public int nPhases, nTilePhases, nGlobalColours;
-        public long nClusters, constraintsInTiles, constraintsInGlobal;
-        public long kernelLaunchesPerSubstep, haloBytesPerSubstep, deviceBytes;
+        public int nTilings, nGlobalColours;
+        public long nTilesT0, nTilesT1, tileConstraintsT0, tileConstraintsT1;
+        public long constraintsInTiles, constraintsInGlobal;
+        public long haloParticlesT1, haloParticlesGlobal, deviceBytes;
     }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -46,9 +47,8 @@ namespace SoftbodyMI355X
     [StructLayout(LayoutKind.Sequential)]
     public struct SbPhaseInfo
     {
-        public int kind, type;
+        public int kind, type, tiling, haloSlot;
         public long orderBegin, orderEnd, taskBegin, taskEnd;
-        public int needsHalo;
     }
 
     public static class SoftbodyNative
@@ -82,19 +82,20 @@ namespace SoftbodyMI355X
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_destroy(IntPtr plan);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_get_plan(IntPtr s, out IntPtr plan);
         [DllImport(Lib, CallingConvention = CC)] public static extern long sb_plan_order_count(IntPtr plan);
-        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_order(IntPtr plan, IntPtr typeOut, IntPtr idOut);
-        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_phase_count(IntPtr plan);
-        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_phases(IntPtr plan, [Out] SbPhaseInfo[] phases);
-        [DllImport(Lib, CallingConvention = CC)] public static extern long sb_plan_task_count(IntPtr plan);
-        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_tasks(IntPtr plan, IntPtr taskOffOut);
-        [DllImport(Lib, CallingConvention = CC)] public static extern long sb_plan_group_count(IntPtr plan);
-        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_groups(IntPtr plan, IntPtr groupOffOut);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_order(IntPtr plan, int parity, IntPtr typeOut, IntPtr idOut);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_phase_count(IntPtr plan, int parity);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_phases(IntPtr plan, int parity, [Out] SbPhaseInfo[] phases);
+        [DllImport(Lib, CallingConvention = CC)] public static extern long sb_plan_task_count(IntPtr plan, int parity);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_tasks(IntPtr plan, int parity, IntPtr taskOffOut);
+        [DllImport(Lib, CallingConvention = CC)] public static extern long sb_plan_group_count(IntPtr plan, int parity);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_groups(IntPtr plan, int parity, IntPtr groupOffOut);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_owner(IntPtr plan, IntPtr ownerRankOut);
         [DllImport(Lib, CallingConvention = CC)] public static extern long sb_plan_local_count(IntPtr plan, out long owned);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_local_particles(IntPtr plan, IntPtr globalIdOut);
-        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_halo_counts(IntPtr plan, int phase, IntPtr sendCountPerRank, IntPtr recvCountPerRank);
-        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_halo(IntPtr plan, int phase, int peer, IntPtr sendIds, IntPtr recvIds);
-        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_local_order_mask(IntPtr plan, IntPtr maskOut);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_halo_slot_count(IntPtr plan);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_halo_counts(IntPtr plan, int slot, IntPtr sendCountPerRank, IntPtr recvCountPerRank);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_halo(IntPtr plan, int slot, int peer, IntPtr sendIds, IntPtr recvIds);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_local_order_mask(IntPtr plan, int parity, IntPtr maskOut);
         [DllImport(Lib, CallingConvention = CC)] public static extern IntPtr sb_last_error();
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_abi_version();
 

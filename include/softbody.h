@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SB_ABI_VERSION 1
+#define SB_ABI_VERSION 2
 
 typedef enum {
     SB_OK = 0,
@@ -101,34 +101,40 @@ int sb_profile_begin(sb_solver *s);
 int sb_profile_end(sb_solver *s, float *elapsed_ms_out);
 int sb_synchronize(sb_solver *s);
 /* One tick launched eagerly with a HIP-event pair around every kernel launch on the solver's stream.
- * slot k < n_phases accumulates phase k's launches, slot n_phases the tick-end velocity kernel.
- * n_slots must be n_phases + 1 (sb_get_stats). Same results as sb_step. */
+ * Slots: 0 / 1 = mid-tick tile kernels on tiling T0 / T1 (cross + velocity/integrate + full),
+ * 2+c = global colour c, 2+G = the first kernel of the tick, 3+G = the last (G = n_global_colours).
+ * n_slots must be 4 + n_global_colours (sb_get_stats). Same results as sb_step. */
 int sb_step_profiled(sb_solver *s, float dt, int32_t substeps, float *slot_ms_out, int32_t *slot_launches_out,
                      int32_t n_slots);
 typedef struct {
     int64_t n_particles_owned, n_particles_local;   /* local = owned + ghost */
     int64_t n_constraints_local[3];                 /* distance, volume, bending (incl. redundant cut copies) */
-    int32_t n_phases, n_tile_phases, n_global_colours;
-    int64_t n_clusters;
-    int64_t constraints_in_tiles, constraints_in_global;
-    int64_t kernel_launches_per_substep;
-    int64_t halo_bytes_per_substep;                 /* bytes this rank sends per substep */
+    int32_t n_tilings;                              /* 2 with tiling, 1 without (tile_particles = -1) */
+    int32_t n_global_colours;
+    int64_t n_tiles[2];                             /* tiles this rank executes per tiling */
+    int64_t tile_constraints[2];                    /* constraint slots (cross + full) stored per tiling, this rank */
+    int64_t constraints_in_tiles, constraints_in_global;   /* whole mesh */
+    int64_t halo_particles_t1;                      /* ghosts sent before every T1 kernel */
+    int64_t halo_particles_global;                  /* ghosts sent per substep for the global colours */
     int64_t device_bytes;                           /* device memory held by the solver */
 } sb_stats;
 int sb_get_stats(sb_solver *s, sb_stats *out);
 
 /* ---- plan inspection (pure host code; works without a GPU) ------------------------------------ */
+/* The planner (SPEC.md §3) publishes one sequential constraint order per substep parity (0,1,0,1,...
+ * restarting at 0 every tick). parity arguments below are 0 or 1. */
 typedef struct {
     int32_t rank, world;
     int32_t part_dims[3];
     int32_t tile_particles;
 } sb_plan_opts;
 typedef struct {
-    int32_t kind;               /* 0 = global colour (one constraint type), 1 = tile phase */
-    int32_t type;               /* kind 0: constraint type 0/1/2; kind 1: -1 */
-    int64_t order_begin, order_end; /* slice of the published order */
+    int32_t kind;               /* 0 = global colour, 1 = full part of a tiling's tiles, 2 = cross part */
+    int32_t type;               /* kind 0: constraint type 0/1/2; else -1 */
+    int32_t tiling;             /* kind 1/2: 0 or 1; kind 0: -1 */
+    int32_t halo_slot;          /* -1 none; 1 = before the T1 tile kernel; 2+c = before global colour c */
+    int64_t order_begin, order_end; /* slice of the parity's published order */
     int64_t task_begin, task_end;   /* slice of the task table: tasks of one phase touch disjoint particles */
-    int32_t needs_halo;         /* 1 = ghosts are refreshed before this phase when world > 1 */
 } sb_phase_info;
 
 int sb_plan_build(const float *rest_xyz, int32_t n,
@@ -142,27 +148,29 @@ int sb_get_plan(sb_solver *s, const sb_plan **out);
 
 int64_t sb_plan_order_count(const sb_plan *p);
 /* The published sequential order (SPEC.md §3): type 0/1/2 + index into that type's input arrays. */
-int sb_plan_get_order(const sb_plan *p, uint8_t *type_out, int32_t *id_out);
-int32_t sb_plan_phase_count(const sb_plan *p);
-int sb_plan_get_phases(const sb_plan *p, sb_phase_info *out);
-int64_t sb_plan_task_count(const sb_plan *p);
-int sb_plan_get_tasks(const sb_plan *p, int64_t *task_off_out /* task_count+1 */);
-/* Finest independent sets (one colour class of one tile / one chunk of a global colour): constraints of
- * one group share no particle; the GPU runs a group's constraints concurrently. */
-int64_t sb_plan_group_count(const sb_plan *p);
-int sb_plan_get_groups(const sb_plan *p, int64_t *group_off_out /* group_count+1 */);
+int sb_plan_get_order(const sb_plan *p, int32_t parity, uint8_t *type_out, int32_t *id_out);
+int32_t sb_plan_phase_count(const sb_plan *p, int32_t parity);
+int sb_plan_get_phases(const sb_plan *p, int32_t parity, sb_phase_info *out);
+int64_t sb_plan_task_count(const sb_plan *p, int32_t parity);
+int sb_plan_get_tasks(const sb_plan *p, int32_t parity, int64_t *task_off_out /* task_count+1 */);
+/* Finest independent sets (one round of one tile / one chunk of a global colour): constraints of one
+ * group share no particle; the GPU runs a group's constraints concurrently. */
+int64_t sb_plan_group_count(const sb_plan *p, int32_t parity);
+int sb_plan_get_groups(const sb_plan *p, int32_t parity, int64_t *group_off_out /* group_count+1 */);
 int sb_plan_get_owner(const sb_plan *p, int32_t *owner_rank_out /* n */);
 /* Per-rank view: particles this rank keeps (owned first, then ghosts), in device order. */
 int64_t sb_plan_local_count(const sb_plan *p, int64_t *owned_out);
 int sb_plan_get_local_particles(const sb_plan *p, int32_t *global_id_out);
-/* Halo schedule of this rank for phase `phase`: for every peer, which of its own particles it sends and
- * which ghosts it receives (global ids, identical order on both sides). Returns counts via *_count. */
-int sb_plan_halo_counts(const sb_plan *p, int32_t phase, int32_t *send_count_per_rank /* world */,
+/* Halo schedule of this rank for halo slot `slot` (sb_phase_info.halo_slot): for every peer, which of its
+ * own particles it sends and which ghosts it receives (caller particle ids, identical order on both
+ * sides). Slot 1 carries positions and previous positions, slots >= 2 positions only. */
+int32_t sb_plan_halo_slot_count(const sb_plan *p);
+int sb_plan_halo_counts(const sb_plan *p, int32_t slot, int32_t *send_count_per_rank /* world */,
                         int32_t *recv_count_per_rank /* world */);
-int sb_plan_get_halo(const sb_plan *p, int32_t phase, int32_t peer, int32_t *send_ids, int32_t *recv_ids);
+int sb_plan_get_halo(const sb_plan *p, int32_t slot, int32_t peer, int32_t *send_ids, int32_t *recv_ids);
 /* Which order entries this rank executes (1) or skips (0) — cut constraints run on every rank that owns
  * one of their particles. */
-int sb_plan_get_local_order_mask(const sb_plan *p, uint8_t *mask_out);
+int sb_plan_get_local_order_mask(const sb_plan *p, int32_t parity, uint8_t *mask_out);
 
 const char *sb_last_error(void);
 int sb_abi_version(void);

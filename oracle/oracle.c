@@ -185,31 +185,41 @@ void orc_project_range(float *x, const float *w, const orc_constraints *c, const
     }
 }
 
-/* One tick (SPEC.md §2), sequential — the semantics of a Unity FixedUpdate loop. xprev: scratch 3n. */
+/* Published schedule for one substep parity (SPEC.md §3). order_id == NULL means natural order. */
+typedef struct {
+    const uint8_t *order_type;
+    const int32_t *order_id;
+    const int64_t *phase_task_off;  /* n_phases+1, may be NULL for the sequential walk */
+    int32_t n_phases;
+    const int64_t *task_off;
+} orc_schedule;
+
+/* One tick (SPEC.md §2), sequential — the semantics of a Unity FixedUpdate loop. Substep k of the tick
+ * walks the order of parity k & 1. xprev: scratch 3n. */
 void orc_step(float *x, float *v, const float *w, float *xprev, int n, const orc_constraints *c,
-              const uint8_t *order_type, const int32_t *order_id, const orc_params *p, float dt, int substeps) {
+              const orc_schedule *sched /* [2] */, const orc_params *p, float dt, int substeps) {
     orc_scalars s;
     orc_scalars_for(p, dt, substeps, &s);
     int64_t total = (int64_t)c->m_d + c->m_v + c->m_b;
     for (int it = 0; it < substeps; ++it) {
+        const orc_schedule *sc = &sched[it & 1];
         orc_integrate(x, xprev, v, w, n, &s);
-        orc_project_range(x, w, c, order_type, order_id, 0, total, &s);
+        orc_project_range(x, w, c, sc->order_type, sc->order_id, 0, total, &s);
         orc_velocity(x, xprev, v, n, &s);
     }
 }
 
 /*
- * Task-parallel variant for the all-cores CPU baseline: the schedule is cut into phases; a phase
+ * Task-parallel variant for the all-cores CPU baseline: a parity's schedule is cut into phases; a phase
  * is a list of tasks (contiguous ranges of the order) that touch pairwise disjoint particles, so
- * they may run concurrently and give bit-identical results to orc_step. phase_task_off has
- * n_phases+1 entries indexing task_off; task_off has n_tasks+1 entries indexing the order.
+ * they may run concurrently and give bit-identical results to orc_step.
  */
 void orc_step_tasks(float *x, float *v, const float *w, float *xprev, int n, const orc_constraints *c,
-                    const uint8_t *order_type, const int32_t *order_id, const int64_t *phase_task_off,
-                    int32_t n_phases, const int64_t *task_off, const orc_params *p, float dt, int substeps) {
+                    const orc_schedule *sched /* [2] */, const orc_params *p, float dt, int substeps) {
     orc_scalars s;
     orc_scalars_for(p, dt, substeps, &s);
     for (int it = 0; it < substeps; ++it) {
+        const orc_schedule *sc = &sched[it & 1];
 #pragma omp parallel
         {
 #pragma omp for schedule(static)
@@ -217,10 +227,10 @@ void orc_step_tasks(float *x, float *v, const float *w, float *xprev, int n, con
                 int b = blk * 4096, e = b + 4096 > n ? n : b + 4096;
                 orc_integrate(x + 3 * (int64_t)b, xprev + 3 * (int64_t)b, v + 3 * (int64_t)b, w + b, e - b, &s);
             }
-            for (int ph = 0; ph < n_phases; ++ph) {
+            for (int ph = 0; ph < sc->n_phases; ++ph) {
 #pragma omp for schedule(dynamic, 16)
-                for (int64_t t = phase_task_off[ph]; t < phase_task_off[ph + 1]; ++t)
-                    orc_project_range(x, w, c, order_type, order_id, task_off[t], task_off[t + 1], &s);
+                for (int64_t t = sc->phase_task_off[ph]; t < sc->phase_task_off[ph + 1]; ++t)
+                    orc_project_range(x, w, c, sc->order_type, sc->order_id, sc->task_off[t], sc->task_off[t + 1], &s);
             }
 #pragma omp for schedule(static)
             for (int blk = 0; blk < (n + 4095) / 4096; ++blk) {

@@ -36,6 +36,11 @@ class OrcConstraints(C.Structure):
                 ("bend_ijkl", C.c_void_p), ("bend_rest", C.c_void_p), ("m_b", C.c_int32)]
 
 
+class OrcSchedule(C.Structure):
+    _fields_ = [("order_type", C.c_void_p), ("order_id", C.c_void_p), ("phase_task_off", C.c_void_p),
+                ("n_phases", C.c_int32), ("task_off", C.c_void_p)]
+
+
 _lib = None
 
 
@@ -84,7 +89,7 @@ class Oracle:
         self.bend_ijkl = np.zeros((0, 4), np.int32); self.bend_rest = np.zeros((0, 2), np.float32)
         self.order_type = None
         self.order_id = None
-        self.tasks = None
+        self.sched = [(None, None, None), (None, None, None)]
 
     def set_distance(self, ij, rest, compliance=0.0):
         self.dist_ij = _i32(ij).reshape(-1, 2).copy(); self.dist_rest = _f32(rest, (-1,)).copy()
@@ -101,15 +106,32 @@ class Oracle:
         self.bend_ijkl = _i32(ijkl).reshape(-1, 4).copy(); self.bend_rest = _f32(rest_cs, (-1, 2)).copy()
         self.params.compliance[2] = float(compliance)
 
-    def set_order(self, order_type, order_id, phase_task_off=None, task_off=None):
-        """Schedule published by the planner (SPEC.md §3)."""
-        self.order_type = np.ascontiguousarray(order_type, dtype=np.uint8)
-        self.order_id = _i32(order_id)
+    def set_order(self, order_type, order_id, phase_task_off=None, task_off=None, parity=None):
+        """Schedule published by the planner (SPEC.md §3). parity=None sets both parities to the same order."""
+        ot = np.ascontiguousarray(order_type, dtype=np.uint8)
+        oi = _i32(order_id)
         total = len(self.dist_rest) + len(self.vol_rest6) + len(self.bend_rest)
-        assert self.order_type.shape[0] == total and self.order_id.shape[0] == total
+        assert ot.shape[0] == total and oi.shape[0] == total
+        tasks = None
         if phase_task_off is not None:
-            self.tasks = (np.ascontiguousarray(phase_task_off, dtype=np.int64),
-                          np.ascontiguousarray(task_off, dtype=np.int64))
+            tasks = (np.ascontiguousarray(phase_task_off, dtype=np.int64), np.ascontiguousarray(task_off, dtype=np.int64))
+        for p in ((0, 1) if parity is None else (parity,)):
+            self.sched[p] = (ot, oi, tasks)
+        # single-order view used by project_range
+        self.order_type, self.order_id = self.sched[0][0], self.sched[0][1]
+
+    def use_parity(self, parity):
+        """Select which parity's order project_range() indexes."""
+        self.order_type, self.order_id = self.sched[parity][0], self.sched[parity][1]
+
+    def _sched(self):
+        arr = (OrcSchedule * 2)()
+        for p in range(2):
+            ot, oi, tasks = self.sched[p]
+            arr[p].order_type = _p(ot); arr[p].order_id = _p(oi)
+            if tasks is not None:
+                arr[p].phase_task_off = _p(tasks[0]); arr[p].n_phases = len(tasks[0]) - 1; arr[p].task_off = _p(tasks[1])
+        return arr
 
     def _cons(self):
         c = OrcConstraints()
@@ -125,16 +147,14 @@ class Oracle:
 
     def step(self, dt, substeps, parallel=False):
         c = self._cons()
+        sch = self._sched()
         if parallel:
-            assert self.tasks is not None, "set_order(..., phase_task_off, task_off) first"
-            pto, to = self.tasks
-            lib().orc_step_tasks(_p(self.x), _p(self.v), _p(self.w), _p(self.xprev), C.c_int(self.n), C.byref(c),
-                                 _p(self.order_type), _p(self.order_id), _p(pto), C.c_int32(len(pto) - 1), _p(to),
-                                 C.byref(self.params), C.c_float(dt), C.c_int(substeps))
+            assert self.sched[0][2] is not None and self.sched[1][2] is not None, "set_order(..., phase_task_off, task_off) first"
+            fn = lib().orc_step_tasks
         else:
-            lib().orc_step(_p(self.x), _p(self.v), _p(self.w), _p(self.xprev), C.c_int(self.n), C.byref(c),
-                           _p(self.order_type), _p(self.order_id), C.byref(self.params), C.c_float(dt),
-                           C.c_int(substeps))
+            fn = lib().orc_step
+        fn(_p(self.x), _p(self.v), _p(self.w), _p(self.xprev), C.c_int(self.n), C.byref(c), sch,
+           C.byref(self.params), C.c_float(dt), C.c_int(substeps))
 
     # fine-grained entry points used by the partitioned-oracle (halo) tests
     def integrate(self, s):

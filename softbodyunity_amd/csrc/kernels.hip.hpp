@@ -15,23 +15,25 @@ struct TickParams {           // SPEC.md §2 host-side scalars, uploaded once pe
     float pad[7];
 };
 
-struct ClusterDesc {          // one LDS tile
-    int32_t run_begin, run_count, n_local, col_begin;
-    int32_t col_count, pad0, pad1, pad2;
+struct TileDesc {             // one LDS tile = one workgroup; 128 B, read with scalar loads
+    int32_t n_local, run_count, round_begin, n_pre;
+    int32_t n_rounds;          // cross rounds, the marker, full rounds
+    uint32_t d_begin, q_begin; // first distance / 4-vertex constraint of the cross part
+    uint32_t d_mid;            // first distance constraint of the full part
+    uint32_t q_mid;
+    int32_t run_overflow;      // runs beyond kInlineRuns live at runs_overflow[run_overflow ...]
+    int32_t pad0, pad1;
+    int2 runs[10];             // {first particle (device numbering), first tile-local index}
 };
-struct ColourDesc {           // one colour class inside a tile
-    int32_t type;             // 0 distance, 1 volume, 2 bending
-    uint32_t begin;           // into the phase's constraint arrays of that arity
-    int32_t count, pad;
-};
+constexpr int kInlineRuns = 10;
 
 struct TileArgs {
     float4 *pos;              // (x,y,z,w) per local particle
     float *prev;              // packed xyz
-    const float *vel;         // packed xyz (MODE 0 only)
-    const ClusterDesc *cl;
-    const int2 *runs;         // {global start, local start}
-    const ColourDesc *cols;
+    float *vel;               // packed xyz (read by KIND 0, written by KIND 2)
+    const TileDesc *tiles;
+    const int2 *runs_overflow;
+    const uint32_t *rounds;   // bits 0-9 count, bits 10-11 type (3 = velocity/integrate marker)
     const uint32_t *d_idx;    // distance: lo16 = i, hi16 = j (tile-local)
     const float *d_rest;
     const uint2 *q_idx;       // 4-vertex: {i0|i1<<16, i2|i3<<16}
@@ -40,7 +42,8 @@ struct TileArgs {
 };
 
 constexpr int kTileThreads = 256;
-constexpr int kMaxRuns = 64;
+constexpr int kPPT = 4;        // particles per lane (tile <= 1024 particles)
+constexpr int kRB = 8;         // rounds of constraint data kept in flight per lane
 
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 sub3(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -135,77 +138,142 @@ __device__ __forceinline__ bool project_bending(float4 &pa, float4 &pb, float4 &
     return true;
 }
 
-// SPEC.md §2 steps 3+1 for one particle. MODE 0: v comes from the velocity array (first substep of a
-// tick); MODE 1: v is re-derived from (x - xprev) (velocity update of the previous substep fused in).
-template <int MODE>
-__device__ __forceinline__ void integrate_one(float4 &X, float *prev, const float *vel, int g, const TickParams &tp) {
-    float vx, vy, vz;
-    if (MODE == 0) {
-        vx = vel[3 * (size_t)g + 0]; vy = vel[3 * (size_t)g + 1]; vz = vel[3 * (size_t)g + 2];
-    } else {
-        float px = prev[3 * (size_t)g + 0], py = prev[3 * (size_t)g + 1], pz = prev[3 * (size_t)g + 2];
-        float dx = X.x - px, dy = X.y - py, dz = X.z - pz;
-        float qx = dx * tp.inv_h, qy = dy * tp.inv_h, qz = dz * tp.inv_h;
-        vx = qx * tp.kd; vy = qy * tp.kd; vz = qz * tp.kd;
-    }
-    prev[3 * (size_t)g + 0] = X.x; prev[3 * (size_t)g + 1] = X.y; prev[3 * (size_t)g + 2] = X.z;
-    if (X.w > 0.0f) {
-        vx = vx + tp.hgx; vy = vy + tp.hgy; vz = vz + tp.hgz;
-        float hx = tp.h * vx, hy = tp.h * vy, hz = tp.h * vz;
-        X.x = X.x + hx; X.y = X.y + hy; X.z = X.z + hz;
-    }
-}
-
-// One workgroup = one tile: stage its particles in LDS, run its colour classes with a barrier between
-// them, write the tile back. MODE 0/1: phase P1 with integrate fused into the load; MODE 2: plain tile.
-template <int MODE>
-__global__ __launch_bounds__(kTileThreads) void tile_kernel(TileArgs A) {
+// One workgroup = one tile. The tile's program is [cross rounds..., MARK, full rounds...] (plan.hpp):
+//   KIND 0 (first kernel of a tick)  : starts at MARK: v from the velocity array, integrate, full rounds
+//   KIND 1 (every other substep)     : cross rounds (finish substep s-1), MARK: v = (x-xprev)/h, integrate
+//                                      (start substep s), full rounds
+//   KIND 2 (after the last substep)  : cross rounds, MARK: write v, stop
+// Particles are staged in LDS once; each lane keeps ownership of up to kPPT particles for the MARK step.
+// Constraint words of the next kRB rounds are kept in flight in registers (rolling prefetch) so that a
+// tile pays the HBM latency once instead of once per colour.
+// QUADS = the tiling stores 4-vertex (volume/bending) rounds: that variant keeps fewer rounds in flight
+// (the 4-vertex code is large) and loads 4-vertex words without prefetch.
+template <int KIND, bool QUADS>
+__global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileArgs A) {
+    constexpr int RB = QUADS ? 2 : kRB;
     extern __shared__ float4 lds_pos[];
-    __shared__ int2 s_runs[kMaxRuns + 1];
-    const ClusterDesc cd = A.cl[blockIdx.x];
+    const TileDesc &td = A.tiles[blockIdx.x];
     const int tid = threadIdx.x;
-    if (tid < cd.run_count) s_runs[tid] = A.runs[cd.run_begin + tid];
-    if (tid == 0) s_runs[cd.run_count] = make_int2(0, cd.n_local);
-    __syncthreads();
+    const int n_local = td.n_local;
+    const int run_count = td.run_count;
     const TickParams tp = *A.tp;
-    for (int l = tid; l < cd.n_local; l += kTileThreads) {
-        int r = 0;
-        while (s_runs[r + 1].y <= l) ++r;
-        const int g = s_runs[r].x + (l - s_runs[r].y);
-        float4 X = A.pos[g];
-        if (MODE < 2) integrate_one<MODE>(X, A.prev, A.vel, g, tp);
-        lds_pos[l] = X;
-    }
-    __syncthreads();
-    for (int c = 0; c < cd.col_count; ++c) {
-        const ColourDesc ce = A.cols[cd.col_begin + c];
-        if (ce.type == 0) {
-            for (int k = tid; k < ce.count; k += kTileThreads) {
-                const uint32_t pr = A.d_idx[ce.begin + k];
-                const float L0 = A.d_rest[ce.begin + k];
-                const int i = pr & 0xffffu, j = pr >> 16;
-                float4 a = lds_pos[i], b = lds_pos[j];
-                if (project_distance(a, b, L0, tp.at_d)) { lds_pos[i] = a; lds_pos[j] = b; }
-            }
-        } else {
-            for (int k = tid; k < ce.count; k += kTileThreads) {
-                const uint2 pr = A.q_idx[ce.begin + k];
-                const float2 rest = A.q_rest[ce.begin + k];
-                const int i0 = pr.x & 0xffffu, i1 = pr.x >> 16, i2 = pr.y & 0xffffu, i3 = pr.y >> 16;
-                float4 p0 = lds_pos[i0], p1 = lds_pos[i1], p2 = lds_pos[i2], p3 = lds_pos[i3];
-                bool ok = ce.type == 1 ? project_volume(p0, p1, p2, p3, rest.x, tp.at_v)
-                                       : project_bending(p0, p1, p2, p3, rest, tp.at_b);
-                if (ok) { lds_pos[i0] = p0; lds_pos[i1] = p1; lds_pos[i2] = p2; lds_pos[i3] = p3; }
+
+    // ---- particle ownership: lane tid owns tile-local particles tid + 256*m -----------------------
+    int g[kPPT];
+#pragma unroll
+    for (int m = 0; m < kPPT; ++m) {
+        const int l = tid + m * kTileThreads;
+        int gi = -1;
+        if (l < n_local) {
+#pragma unroll
+            for (int r = 0; r < kInlineRuns; ++r)
+                if (r < run_count && td.runs[r].y <= l) gi = td.runs[r].x + (l - td.runs[r].y);
+            for (int r = kInlineRuns; r < run_count; ++r) {
+                const int2 rn = A.runs_overflow[td.run_overflow + r - kInlineRuns];
+                if (rn.y <= l) gi = rn.x + (l - rn.y);
             }
         }
-        __syncthreads();
+        g[m] = gi;
     }
-    for (int l = tid; l < cd.n_local; l += kTileThreads) {
-        int r = 0;
-        while (s_runs[r + 1].y <= l) ++r;
-        const int g = s_runs[r].x + (l - s_runs[r].y);
-        A.pos[g] = lds_pos[l];
+    float pvx[kPPT], pvy[kPPT], pvz[kPPT];
+#pragma unroll
+    for (int m = 0; m < kPPT; ++m) {
+        pvx[m] = pvy[m] = pvz[m] = 0.0f;
+        if (g[m] >= 0) {
+            lds_pos[tid + m * kTileThreads] = A.pos[g[m]];
+            if (KIND != 0) {
+                pvx[m] = A.prev[3 * (size_t)g[m] + 0]; pvy[m] = A.prev[3 * (size_t)g[m] + 1]; pvz[m] = A.prev[3 * (size_t)g[m] + 2];
+            }
+        }
     }
+
+    // ---- rolling prefetch of constraint words ------------------------------------------------------
+    const int r_begin = KIND == 0 ? td.n_pre : 0;
+    const int r_end = KIND == 2 ? td.n_pre + 1 : td.n_rounds;
+    const uint32_t *rounds = A.rounds + td.round_begin;
+    uint32_t pf_d = KIND == 0 ? td.d_mid : td.d_begin;     // data offset of the next round to prefetch
+    uint32_t cur_q = KIND == 0 ? td.q_mid : td.q_begin;
+    int pf_r = r_begin;
+    uint32_t s_idx[RB];
+    float s_rest[RB];
+    auto prefetch = [&](int slot) {
+        if (pf_r < r_end) {
+            const uint32_t w = rounds[pf_r];
+            const int cnt = w & 1023u, type = (w >> 10) & 3u;
+            if (type == 0) {
+                if (tid < cnt) { s_idx[slot] = A.d_idx[pf_d + tid]; s_rest[slot] = A.d_rest[pf_d + tid]; }
+                pf_d += cnt;
+            }
+            ++pf_r;
+        }
+    };
+#pragma unroll
+    for (int j = 0; j < RB; ++j) prefetch(j);
+    __syncthreads();
+
+    int r = r_begin;
+    while (r < r_end) {
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+            if (r < r_end) {
+                const uint32_t w = rounds[r];
+                const int cnt = w & 1023u, type = (w >> 10) & 3u;
+                if (type == 0) {
+                    if (tid < cnt) {
+                        const uint32_t pr = s_idx[j];
+                        const int i = pr & 0xffffu, k = pr >> 16;
+                        float4 a = lds_pos[i], b = lds_pos[k];
+                        if (project_distance(a, b, s_rest[j], tp.at_d)) { lds_pos[i] = a; lds_pos[k] = b; }
+                    }
+                } else if (type == 3) {
+                    // velocity update of the substep that just finished + integrate of the next one (SPEC.md §2)
+#pragma unroll
+                    for (int m = 0; m < kPPT; ++m)
+                        if (g[m] >= 0) {
+                            const int l = tid + m * kTileThreads;
+                            float4 P = lds_pos[l];
+                            float vx, vy, vz;
+                            const size_t o = 3 * (size_t)g[m];
+                            if (KIND == 0) {
+                                vx = A.vel[o + 0]; vy = A.vel[o + 1]; vz = A.vel[o + 2];
+                            } else {
+                                float dx = P.x - pvx[m], dy = P.y - pvy[m], dz = P.z - pvz[m];
+                                float qx = dx * tp.inv_h, qy = dy * tp.inv_h, qz = dz * tp.inv_h;
+                                vx = qx * tp.kd; vy = qy * tp.kd; vz = qz * tp.kd;
+                            }
+                            if (KIND == 2) {
+                                A.vel[o + 0] = vx; A.vel[o + 1] = vy; A.vel[o + 2] = vz;
+                            } else {
+                                A.prev[o + 0] = P.x; A.prev[o + 1] = P.y; A.prev[o + 2] = P.z;
+                                if (P.w > 0.0f) {
+                                    vx = vx + tp.hgx; vy = vy + tp.hgy; vz = vz + tp.hgz;
+                                    float hx = tp.h * vx, hy = tp.h * vy, hz = tp.h * vz;
+                                    P.x = P.x + hx; P.y = P.y + hy; P.z = P.z + hz;
+                                    lds_pos[l] = P;
+                                }
+                            }
+                        }
+                } else if (QUADS) {
+                    if (tid < cnt) {
+                        const uint2 pr = A.q_idx[cur_q + tid];
+                        const float2 rest = A.q_rest[cur_q + tid];
+                        const int i0 = pr.x & 0xffffu, i1 = pr.x >> 16, i2 = pr.y & 0xffffu, i3 = pr.y >> 16;
+                        float4 p0 = lds_pos[i0], p1 = lds_pos[i1], p2 = lds_pos[i2], p3 = lds_pos[i3];
+                        bool ok = type == 1 ? project_volume(p0, p1, p2, p3, rest.x, tp.at_v)
+                                            : project_bending(p0, p1, p2, p3, rest, tp.at_b);
+                        if (ok) { lds_pos[i0] = p0; lds_pos[i1] = p1; lds_pos[i2] = p2; lds_pos[i3] = p3; }
+                    }
+                    cur_q += cnt;
+                }
+                prefetch(j);
+                __syncthreads();
+                ++r;
+            }
+        }
+    }
+#pragma unroll
+    for (int m = 0; m < kPPT; ++m)
+        if (g[m] >= 0) A.pos[g[m]] = lds_pos[tid + m * kTileThreads];
 }
 
 // Global-colour kernels: one constraint per lane, gather/scatter straight on HBM.
@@ -230,26 +298,28 @@ __global__ __launch_bounds__(256) void global_quad_kernel(float4 *pos, const int
     if (ok) { pos[e.x] = p0; pos[e.y] = p1; pos[e.z] = p2; pos[e.w] = p3; }
 }
 
-// SPEC.md §2 step 3 at the end of a tick (inside the tick it is fused into the next P1 load).
-__global__ __launch_bounds__(256) void velocity_kernel(const float4 *pos, const float *prev, float *vel, int n_owned,
-                                                       const TickParams *tpp) {
-    const int g = blockIdx.x * 256 + threadIdx.x;
-    if (g >= n_owned) return;
-    const float inv_h = tpp->inv_h, kd = tpp->kd;
-    const float4 X = pos[g];
-    float dx = X.x - prev[3 * (size_t)g + 0], dy = X.y - prev[3 * (size_t)g + 1], dz = X.z - prev[3 * (size_t)g + 2];
-    float qx = dx * inv_h, qy = dy * inv_h, qz = dz * inv_h;
-    vel[3 * (size_t)g + 0] = qx * kd; vel[3 * (size_t)g + 1] = qy * kd; vel[3 * (size_t)g + 2] = qz * kd;
-}
-
-// Halo pack / unpack: ghost positions travel as float4.
-__global__ __launch_bounds__(256) void halo_pack_kernel(const float4 *pos, const int32_t *idx, float4 *buf, int count) {
+// Halo pack / unpack: ghost positions travel as float4; with WITH_PREV the previous positions follow in a
+// second float4 block (needed by the T1 kernels, which run velocity + integrate on ghosts too).
+template <bool WITH_PREV>
+__global__ __launch_bounds__(256) void halo_pack_kernel(const float4 *pos, const float *prev, const int32_t *idx,
+                                                        float4 *buf, int count) {
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k < count) buf[k] = pos[idx[k]];
+    if (k >= count) return;
+    const int g = idx[k];
+    buf[k] = pos[g];
+    if (WITH_PREV) buf[count + k] = make_float4(prev[3 * (size_t)g], prev[3 * (size_t)g + 1], prev[3 * (size_t)g + 2], 0.0f);
 }
-__global__ __launch_bounds__(256) void halo_unpack_kernel(float4 *pos, const int32_t *idx, const float4 *buf, int count) {
+template <bool WITH_PREV>
+__global__ __launch_bounds__(256) void halo_unpack_kernel(float4 *pos, float *prev, const int32_t *idx, const float4 *buf,
+                                                          int count) {
     const int k = blockIdx.x * 256 + threadIdx.x;
-    if (k < count) pos[idx[k]] = buf[k];
+    if (k >= count) return;
+    const int g = idx[k];
+    pos[g] = buf[k];
+    if (WITH_PREV) {
+        const float4 p = buf[count + k];
+        prev[3 * (size_t)g] = p.x; prev[3 * (size_t)g + 1] = p.y; prev[3 * (size_t)g + 2] = p.z;
+    }
 }
 
 }  // namespace sbk

@@ -51,13 +51,13 @@ void resolve_dims(int world, const float ext[3], const int want[3], int dims[3])
     }
 }
 
-// Greedy colouring of a list of constraints over a small local index space. Returns colour per item.
-// used: scratch masks indexed by local particle id, must be zero on entry for the touched ids; zeroed on exit.
+// Greedy colouring of `count` constraints over an index space. used[] must be zero for the touched
+// indices on entry and is zeroed again on exit. Returns the colour count, -1 if more than 128 are needed.
 template <class GetVerts>
-int greedy_colour(int count, int nverts, GetVerts get, std::vector<Mask128> &used, std::vector<int> &colour_out) {
+int greedy_colour(int64_t count, int nverts, GetVerts get, std::vector<Mask128> &used, std::vector<int> &colour_out) {
     colour_out.resize(count);
     int ncol = 0;
-    for (int k = 0; k < count; ++k) {
+    for (int64_t k = 0; k < count; ++k) {
         const int32_t *v = get(k);
         Mask128 m;
         for (int a = 0; a < nverts; ++a) m = m | used[v[a]];
@@ -67,11 +67,45 @@ int greedy_colour(int count, int nverts, GetVerts get, std::vector<Mask128> &use
         colour_out[k] = c;
         ncol = std::max(ncol, c + 1);
     }
-    for (int k = 0; k < count; ++k) {
+    for (int64_t k = 0; k < count; ++k) {
         const int32_t *v = get(k);
         for (int a = 0; a < nverts; ++a) used[v[a]] = Mask128();
     }
     return ncol;
+}
+
+// Groups sorted particle ids [b,e) of `byc` into pieces of at most `cap` by recursive median split along
+// the longest axis (plain chunks when !spatial). Appends piece start offsets (ascending) to `begins`.
+void split_group(std::vector<int32_t> &byc, int32_t b, int32_t e, int cap, bool spatial, const float *rest,
+                 std::vector<int32_t> &begins) {
+    std::vector<std::pair<int32_t, int32_t>> stack{{b, e}}, done;
+    while (!stack.empty()) {
+        auto [gb, ge] = stack.back();
+        stack.pop_back();
+        if (ge - gb <= cap) { done.push_back({gb, ge}); continue; }
+        if (!spatial) {
+            for (int32_t s = gb; s < ge; s += cap) done.push_back({s, std::min(s + cap, ge)});
+            continue;
+        }
+        double l2[3] = {1e300, 1e300, 1e300}, h2[3] = {-1e300, -1e300, -1e300};
+        for (int32_t q = gb; q < ge; ++q)
+            for (int a = 0; a < 3; ++a) {
+                double v = rest[3 * (int64_t)byc[q] + a];
+                l2[a] = std::min(l2[a], v); h2[a] = std::max(h2[a], v);
+            }
+        int ax = 0;
+        for (int a = 1; a < 3; ++a) if (h2[a] - l2[a] > h2[ax] - l2[ax]) ax = a;
+        int32_t mid = gb + (ge - gb) / 2;
+        std::sort(byc.begin() + gb, byc.begin() + ge, [&](int32_t a, int32_t b2) {
+            float va = rest[3 * (int64_t)a + ax], vb = rest[3 * (int64_t)b2 + ax];
+            if (va != vb) return va < vb;
+            return a < b2;
+        });
+        stack.push_back({mid, ge});
+        stack.push_back({gb, mid});
+    }
+    std::sort(done.begin(), done.end());
+    for (auto &d : done) begins.push_back(d.first);
 }
 
 }  // namespace
@@ -127,6 +161,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
     resolve_dims(opts.world, ext, opts.dims, P.dims);
 
     const bool tiling = opts.tile_particles > 0;
+    P.tiling = tiling;
     const int target = tiling ? opts.tile_particles : 512;
     if (target > kMaxTileLocal) throw std::runtime_error("tile_particles too large");
     int kk;
@@ -145,7 +180,6 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         nc[a] = (int)std::floor((hi[a] - org[a]) / cs) + 1;
     }
     if ((int64_t)nc[0] * nc[1] * nc[2] > (int64_t)1 << 40) throw std::runtime_error("grid too large");
-    // per particle: cell coords, shifted-cell linear id, owner
     std::vector<int64_t> cell(n), scell(n);
     P.owner_of_old.resize(n);
     for (int32_t p = 0; p < n; ++p) {
@@ -160,334 +194,304 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         scell[p] = ((int64_t)s[2] * (nc[1] + 1) + s[1]) * (nc[0] + 1) + s[0];
         P.owner_of_old[p] = (blk[2] * P.dims[1] + blk[1]) * P.dims[0] + blk[0];
     }
-    // ---- P1 clusters: group particles by (owner, cell); split oversized groups ----------------
-    // order particles by (owner, cell, old id)
+    const int cap = tiling ? std::min(kMaxTileLocal, std::max(2 * target, 64)) : 512;
+
+    // ---- tiling T1 (shifted cells), computed first so that T0 can order its particles by T1 tile ----
+    std::vector<int32_t> t1_of_old(n, 0);
+    int32_t n_t1 = 0;
+    if (tiling) {
+        std::vector<int32_t> bys(n);
+        std::iota(bys.begin(), bys.end(), 0);
+        std::sort(bys.begin(), bys.end(), [&](int32_t a, int32_t b) {
+            if (scell[a] != scell[b]) return scell[a] < scell[b];
+            return a < b;
+        });
+        std::vector<int32_t> begins;
+        for (int32_t b = 0; b < n;) {
+            int32_t e = b + 1;
+            while (e < n && scell[bys[e]] == scell[bys[b]]) ++e;
+            split_group(bys, b, e, cap, true, in.rest, begins);
+            b = e;
+        }
+        begins.push_back(n);
+        n_t1 = (int32_t)begins.size() - 1;
+        for (int32_t c = 0; c < n_t1; ++c)
+            for (int32_t q = begins[c]; q < begins[c + 1]; ++q) t1_of_old[bys[q]] = c;
+    }
+    // ---- tiling T0 (aligned cells, grouped by owner) ---------------------------------------------
     std::vector<int32_t> byc(n);
     std::iota(byc.begin(), byc.end(), 0);
-    if (tiling) {
+    if (tiling)
         std::sort(byc.begin(), byc.end(), [&](int32_t a, int32_t b) {
             if (P.owner_of_old[a] != P.owner_of_old[b]) return P.owner_of_old[a] < P.owner_of_old[b];
             if (cell[a] != cell[b]) return cell[a] < cell[b];
             return a < b;
         });
-    } else {
+    else
         std::stable_sort(byc.begin(), byc.end(), [&](int32_t a, int32_t b) { return P.owner_of_old[a] < P.owner_of_old[b]; });
-    }
-    const int cap = tiling ? std::min(kMaxTileLocal, std::max(2 * target, 64)) : 512;
-    std::vector<int32_t> p1_of_old(n);
-    std::vector<int32_t> p1_begin;  // into byc (after splitting, byc is re-ordered inside a group)
-    {
-        // recursive median split along the longest axis until <= cap
-        std::vector<std::pair<int32_t, int32_t>> stack;
-        auto emit_group = [&](int32_t b, int32_t e) {
-            stack.clear();
-            stack.push_back({b, e});
-            std::vector<std::pair<int32_t, int32_t>> done;
-            while (!stack.empty()) {
-                auto [gb, ge] = stack.back();
-                stack.pop_back();
-                if (ge - gb <= cap) { done.push_back({gb, ge}); continue; }
-                if (!tiling) {  // plain chunks
-                    for (int32_t s = gb; s < ge; s += cap) done.push_back({s, std::min(s + cap, ge)});
-                    continue;
-                }
-                double l2[3] = {1e300, 1e300, 1e300}, h2[3] = {-1e300, -1e300, -1e300};
-                for (int32_t q = gb; q < ge; ++q)
-                    for (int a = 0; a < 3; ++a) {
-                        double v = in.rest[3 * (int64_t)byc[q] + a];
-                        l2[a] = std::min(l2[a], v); h2[a] = std::max(h2[a], v);
-                    }
-                int ax = 0;
-                for (int a = 1; a < 3; ++a) if (h2[a] - l2[a] > h2[ax] - l2[ax]) ax = a;
-                int32_t mid = gb + (ge - gb) / 2;
-                std::sort(byc.begin() + gb, byc.begin() + ge, [&](int32_t a, int32_t b2) {
-                    float va = in.rest[3 * (int64_t)a + ax], vb = in.rest[3 * (int64_t)b2 + ax];
-                    if (va != vb) return va < vb;
-                    return a < b2;
-                });
-                stack.push_back({mid, ge});
-                stack.push_back({gb, mid});
-            }
-            std::sort(done.begin(), done.end());
-            for (auto &d : done) p1_begin.push_back(d.first);
-        };
-        int32_t b = 0;
-        while (b < n) {
-            int32_t e = b + 1;
-            if (tiling)
-                while (e < n && P.owner_of_old[byc[e]] == P.owner_of_old[byc[b]] && cell[byc[e]] == cell[byc[b]]) ++e;
-            else
-                while (e < n && P.owner_of_old[byc[e]] == P.owner_of_old[byc[b]]) ++e;
-            emit_group(b, e);
-            b = e;
-        }
-        p1_begin.push_back(n);
-    }
-    const int32_t n_p1 = (int32_t)p1_begin.size() - 1;
-    for (int32_t c = 0; c < n_p1; ++c)
-        for (int32_t q = p1_begin[c]; q < p1_begin[c + 1]; ++q) p1_of_old[byc[q]] = c;
-
-    // ---- classify constraints, shell flags ----------------------------------------------------
-    // cls: 1 = P1, 2 = P2, 3 = global
-    std::vector<uint8_t> cls[3];
-    std::vector<uint8_t> shell(n, 0);
-    for (int t = 0; t < 3; ++t) {
-        cls[t].assign(C.count(t), 3);
-        if (!tiling) continue;
-        for (int64_t k = 0; k < C.count(t); ++k) {
-            const int32_t *v = C.idx(t, k);
-            bool same = true;
-            for (int a = 1; a < kVerts[t]; ++a) same &= p1_of_old[v[a]] == p1_of_old[v[0]];
-            if (same) cls[t][k] = 1;
-            else for (int a = 0; a < kVerts[t]; ++a) shell[v[a]] = 1;
-        }
-    }
-    // ---- final numbering: inside a P1 cluster order by (shell, shifted cell, old id) ----------
-    P.old_of_new.resize(n);
-    P.new_of_old.resize(n);
-    for (int32_t c = 0; c < n_p1; ++c) {
+    std::vector<int32_t> t0_begin;
+    for (int32_t b = 0; b < n;) {
+        int32_t e = b + 1;
         if (tiling)
-            std::sort(byc.begin() + p1_begin[c], byc.begin() + p1_begin[c + 1], [&](int32_t a, int32_t b) {
-                if (shell[a] != shell[b]) return shell[a] < shell[b];
-                if (scell[a] != scell[b]) return scell[a] < scell[b];
+            while (e < n && P.owner_of_old[byc[e]] == P.owner_of_old[byc[b]] && cell[byc[e]] == cell[byc[b]]) ++e;
+        else
+            while (e < n && P.owner_of_old[byc[e]] == P.owner_of_old[byc[b]]) ++e;
+        split_group(byc, b, e, cap, tiling, in.rest, t0_begin);
+        b = e;
+    }
+    t0_begin.push_back(n);
+    const int32_t n_t0 = (int32_t)t0_begin.size() - 1;
+    std::vector<int32_t> t0_of_old(n);
+    for (int32_t c = 0; c < n_t0; ++c) {
+        // final order inside a T0 tile: by T1 tile, then original id -> T0∩T1 pieces are contiguous
+        if (tiling)
+            std::sort(byc.begin() + t0_begin[c], byc.begin() + t0_begin[c + 1], [&](int32_t a, int32_t b) {
+                if (t1_of_old[a] != t1_of_old[b]) return t1_of_old[a] < t1_of_old[b];
                 return a < b;
             });
         else
-            std::sort(byc.begin() + p1_begin[c], byc.begin() + p1_begin[c + 1]);
+            std::sort(byc.begin() + t0_begin[c], byc.begin() + t0_begin[c + 1]);
+        for (int32_t q = t0_begin[c]; q < t0_begin[c + 1]; ++q) t0_of_old[byc[q]] = c;
     }
-    for (int32_t q = 0; q < n; ++q) { P.old_of_new[q] = byc[q]; P.new_of_old[byc[q]] = q; }
-    // shell segments: maximal runs of shell particles with equal (P1 cluster, shifted cell)
-    std::vector<int32_t> seg_of_new(n, -1), seg_start, seg_len;
-    if (tiling) {
-        for (int32_t q = 0; q < n; ++q) {
-            int32_t o = byc[q];
-            if (!shell[o]) continue;
-            bool fresh = q == 0 || !shell[byc[q - 1]] || p1_of_old[byc[q - 1]] != p1_of_old[o] || scell[byc[q - 1]] != scell[o];
-            if (fresh) { seg_start.push_back(q); seg_len.push_back(0); }
-            seg_of_new[q] = (int32_t)seg_start.size() - 1;
-            ++seg_len.back();
-        }
-    }
+    P.old_of_new = byc;
+    P.new_of_old.resize(n);
+    for (int32_t q = 0; q < n; ++q) P.new_of_old[byc[q]] = q;
 
-    // ---- emit helpers -------------------------------------------------------------------------
-    std::vector<Mask128> used((size_t)std::max<int>(kMaxTileLocal, 1));
-    std::vector<int> col_tmp;
-    auto push_order = [&](int type, int32_t id) { P.order_type.push_back((uint8_t)type); P.order_id.push_back(id); };
-    P.order_type.reserve(P.m[0] + P.m[1] + P.m[2]);
-    P.order_id.reserve(P.m[0] + P.m[1] + P.m[2]);
-    P.task_off.push_back(0);
-    P.group_off.push_back(0);
-
-    // Emit one tile: items[t] = constraint ids of type t (increasing), local index via loc(new idx).
-    // Returns false (and emits nothing) if some type needs more than 128 colours.
-    std::vector<int32_t> lv;  // local vertex scratch
-    auto emit_tile = [&](Cluster &cl, const std::vector<int32_t> items[3], auto loc) -> bool {
-        struct Pending { int type; std::vector<std::vector<int32_t>> by_col; };
-        std::vector<Pending> pend;
-        for (int t = 0; t < 3; ++t) {
-            const auto &it = items[t];
-            if (it.empty()) continue;
-            const int nv = kVerts[t];
-            lv.resize(it.size() * nv);
-            for (size_t k = 0; k < it.size(); ++k) {
-                const int32_t *v = C.idx(t, it[k]);
-                for (int a = 0; a < nv; ++a) lv[k * nv + a] = loc(P.new_of_old[v[a]]);
-            }
-            int ncol = greedy_colour((int)it.size(), nv, [&](int k) { return lv.data() + (size_t)k * nv; }, used, col_tmp);
-            if (ncol < 0) return false;
-            Pending pd; pd.type = t; pd.by_col.resize(ncol);
-            for (size_t k = 0; k < it.size(); ++k) pd.by_col[col_tmp[k]].push_back((int32_t)k);
-            // commit below (needs lv, which is per type) -> do it now into temporaries
-            pend.push_back(std::move(pd));
-            Pending &pp = pend.back();
-            // stash local indices inside by_col as packed entries: replace item index by position; keep lv copy
-            // (emit immediately: order inside a tile is type-major, so committing per type is fine)
-            for (auto &colv : pp.by_col) {
-                ColourEntry ce; ce.type = t; ce.count = (int32_t)colv.size();
-                ce.begin = t == 0 ? (int64_t)P.t_dist.size() : (int64_t)P.t_quad_id.size();
-                for (int32_t k : colv) {
-                    const int32_t *l = lv.data() + (size_t)k * nv;
-                    if (t == 0) {
-                        P.t_dist.push_back((uint32_t)l[0] | ((uint32_t)l[1] << 16));
-                        P.t_dist_id.push_back(it[k]);
-                    } else {
-                        P.t_quad.push_back((uint32_t)l[0] | ((uint32_t)l[1] << 16));
-                        P.t_quad.push_back((uint32_t)l[2] | ((uint32_t)l[3] << 16));
-                        P.t_quad_id.push_back(it[k]);
-                        P.t_quad_type.push_back((uint8_t)t);
-                    }
-                    push_order(t, it[k]);
-                }
-                P.colours.push_back(ce);
-                P.group_off.push_back((int64_t)P.order_id.size());
-            }
-        }
-        return true;
-    };
-
-    // ---- phase P1 -----------------------------------------------------------------------------
+    // ---- tiles: runs and tile-local indices ------------------------------------------------------
+    std::vector<int32_t> lidx[2];           // tile-local index of every particle (new numbering)
+    const std::vector<int32_t> *tile_of[2] = {&t0_of_old, &t1_of_old};
+    const int32_t n_tiles[2] = {n_t0, tiling ? n_t1 : 0};
     {
-        Phase ph; ph.kind = 1; ph.type = -1; ph.fused_integrate = true; ph.needs_halo = false;
-        ph.order_begin = 0; ph.task_begin = 0; ph.cluster_begin = 0;
-        // bucket P1 constraints by cluster (ids increasing inside a bucket)
-        std::vector<int64_t> off[3];
-        std::vector<int32_t> lst[3];
-        for (int t = 0; t < 3; ++t) {
-            off[t].assign((size_t)n_p1 + 1, 0);
-            for (int64_t k = 0; k < C.count(t); ++k) if (cls[t][k] == 1) ++off[t][p1_of_old[C.idx(t, k)[0]] + 1];
-            for (int32_t c = 0; c < n_p1; ++c) off[t][c + 1] += off[t][c];
-            lst[t].resize(off[t][n_p1]);
-            std::vector<int64_t> cur(off[t].begin(), off[t].end() - 1);
-            for (int64_t k = 0; k < C.count(t); ++k) if (cls[t][k] == 1) lst[t][cur[p1_of_old[C.idx(t, k)[0]]]++] = (int32_t)k;
+        Tiling &A = P.T[0];
+        A.tiles.resize(n_t0);
+        lidx[0].resize(n);
+        for (int32_t c = 0; c < n_t0; ++c) {
+            Tile &t = A.tiles[c];
+            t = Tile();
+            t.owner = P.owner_of_old[byc[t0_begin[c]]];
+            t.run_begin = (int32_t)A.runs.size(); t.run_count = 1;
+            t.n_local = t0_begin[c + 1] - t0_begin[c];
+            A.runs.push_back({t0_begin[c], t.n_local});
+            for (int32_t q = t0_begin[c]; q < t0_begin[c + 1]; ++q) lidx[0][q] = q - t0_begin[c];
+            A.max_local = std::max(A.max_local, t.n_local);
         }
-        std::vector<int32_t> items[3];
-        for (int32_t c = 0; c < n_p1; ++c) {
-            Cluster cl;
-            cl.owner = P.owner_of_old[byc[p1_begin[c]]];
-            cl.run_begin = (int32_t)P.runs.size(); cl.run_count = 1;
-            P.runs.push_back({p1_begin[c], p1_begin[c + 1] - p1_begin[c]});
-            cl.n_local = p1_begin[c + 1] - p1_begin[c];
-            cl.col_begin = (int32_t)P.colours.size();
-            cl.order_begin = (int64_t)P.order_id.size();
-            for (int t = 0; t < 3; ++t) items[t].assign(lst[t].begin() + off[t][c], lst[t].begin() + off[t][c + 1]);
-            const int32_t base = p1_begin[c];
-            size_t sv_d = P.t_dist.size(), sv_q = P.t_quad_id.size(), sv_c = P.colours.size(), sv_o = P.order_id.size(), sv_g = P.group_off.size();
-            if (!emit_tile(cl, items, [&](int32_t nw) { return nw - base; })) {
-                // more than 128 colours inside one tile: push its constraints to the global phases
-                P.t_dist.resize(sv_d); P.t_dist_id.resize(sv_d); P.t_quad.resize(2 * sv_q); P.t_quad_id.resize(sv_q);
-                P.t_quad_type.resize(sv_q); P.colours.resize(sv_c); P.order_id.resize(sv_o); P.order_type.resize(sv_o); P.group_off.resize(sv_g);
-                for (int t = 0; t < 3; ++t) for (int32_t k : items[t]) cls[t][k] = 3;
-            }
-            cl.col_count = (int32_t)P.colours.size() - cl.col_begin;
-            cl.order_end = (int64_t)P.order_id.size();
-            P.clusters.push_back(cl);
-            P.task_off.push_back(cl.order_end);
-            P.max_tile_local = std::max(P.max_tile_local, cl.n_local);
-            P.max_tile_runs = std::max(P.max_tile_runs, 1);
-        }
-        ph.cluster_end = (int32_t)P.clusters.size();
-        ph.order_end = (int64_t)P.order_id.size();
-        ph.task_end = (int64_t)P.task_off.size() - 1;
-        P.phases.push_back(ph);
-        P.n_tile_phases = 1;
+        A.max_runs = 1;
     }
-    // ---- phase P2: shifted cells ---------------------------------------------------------------
     if (tiling) {
-        // candidates: non-P1 constraints whose particles share a shifted cell
-        struct Cand { int64_t sc; int32_t type; int32_t id; };
-        std::vector<Cand> cand;
-        for (int t = 0; t < 3; ++t)
-            for (int64_t k = 0; k < C.count(t); ++k) {
-                if (cls[t][k] != 3) continue;
-                const int32_t *v = C.idx(t, k);
-                bool same = true;
-                for (int a = 1; a < kVerts[t]; ++a) same &= scell[v[a]] == scell[v[0]];
-                if (same) cand.push_back({scell[v[0]], t, (int32_t)k});
-            }
-        std::sort(cand.begin(), cand.end(), [](const Cand &a, const Cand &b) {
-            if (a.sc != b.sc) return a.sc < b.sc;
-            if (a.type != b.type) return a.type < b.type;
-            return a.id < b.id;
-        });
-        Phase ph; ph.kind = 1; ph.type = -1; ph.fused_integrate = false; ph.needs_halo = false;
-        ph.order_begin = (int64_t)P.order_id.size(); ph.task_begin = (int64_t)P.task_off.size() - 1;
-        ph.cluster_begin = (int32_t)P.clusters.size();
-        std::vector<int32_t> items[3], segs, seg_lstart;
-        size_t b = 0;
-        while (b < cand.size()) {
-            size_t e = b;
-            while (e < cand.size() && cand[e].sc == cand[b].sc) ++e;
-            for (int t = 0; t < 3; ++t) items[t].clear();
-            segs.clear();
-            for (size_t q = b; q < e; ++q) {
-                items[cand[q].type].push_back(cand[q].id);
-                const int32_t *v = C.idx(cand[q].type, cand[q].id);
-                for (int a = 0; a < kVerts[cand[q].type]; ++a) segs.push_back(seg_of_new[P.new_of_old[v[a]]]);
-            }
-            std::sort(segs.begin(), segs.end());
-            segs.erase(std::unique(segs.begin(), segs.end()), segs.end());
-            int32_t nl = 0;
-            seg_lstart.resize(segs.size());
-            for (size_t s = 0; s < segs.size(); ++s) { seg_lstart[s] = nl; nl += seg_len[segs[s]]; }
-            bool ok = nl <= kMaxTileLocal && (int)segs.size() <= kMaxTileRuns;
-            if (ok) {
-                Cluster cl; cl.owner = -1;
-                cl.run_begin = (int32_t)P.runs.size(); cl.run_count = (int32_t)segs.size();
-                bool multi = false; int own0 = -1;
-                for (size_t s = 0; s < segs.size(); ++s) {
-                    P.runs.push_back({seg_start[segs[s]], seg_len[segs[s]]});
-                    int ow = P.owner_of_old[byc[seg_start[segs[s]]]];
-                    if (own0 < 0) own0 = ow; else if (ow != own0) multi = true;
-                }
-                cl.owner = multi ? -1 : own0;
-                cl.n_local = nl;
-                cl.col_begin = (int32_t)P.colours.size();
-                cl.order_begin = (int64_t)P.order_id.size();
-                size_t sv_d = P.t_dist.size(), sv_q = P.t_quad_id.size(), sv_c = P.colours.size(), sv_o = P.order_id.size(), sv_g = P.group_off.size();
-                auto loc = [&](int32_t nw) {
-                    int32_t sg = seg_of_new[nw];
-                    size_t s = std::lower_bound(segs.begin(), segs.end(), sg) - segs.begin();
-                    return seg_lstart[s] + (nw - seg_start[sg]);
-                };
-                if (emit_tile(cl, items, loc)) {
-                    cl.col_count = (int32_t)P.colours.size() - cl.col_begin;
-                    cl.order_end = (int64_t)P.order_id.size();
-                    P.clusters.push_back(cl);
-                    P.task_off.push_back(cl.order_end);
-                    P.max_tile_local = std::max(P.max_tile_local, cl.n_local);
-                    P.max_tile_runs = std::max(P.max_tile_runs, cl.run_count);
-                    for (size_t q = b; q < e; ++q) cls[cand[q].type][cand[q].id] = 2;
-                    if (multi) ph.needs_halo = true;
-                } else {
-                    P.t_dist.resize(sv_d); P.t_dist_id.resize(sv_d); P.t_quad.resize(2 * sv_q); P.t_quad_id.resize(sv_q);
-                    P.t_quad_type.resize(sv_q); P.colours.resize(sv_c); P.order_id.resize(sv_o); P.order_type.resize(sv_o); P.group_off.resize(sv_g);
-                    P.runs.resize(cl.run_begin);
-                }
-            }
-            b = e;
+        Tiling &B = P.T[1];
+        B.tiles.resize(n_t1);
+        lidx[1].resize(n);
+        // segments = maximal ranges of the new numbering with equal (T0 tile, T1 tile)
+        struct Seg { int32_t t1, start, len; };
+        std::vector<Seg> segs;
+        for (int32_t q = 0; q < n;) {
+            int32_t e = q + 1;
+            while (e < n && t1_of_old[byc[e]] == t1_of_old[byc[q]] && t0_of_old[byc[e]] == t0_of_old[byc[q]]) ++e;
+            segs.push_back({t1_of_old[byc[q]], q, e - q});
+            q = e;
         }
-        ph.cluster_end = (int32_t)P.clusters.size();
-        ph.order_end = (int64_t)P.order_id.size();
-        ph.task_end = (int64_t)P.task_off.size() - 1;
-        if (ph.cluster_end > ph.cluster_begin) { P.phases.push_back(ph); P.n_tile_phases = 2; }
+        std::stable_sort(segs.begin(), segs.end(), [](const Seg &a, const Seg &b) { return a.t1 < b.t1; });
+        size_t si = 0;
+        for (int32_t c = 0; c < n_t1; ++c) {
+            Tile &t = B.tiles[c];
+            t = Tile();
+            t.run_begin = (int32_t)B.runs.size();
+            int32_t l = 0; int own = -2;
+            while (si < segs.size() && segs[si].t1 == c) {
+                B.runs.push_back({segs[si].start, segs[si].len});
+                for (int32_t q = 0; q < segs[si].len; ++q) lidx[1][segs[si].start + q] = l + q;
+                l += segs[si].len;
+                int ow = P.owner_of_old[byc[segs[si].start]];
+                own = own == -2 ? ow : (own == ow ? ow : -1);
+                ++si;
+            }
+            t.run_count = (int32_t)B.runs.size() - t.run_begin;
+            t.n_local = l; t.owner = own;
+            if (t.run_count > kMaxTileRuns) throw std::runtime_error("a shifted tile is split into too many runs");
+            B.max_local = std::max(B.max_local, l);
+            B.max_runs = std::max(B.max_runs, t.run_count);
+        }
     }
-    P.cons_in_tiles = (int64_t)P.order_id.size();
-    // ---- global colour phases for the rest ----------------------------------------------------
+
+    // ---- classify constraints --------------------------------------------------------------------
+    // bit0: inside T0, bit1: inside T1
+    std::vector<uint8_t> cls[3];
+    for (int t = 0; t < 3; ++t) {
+        cls[t].assign(C.count(t), 0);
+        if (!tiling) continue;
+        for (int64_t k = 0; k < C.count(t); ++k) {
+            const int32_t *v = C.idx(t, k);
+            bool s0 = true, s1 = true;
+            for (int a = 1; a < kVerts[t]; ++a) { s0 &= t0_of_old[v[a]] == t0_of_old[v[0]]; s1 &= t1_of_old[v[a]] == t1_of_old[v[0]]; }
+            cls[t][k] = (uint8_t)((s0 ? 1 : 0) | (s1 ? 2 : 0));
+        }
+    }
+
+    // ---- tile programs ---------------------------------------------------------------------------
+    // seq[tl][part] = (type,id) in execution order, part 0 = cross, 1 = full; tile slices recorded in the tiles
+    std::vector<uint8_t> seq_type[2][2];
+    std::vector<int32_t> seq_id[2][2];
+    std::vector<int64_t> seq_groups[2][2];   // group boundaries (end offsets) inside seq
+    std::vector<Mask128> used((size_t)kMaxTileLocal);
+    std::vector<int> col_tmp;
+    std::vector<int32_t> lv;
+    for (int tl = 0; tl < 2; ++tl) {
+        if (n_tiles[tl] == 0) continue;
+        Tiling &TT = P.T[tl];
+        const std::vector<int32_t> &tof = *tile_of[tl];
+        const uint8_t in_bit = tl == 0 ? 1 : 2, other_bit = tl == 0 ? 2 : 1;
+        // bucket by tile: part 0 (cross) = inside this tiling but not the other; part 1 (full) = inside this tiling
+        std::vector<int64_t> off[2][3];
+        std::vector<int32_t> lst[2][3];
+        for (int part = 0; part < 2; ++part)
+            for (int t = 0; t < 3; ++t) {
+                auto want = [&](int64_t k) {
+                    uint8_t c = cls[t][k];
+                    return part == 1 ? (c & in_bit) != 0 : ((c & in_bit) != 0 && (c & other_bit) == 0);
+                };
+                auto &o = off[part][t];
+                o.assign((size_t)n_tiles[tl] + 1, 0);
+                for (int64_t k = 0; k < C.count(t); ++k) if (want(k)) ++o[tof[C.idx(t, k)[0]] + 1];
+                for (int32_t c = 0; c < n_tiles[tl]; ++c) o[c + 1] += o[c];
+                lst[part][t].resize(o[n_tiles[tl]]);
+                std::vector<int64_t> cur(o.begin(), o.end() - 1);
+                for (int64_t k = 0; k < C.count(t); ++k) if (want(k)) lst[part][t][cur[tof[C.idx(t, k)[0]]]++] = (int32_t)k;
+            }
+        for (int32_t c = 0; c < n_tiles[tl]; ++c) {
+            Tile &tile = TT.tiles[c];
+            tile.round_begin = (int32_t)TT.rounds.size();
+            tile.d_begin = (int64_t)TT.t_dist.size(); tile.q_begin = (int64_t)TT.t_quad_id.size();
+            for (int part = 0; part < 2; ++part) {
+                if (part == 1) {
+                    tile.n_pre = (int32_t)TT.rounds.size() - tile.round_begin;
+                    TT.rounds.push_back(kRoundMark);
+                    tile.d_mid = (int64_t)TT.t_dist.size(); tile.q_mid = (int64_t)TT.t_quad_id.size();
+                }
+                int64_t &ob = part == 0 ? tile.cross_order_begin : tile.full_order_begin;
+                int64_t &oe = part == 0 ? tile.cross_order_end : tile.full_order_end;
+                ob = (int64_t)seq_id[tl][part].size();
+                for (int t = 0; t < 3; ++t) {
+                    const int32_t *it = lst[part][t].data() + off[part][t][c];
+                    const int64_t cnt = off[part][t][c + 1] - off[part][t][c];
+                    if (cnt == 0) continue;
+                    const int nv = kVerts[t];
+                    lv.resize((size_t)cnt * nv);
+                    for (int64_t k = 0; k < cnt; ++k) {
+                        const int32_t *v = C.idx(t, it[k]);
+                        for (int a = 0; a < nv; ++a) lv[k * nv + a] = lidx[tl][P.new_of_old[v[a]]];
+                    }
+                    int ncol = greedy_colour(cnt, nv, [&](int64_t k) { return lv.data() + (size_t)k * nv; }, used, col_tmp);
+                    if (ncol < 0) throw std::runtime_error("a tile needs more than 128 colours (particle valence too high)");
+                    std::vector<std::vector<int32_t>> by(ncol);
+                    for (int64_t k = 0; k < cnt; ++k) by[col_tmp[k]].push_back((int32_t)k);
+                    for (auto &colv : by) {
+                        for (size_t s0 = 0; s0 < colv.size(); s0 += kRoundThreads) {
+                            size_t s1 = std::min(colv.size(), s0 + kRoundThreads);
+                            TT.rounds.push_back((uint32_t)(s1 - s0) | ((uint32_t)t << 10));
+                            for (size_t q = s0; q < s1; ++q) {
+                                const int32_t k = colv[q];
+                                const int32_t *l = lv.data() + (size_t)k * nv;
+                                if (t == 0) {
+                                    TT.t_dist.push_back((uint32_t)l[0] | ((uint32_t)l[1] << 16));
+                                    TT.t_dist_id.push_back(it[k]);
+                                } else {
+                                    TT.t_quad.push_back((uint32_t)l[0] | ((uint32_t)l[1] << 16));
+                                    TT.t_quad.push_back((uint32_t)l[2] | ((uint32_t)l[3] << 16));
+                                    TT.t_quad_id.push_back(it[k]);
+                                    TT.t_quad_type.push_back((uint8_t)t);
+                                }
+                                seq_type[tl][part].push_back((uint8_t)t);
+                                seq_id[tl][part].push_back(it[k]);
+                            }
+                            seq_groups[tl][part].push_back((int64_t)seq_id[tl][part].size());
+                        }
+                    }
+                }
+                oe = (int64_t)seq_id[tl][part].size();
+            }
+            tile.n_rounds = (int32_t)TT.rounds.size() - tile.round_begin;
+            tile.d_end = (int64_t)TT.t_dist.size(); tile.q_end = (int64_t)TT.t_quad_id.size();
+        }
+    }
+
+    // ---- global colours for constraints inside neither tiling ------------------------------------
     {
         std::vector<Mask128> gused;
         std::vector<int32_t> left;
         std::vector<int> colr;
         for (int t = 0; t < 3; ++t) {
             left.clear();
-            for (int64_t k = 0; k < C.count(t); ++k) if (cls[t][k] == 3) left.push_back((int32_t)k);
+            for (int64_t k = 0; k < C.count(t); ++k) if (cls[t][k] == 0) left.push_back((int32_t)k);
             if (left.empty()) continue;
             if (gused.empty()) gused.assign(n, Mask128());
             const int nv = kVerts[t];
-            int ncol = greedy_colour((int)left.size(), nv, [&](int k) { return C.idx(t, left[k]); }, gused, colr);
+            int ncol = greedy_colour((int64_t)left.size(), nv, [&](int64_t k) { return C.idx(t, left[k]); }, gused, colr);
             if (ncol < 0) throw std::runtime_error("constraint graph needs more than 128 colours");
-            std::vector<std::vector<int32_t>> by(ncol);
-            for (size_t k = 0; k < left.size(); ++k) by[colr[k]].push_back(left[k]);
-            for (int c = 0; c < ncol; ++c) {
-                Phase ph; ph.kind = 0; ph.type = t; ph.fused_integrate = false; ph.needs_halo = false;
-                ph.order_begin = (int64_t)P.order_id.size(); ph.task_begin = (int64_t)P.task_off.size() - 1;
-                int cnt = 0;
-                for (int32_t id : by[c]) {
-                    push_order(t, id);
-                    if (++cnt == 256) { P.task_off.push_back((int64_t)P.order_id.size()); P.group_off.push_back((int64_t)P.order_id.size()); cnt = 0; }
-                    if (opts.world > 1 && !ph.needs_halo) {
-                        const int32_t *v = C.idx(t, id);
-                        for (int a = 1; a < nv; ++a) if (P.owner_of_old[v[a]] != P.owner_of_old[v[0]]) ph.needs_halo = true;
-                    }
-                }
-                if (cnt) { P.task_off.push_back((int64_t)P.order_id.size()); P.group_off.push_back((int64_t)P.order_id.size()); }
-                ph.order_end = (int64_t)P.order_id.size(); ph.task_end = (int64_t)P.task_off.size() - 1;
-                P.phases.push_back(ph);
-                ++P.n_global_colours;
+            size_t base = P.gcolours.size();
+            P.gcolours.resize(base + ncol);
+            for (int c = 0; c < ncol; ++c) P.gcolours[base + c].type = t;
+            for (size_t k = 0; k < left.size(); ++k) {
+                GColour &g = P.gcolours[base + colr[k]];
+                g.ids.push_back(left[k]);
+                const int32_t *v = C.idx(t, left[k]);
+                for (int a = 1; a < nv; ++a) if (P.owner_of_old[v[a]] != P.owner_of_old[v[0]]) g.cut = true;
             }
+            P.cons_in_global += (int64_t)left.size();
         }
     }
-    P.cons_in_global = (int64_t)P.order_id.size() - P.cons_in_tiles;
-    if ((int64_t)P.order_id.size() != P.m[0] + P.m[1] + P.m[2]) throw std::runtime_error("planner lost constraints");
+    P.cons_in_tiles = P.m[0] + P.m[1] + P.m[2] - P.cons_in_global;
+
+    // ---- published orders per parity --------------------------------------------------------------
+    for (int p = 0; p < 2; ++p) {
+        auto &ot = P.order_type[p]; auto &oi = P.order_id[p];
+        auto &tasks = P.task_off[p]; auto &groups = P.group_off[p];
+        tasks.push_back(0); groups.push_back(0);
+        const int tf = tiling ? p : 0;           // tiling whose tiles run their full part
+        const int tc = tiling ? 1 - p : -1;      // tiling whose tiles run their cross part
+        auto append_tiles = [&](int tl, int part, int kind) {
+            Phase ph; ph.kind = kind; ph.type = -1; ph.tiling = tl; ph.gcolour = -1; ph.halo_slot = -1;
+            ph.order_begin = (int64_t)oi.size(); ph.task_begin = (int64_t)tasks.size() - 1;
+            const int64_t base = (int64_t)oi.size();
+            ot.insert(ot.end(), seq_type[tl][part].begin(), seq_type[tl][part].end());
+            oi.insert(oi.end(), seq_id[tl][part].begin(), seq_id[tl][part].end());
+            for (int64_t g : seq_groups[tl][part]) groups.push_back(base + g);
+            for (Tile &tile : P.T[tl].tiles) {
+                int64_t &b = part == 0 ? tile.cross_order_begin : tile.full_order_begin;
+                int64_t &e = part == 0 ? tile.cross_order_end : tile.full_order_end;
+                if (e > b) tasks.push_back(base + e);
+                // rebase tile slices to the published order (done once: slices of parity `p` order)
+                b += base; e += base;
+            }
+            ph.order_end = (int64_t)oi.size(); ph.task_end = (int64_t)tasks.size() - 1;
+            if (ph.order_end > ph.order_begin) P.phases[p].push_back(ph);
+        };
+        // full part of tiling tf lives in order[tf]; cross part of tiling tc lives in order[1-tc] = order[p]
+        if (!P.T[tf].tiles.empty() && (tiling || p == 0)) append_tiles(tf, 1, 1);
+        for (size_t gc = 0; gc < P.gcolours.size(); ++gc) {
+            const GColour &g = P.gcolours[gc];
+            Phase ph; ph.kind = 0; ph.type = g.type; ph.tiling = -1; ph.gcolour = (int)gc;
+            ph.halo_slot = g.cut ? 2 + (int)gc : -1;
+            ph.order_begin = (int64_t)oi.size(); ph.task_begin = (int64_t)tasks.size() - 1;
+            int cnt = 0;
+            for (int32_t id : g.ids) {
+                ot.push_back((uint8_t)g.type); oi.push_back(id);
+                if (++cnt == kRoundThreads) { tasks.push_back((int64_t)oi.size()); groups.push_back((int64_t)oi.size()); cnt = 0; }
+            }
+            if (cnt) { tasks.push_back((int64_t)oi.size()); groups.push_back((int64_t)oi.size()); }
+            ph.order_end = (int64_t)oi.size(); ph.task_end = (int64_t)tasks.size() - 1;
+            P.phases[p].push_back(ph);
+        }
+        if (tc >= 0 && !P.T[tc].tiles.empty()) append_tiles(tc, 0, 2);
+        if ((int64_t)oi.size() != P.m[0] + P.m[1] + P.m[2]) throw std::runtime_error("planner lost constraints");
+    }
+    // halo slot 1: T1 tiles with more than one owner need ghosts (positions and previous positions)
+    if (tiling && opts.world > 1) {
+        bool multi = false;
+        for (const Tile &t : P.T[1].tiles) multi |= t.owner < 0;
+        if (multi)
+            for (int p = 0; p < 2; ++p)
+                for (Phase &ph : P.phases[p]) if (ph.kind != 0 && ph.tiling == 1 && ph.kind == 2) ph.halo_slot = 1;
+    }
 }
 
 void extract_local(const Plan &P, const Input &in, int rank, LocalPlan &L) {
@@ -497,80 +501,84 @@ void extract_local(const Plan &P, const Input &in, int rank, LocalPlan &L) {
     const int world = P.opts.world;
     Cons C{&in};
     auto owner_new = [&](int32_t nw) { return P.owner_of_old[P.old_of_new[nw]]; };
-    // owned range in new numbering (sorted by owner first)
-    int32_t ob = 0, oe = 0;
-    {
-        ob = n; oe = n;
-        for (int32_t q = 0; q < n; ++q) if (owner_new(q) == rank) { ob = q; break; }
-        for (int32_t q = ob; q < n; ++q) if (owner_new(q) != rank) { oe = q; break; }
-        if (ob == n) ob = oe = 0;
-    }
+    int32_t ob = n, oe = n;
+    for (int32_t q = 0; q < n; ++q) if (owner_new(q) == rank) { ob = q; break; }
+    for (int32_t q = ob; q < n; ++q) if (owner_new(q) != rank) { oe = q; break; }
+    if (ob == n) ob = oe = 0;
     L.n_owned = oe - ob;
-    // which items does `r` execute, and which particles do they touch? Walk all phases once, for all ranks,
-    // collecting (phase, consumer rank, particle new idx) triples where particle owner != consumer.
-    struct Need { int32_t phase, consumer, nw; };
+    // (slot, consumer rank, particle) triples where the particle's owner differs from the consumer and
+    // either side is this rank
+    struct Need { int32_t slot, consumer, nw; };
     std::vector<Need> needs;
-    L.order_mask.assign(P.order_id.size(), 0);
-    L.phases.resize(P.phases.size());
+    L.halo.resize(2 + P.gcolours.size());
+    for (auto &h : L.halo) { h.send_idx.assign(world, {}); h.recv_idx.assign(world, {}); }
+    for (int p = 0; p < 2; ++p) L.order_mask[p].assign(P.order_id[p].size(), 0);
     std::vector<int> owners;
-    for (size_t ph = 0; ph < P.phases.size(); ++ph) {
-        const Phase &F = P.phases[ph];
-        LocalPhase &LP = L.phases[ph];
-        LP.kind = F.kind; LP.type = F.type; LP.fused_integrate = F.fused_integrate; LP.needs_halo = F.needs_halo;
-        LP.send_idx.assign(world, {}); LP.recv_idx.assign(world, {});
-        if (F.kind == 1) {
-            for (int32_t c = F.cluster_begin; c < F.cluster_end; ++c) {
-                const Cluster &cl = P.clusters[c];
+    // tiles
+    for (int tl = 0; tl < 2; ++tl) {
+        const Tiling &TT = P.T[tl];
+        for (int32_t c = 0; c < (int32_t)TT.tiles.size(); ++c) {
+            const Tile &tile = TT.tiles[c];
+            bool mine;
+            if (tile.owner >= 0) {
+                mine = tile.owner == rank;
+            } else {
                 owners.clear();
-                for (int r = 0; r < cl.run_count; ++r) owners.push_back(owner_new(P.runs[cl.run_begin + r].start));
+                for (int r = 0; r < tile.run_count; ++r) owners.push_back(owner_new(TT.runs[tile.run_begin + r].start));
                 std::sort(owners.begin(), owners.end());
                 owners.erase(std::unique(owners.begin(), owners.end()), owners.end());
-                bool mine = std::binary_search(owners.begin(), owners.end(), rank);
-                if (mine) {
-                    LP.cluster_ids.push_back(c);
-                    for (int64_t k = cl.order_begin; k < cl.order_end; ++k) L.order_mask[k] = 1;
-                }
-                if (owners.size() > 1)
-                    for (int r = 0; r < cl.run_count; ++r) {
-                        const Run &rn = P.runs[cl.run_begin + r];
-                        int ow = owner_new(rn.start);
-                        for (int cons : owners) {
-                            if (cons == ow) continue;
-                            if (cons != rank && ow != rank) continue;  // only triples that involve me
-                            for (int32_t q = 0; q < rn.len; ++q) needs.push_back({(int32_t)ph, cons, rn.start + q});
-                        }
+                mine = std::binary_search(owners.begin(), owners.end(), rank);
+                for (int r = 0; r < tile.run_count; ++r) {
+                    const Run &rn = TT.runs[tile.run_begin + r];
+                    int ow = owner_new(rn.start);
+                    for (int cons : owners) {
+                        if (cons == ow || (cons != rank && ow != rank)) continue;
+                        for (int32_t q = 0; q < rn.len; ++q) needs.push_back({1, cons, rn.start + q});
                     }
-            }
-        } else {
-            const int nv = kVerts[F.type];
-            for (int64_t k = F.order_begin; k < F.order_end; ++k) {
-                const int32_t *v = C.idx(F.type, P.order_id[k]);
-                bool mine = false, multi = false;
-                for (int a = 0; a < nv; ++a) {
-                    int ow = P.owner_of_old[v[a]];
-                    mine |= ow == rank;
-                    multi |= ow != P.owner_of_old[v[0]];
                 }
-                if (mine) L.order_mask[k] = 1;
-                if (multi)
-                    for (int a = 0; a < nv; ++a)
-                        for (int b = 0; b < nv; ++b) {
-                            int cons = P.owner_of_old[v[b]], ow = P.owner_of_old[v[a]];
-                            if (cons == ow) continue;
-                            if (cons != rank && ow != rank) continue;
-                            needs.push_back({(int32_t)ph, cons, P.new_of_old[v[a]]});
-                        }
             }
+            if (!mine) continue;
+            L.T[tl].tile_ids.push_back(c);
+            // full part is in order[tl], cross part in order[1-tl]
+            for (int64_t k = tile.full_order_begin; k < tile.full_order_end; ++k) L.order_mask[tl][k] = 1;
+            for (int64_t k = tile.cross_order_begin; k < tile.cross_order_end; ++k) L.order_mask[1 - tl][k] = 1;
         }
     }
+    // global colours: executed by every rank that owns one of the constraint's particles
+    std::vector<std::vector<int32_t>> g_exec(P.gcolours.size());
+    for (size_t gc = 0; gc < P.gcolours.size(); ++gc) {
+        const GColour &g = P.gcolours[gc];
+        const int nv = kVerts[g.type];
+        for (int32_t id : g.ids) {
+            const int32_t *v = C.idx(g.type, id);
+            bool mine = false, multi = false;
+            for (int a = 0; a < nv; ++a) { int ow = P.owner_of_old[v[a]]; mine |= ow == rank; multi |= ow != P.owner_of_old[v[0]]; }
+            if (mine) g_exec[gc].push_back(id);
+            if (multi)
+                for (int a = 0; a < nv; ++a)
+                    for (int b = 0; b < nv; ++b) {
+                        int cons = P.owner_of_old[v[b]], ow = P.owner_of_old[v[a]];
+                        if (cons == ow || (cons != rank && ow != rank)) continue;
+                        needs.push_back({2 + (int32_t)gc, cons, P.new_of_old[v[a]]});
+                    }
+        }
+    }
+    for (int p = 0; p < 2; ++p)
+        for (const Phase &ph : P.phases[p]) {
+            if (ph.kind != 0) continue;
+            // order entries of a global colour: mark the executed ones (ids are listed in the same order)
+            const auto &ex = g_exec[ph.gcolour];
+            size_t e = 0;
+            for (int64_t k = ph.order_begin; k < ph.order_end; ++k)
+                if (e < ex.size() && ex[e] == P.order_id[p][k]) { L.order_mask[p][k] = 1; ++e; }
+        }
     std::sort(needs.begin(), needs.end(), [](const Need &a, const Need &b) {
-        if (a.phase != b.phase) return a.phase < b.phase;
+        if (a.slot != b.slot) return a.slot < b.slot;
         if (a.consumer != b.consumer) return a.consumer < b.consumer;
         return a.nw < b.nw;
     });
     needs.erase(std::unique(needs.begin(), needs.end(), [](const Need &a, const Need &b) {
-        return a.phase == b.phase && a.consumer == b.consumer && a.nw == b.nw; }), needs.end());
-    // ghost set of this rank
+        return a.slot == b.slot && a.consumer == b.consumer && a.nw == b.nw; }), needs.end());
     std::vector<int32_t> ghosts;
     for (const Need &nd : needs) if (nd.consumer == rank) ghosts.push_back(nd.nw);
     std::sort(ghosts.begin(), ghosts.end());
@@ -582,43 +590,41 @@ void extract_local(const Plan &P, const Input &in, int rank, LocalPlan &L) {
         local_of_new[ghosts[g]] = (int32_t)(L.n_owned + g);
         L.local_to_old[L.n_owned + g] = P.old_of_new[ghosts[g]];
     }
-    // halo lists (both sides sorted by new idx -> same order)
     for (const Need &nd : needs) {
-        LocalPhase &LP = L.phases[nd.phase];
+        HaloSlot &H = L.halo[nd.slot];
         int ow = owner_new(nd.nw);
-        if (nd.consumer == rank) LP.recv_idx[ow].push_back(local_of_new[nd.nw]);
-        else if (ow == rank) LP.send_idx[nd.consumer].push_back(local_of_new[nd.nw]);
+        if (nd.consumer == rank) H.recv_idx[ow].push_back(local_of_new[nd.nw]);
+        else if (ow == rank) H.send_idx[nd.consumer].push_back(local_of_new[nd.nw]);
     }
-    // local phases
-    for (size_t ph = 0; ph < P.phases.size(); ++ph) {
-        const Phase &F = P.phases[ph];
-        LocalPhase &LP = L.phases[ph];
-        if (F.kind == 1) {
-            LP.run_begin.push_back(0);
-            for (int32_t c : LP.cluster_ids) {
-                const Cluster &cl = P.clusters[c];
-                for (int r = 0; r < cl.run_count; ++r) {
-                    const Run &rn = P.runs[cl.run_begin + r];
-                    int32_t ls = local_of_new[rn.start];
-                    if (ls < 0) throw std::runtime_error("internal: tile run not resident");
-                    // runs stay contiguous locally: whole segments are resident and ghosts are in new-index order
-                    if (local_of_new[rn.start + rn.len - 1] != ls + rn.len - 1) throw std::runtime_error("internal: run split");
-                    LP.runs.push_back({ls, rn.len});
-                }
-                LP.run_begin.push_back((int32_t)LP.runs.size());
+    for (int tl = 0; tl < 2; ++tl) {
+        LocalTiling &LT = L.T[tl];
+        LT.run_begin.push_back(0);
+        for (int32_t c : LT.tile_ids) {
+            const Tile &tile = P.T[tl].tiles[c];
+            for (int r = 0; r < tile.run_count; ++r) {
+                const Run &rn = P.T[tl].runs[tile.run_begin + r];
+                int32_t ls = local_of_new[rn.start];
+                if (ls < 0) throw std::runtime_error("internal: tile run not resident");
+                if (local_of_new[rn.start + rn.len - 1] != ls + rn.len - 1) throw std::runtime_error("internal: run split");
+                LT.runs.push_back({ls, rn.len});
             }
-        } else {
-            const int nv = kVerts[F.type];
-            for (int64_t k = F.order_begin; k < F.order_end; ++k) {
-                if (!L.order_mask[k]) continue;
-                const int32_t *v = C.idx(F.type, P.order_id[k]);
-                for (int a = 0; a < nv; ++a) {
-                    int32_t li = local_of_new[P.new_of_old[v[a]]];
-                    if (li < 0) throw std::runtime_error("internal: constraint particle not resident");
-                    LP.g_idx.push_back(li);
-                }
-                LP.g_id.push_back(P.order_id[k]);
+            LT.run_begin.push_back((int32_t)LT.runs.size());
+        }
+    }
+    L.gcolours.resize(P.gcolours.size());
+    for (size_t gc = 0; gc < P.gcolours.size(); ++gc) {
+        const GColour &g = P.gcolours[gc];
+        LocalGColour &LG = L.gcolours[gc];
+        LG.type = g.type;
+        const int nv = kVerts[g.type];
+        for (int32_t id : g_exec[gc]) {
+            const int32_t *v = C.idx(g.type, id);
+            for (int a = 0; a < nv; ++a) {
+                int32_t li = local_of_new[P.new_of_old[v[a]]];
+                if (li < 0) throw std::runtime_error("internal: constraint particle not resident");
+                LG.idx.push_back(li);
             }
+            LG.id.push_back(id);
         }
     }
 }

@@ -1,12 +1,22 @@
 // plan.hpp — host-side planner: tiles, colours, partition, halo schedule (pure C++, no HIP).
 //
 // No reference counterpart exists (/root/reference/README.md:1 is the whole reference tree); the
-// planner implements SPEC.md §3 and the design in DESIGN.md §3: the constraint graph is cut into
-//   phase P1  : vertex-disjoint tiles = cells of a uniform grid over the rest pose (every particle is in
-//               exactly one P1 tile, so P1 also carries integrate/velocity),
-//   phase P2  : tiles = cells of the same grid shifted by half a cell, holding the constraints P1 left,
-//   phases G* : whatever is still left, greedy edge-coloured, one global kernel per colour,
-// and the flat sequential order equivalent to that execution is published for the oracle.
+// planner implements SPEC.md §3 and DESIGN.md §3 ("two-tiling alternating schedule"):
+//
+//   tiling T0 : cells of a uniform grid over the rest pose            (a partition of the particles)
+//   tiling T1 : cells of the same grid shifted by half a cell         (another partition)
+//   in0/in1   : a constraint is "inside" a tiling when all its particles share one of its tiles
+//   G         : constraints inside neither tiling, greedy edge-coloured, one global kernel per colour
+//
+//   substep of parity p (0,1,0,1,... restarting at 0 every tick) projects, in this order,
+//     full(T_p)     = every constraint inside T_p,               tile by tile, colour by colour
+//     G             = the global colours
+//     cross(T_1-p)  = constraints inside T_1-p but not inside T_p, tile by tile, colour by colour
+//
+// cross(T_q) of one substep and full(T_q) of the next run on the same tiles, so the GPU fuses them
+// (with the per-particle velocity update + integrate between them) into ONE kernel per substep that
+// reads and writes every particle once. The flat sequential order equivalent to that execution is
+// published per parity for the oracle.
 #pragma once
 #include <cstdint>
 #include <string>
@@ -25,28 +35,52 @@ struct Run {            // a contiguous range of particles
     int32_t len;
 };
 
-struct ColourEntry {    // one colour class of one constraint type inside a tile
-    int32_t type;       // 0 distance, 1 volume, 2 bending
-    int64_t begin;      // into the phase's per-type tile-constraint arrays
-    int32_t count;
-};
+constexpr int kRoundThreads = 256;          // constraints per round (one per lane of a 256-thread workgroup)
+constexpr uint32_t kRoundMark = 3u << 10;   // round word: bits 0-9 count, bits 10-11 type (3 = velocity/integrate marker)
+constexpr int kMaxTileLocal = 1024;         // particles staged per tile (4 per lane)
+constexpr int kMaxTileRuns = 64;
 
-struct Cluster {
-    int32_t owner;          // P1: owning rank; P2: -1 (executed by every rank owning one of its runs)
+struct Tile {
+    int32_t owner;          // owning rank if all its particles have one owner, else -1
     int32_t run_begin, run_count;
     int32_t n_local;        // particles staged in LDS
-    int32_t col_begin, col_count;
-    int64_t order_begin, order_end;
+    int32_t round_begin;    // into Tiling::rounds: [cross rounds..., MARK, full rounds...]
+    int32_t n_pre;          // number of cross rounds (marker is at round_begin + n_pre)
+    int32_t n_rounds;       // including the marker
+    int64_t d_begin, q_begin;   // start of the cross part in the tiling's constraint arrays
+    int64_t d_mid, q_mid;       // start of the full part
+    int64_t d_end, q_end;
+    // slices of the published orders: cross part lives in order[1-t], full part in order[t]
+    int64_t cross_order_begin, cross_order_end, full_order_begin, full_order_end;
 };
 
-struct Phase {
-    int kind;               // 0 global colour, 1 tile
-    int type;               // kind 0: constraint type
+struct Tiling {
+    std::vector<Tile> tiles;
+    std::vector<Run> runs;
+    std::vector<uint32_t> rounds;
+    // tile constraints in execution order, tile-local particle indices (16 bit each)
+    std::vector<uint32_t> t_dist;       // lo16 = i, hi16 = j
+    std::vector<int32_t> t_dist_id;     // original constraint id (for rest values)
+    std::vector<uint32_t> t_quad;       // 2 words per 4-vertex constraint
+    std::vector<int32_t> t_quad_id;     // original id within its type
+    std::vector<uint8_t> t_quad_type;   // 1 volume, 2 bending
+    int32_t max_local = 0, max_runs = 0;
+};
+
+struct GColour {            // one global colour: constraints of one type that share no particle
+    int type;
+    std::vector<int32_t> ids;   // original ids, increasing
+    bool cut = false;           // touches particles of more than one rank
+};
+
+struct Phase {              // one entry of a parity's phase list (inspection / oracle task parallelism)
+    int kind;               // 0 global colour, 1 full(T_p), 2 cross(T_1-p)
+    int type;               // kind 0: constraint type, else -1
+    int tiling;             // kind 1/2: which tiling's tiles; kind 0: -1
+    int gcolour;            // kind 0: index into Plan::gcolours
     int64_t order_begin, order_end;
     int64_t task_begin, task_end;
-    int32_t cluster_begin = 0, cluster_end = 0;  // kind 1
-    bool fused_integrate = false;                // P1
-    bool needs_halo = false;
+    int halo_slot;          // -1 none; 1 = before the T1 kernel (x and xprev); 2+c = before global colour c (x)
 };
 
 struct Plan {
@@ -54,42 +88,33 @@ struct Plan {
     int32_t n = 0;
     int64_t m[3] = {0, 0, 0};
     int dims[3] = {1, 1, 1};
+    bool tiling = true;
     // particle numbering
     std::vector<int32_t> new_of_old, old_of_new, owner_of_old;
-    // published order (original constraint ids)
-    std::vector<uint8_t> order_type;
-    std::vector<int32_t> order_id;
-    std::vector<Phase> phases;
-    std::vector<int64_t> task_off;
-    std::vector<int64_t> group_off;   // finest independent sets: one tile colour class / one global-colour chunk
-    // tile data (all ranks)
-    std::vector<Cluster> clusters;
-    std::vector<Run> runs;
-    std::vector<ColourEntry> colours;
-    // tile constraints in execution order, cluster-local particle indices (16 bit each)
-    std::vector<uint32_t> t_dist;       // lo16 = i, hi16 = j
-    std::vector<int32_t> t_dist_id;     // original constraint id (for rest values)
-    std::vector<uint32_t> t_quad;       // 2 words per 4-vertex constraint (volume then bending share the array)
-    std::vector<int32_t> t_quad_id;     // original id within its type
-    std::vector<uint8_t> t_quad_type;
-    int32_t max_tile_local = 0, max_tile_runs = 0;
+    Tiling T[2];            // T[1] is empty when tiling is off
+    std::vector<GColour> gcolours;
+    // published orders per substep parity (original constraint ids)
+    std::vector<uint8_t> order_type[2];
+    std::vector<int32_t> order_id[2];
+    std::vector<Phase> phases[2];
+    std::vector<int64_t> task_off[2];
+    std::vector<int64_t> group_off[2];
     // stats
     int64_t cons_in_tiles = 0, cons_in_global = 0;
-    int n_tile_phases = 0, n_global_colours = 0;
 };
 
 // What one rank uploads and executes.
-struct LocalPhase {
-    int kind, type;
-    bool fused_integrate, needs_halo;
-    // kind 1
-    std::vector<int32_t> cluster_ids;       // global cluster ids, execution order
-    std::vector<Run> runs;                  // local numbering, concatenated per cluster
-    std::vector<int32_t> run_begin;         // per local cluster (+1)
-    // kind 0: constraints with local particle indices
-    std::vector<int32_t> g_idx;             // 2 or 4 per constraint
-    std::vector<int32_t> g_id;              // original id
-    // halo before this phase: per peer, local indices to send / to receive into
+struct LocalTiling {
+    std::vector<int32_t> tile_ids;          // global tile ids, execution order
+    std::vector<Run> runs;                  // local numbering, concatenated per tile
+    std::vector<int32_t> run_begin;         // per local tile (+1)
+};
+struct LocalGColour {
+    int type;
+    std::vector<int32_t> idx;               // 2 or 4 local particle indices per constraint
+    std::vector<int32_t> id;                // original id
+};
+struct HaloSlot {                           // per peer: local indices to send / to receive into
     std::vector<std::vector<int32_t>> send_idx, recv_idx;
 };
 
@@ -97,8 +122,10 @@ struct LocalPlan {
     int rank = 0, world = 1;
     int64_t n_owned = 0;
     std::vector<int32_t> local_to_old;      // owned first (global-new order), then ghosts
-    std::vector<LocalPhase> phases;
-    std::vector<uint8_t> order_mask;        // which order entries this rank executes
+    LocalTiling T[2];
+    std::vector<LocalGColour> gcolours;
+    std::vector<HaloSlot> halo;             // slot 0 unused, 1 = before T1 kernels, 2+c = before global colour c
+    std::vector<uint8_t> order_mask[2];     // which order entries this rank executes
 };
 
 struct Input {
@@ -112,8 +139,5 @@ struct Input {
 // Throws std::runtime_error on invalid input.
 void build_plan(const Input &in, const Opts &opts, Plan &out);
 void extract_local(const Plan &plan, const Input &in, int rank, LocalPlan &out);
-
-constexpr int kMaxTileLocal = 4096;   // particles staged per tile (64 KiB of LDS as float4)
-constexpr int kMaxTileRuns = 64;
 
 }  // namespace sbp

@@ -59,30 +59,33 @@ struct DevBuf {
     ~DevBuf() { free(); }
 };
 
-struct DevPhase {
-    int kind = 0, type = 0;
-    bool fused_integrate = false, needs_halo = false;
-    // tile phase
-    int32_t n_clusters = 0;
+struct DevHalo {                 // one halo slot: who we talk to and which particles travel
+    std::vector<int> peers;
+    std::vector<int32_t> send_off, recv_off;  // per peer (+1), in particles
+    DevBuf<int32_t> send_idx, recv_idx;
+    bool active() const { return !peers.empty(); }
+};
+
+struct DevTiling {
+    int32_t n_tiles = 0;
     size_t lds_bytes = 0;
-    DevBuf<sbk::ClusterDesc> cl;
-    DevBuf<int2> runs;
-    DevBuf<sbk::ColourDesc> cols;
+    int64_t n_slots = 0;         // constraint slots stored (cross + full)
+    DevBuf<sbk::TileDesc> tiles;
+    DevBuf<int2> runs_overflow;
+    DevBuf<uint32_t> rounds;
     DevBuf<uint32_t> d_idx;
     DevBuf<float> d_rest;
     DevBuf<uint2> q_idx;
     DevBuf<float2> q_rest;
-    // global phase
-    int32_t g_count = 0;
-    DevBuf<int2> g_ij;
-    DevBuf<int4> g_quad;
-    DevBuf<float> g_rest;
-    DevBuf<float2> g_rest2;
-    // halo
-    std::vector<int> peers;
-    std::vector<int32_t> send_off, recv_off;  // per peer (+1), in particles
-    DevBuf<int32_t> send_idx, recv_idx;
-    int64_t n_cons = 0;
+};
+
+struct DevGColour {
+    int type = 0;
+    int32_t count = 0;
+    DevBuf<int2> ij;
+    DevBuf<int4> quad;
+    DevBuf<float> rest;
+    DevBuf<float2> rest2;
 };
 
 }  // namespace
@@ -115,17 +118,18 @@ struct sb_solver {
     DevBuf<float> d_prev, d_vel;
     DevBuf<sbk::TickParams> d_tp;
     DevBuf<float4> d_sendbuf, d_recvbuf;
-    std::vector<std::unique_ptr<DevPhase>> phases;
+    DevTiling tiling[2];
+    std::vector<std::unique_ptr<DevGColour>> gcolours;
+    std::vector<std::unique_ptr<DevHalo>> halos;   // indexed by halo slot
     sbk::TickParams tp_host{};
     bool tp_valid = false;
     std::map<int, hipGraphExec_t> graphs;
-    int64_t launches_per_substep = 0, halo_bytes_per_substep = 0;
     std::vector<float4> h_stage;
 
     ~sb_solver() {
         for (auto &g : graphs) (void)hipGraphExecDestroy(g.second);
         if (comm) (void)ncclCommDestroy(comm);
-        phases.clear();
+        gcolours.clear(); halos.clear();
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -181,182 +185,193 @@ void build_device(sb_solver *s) {
     s->d_prev.alloc((size_t)s->n_local * 3, s->dev_bytes);
     HIP_CHECK(hipMemset(s->d_prev.p, 0, (size_t)s->n_local * 3 * sizeof(float)));
     s->d_tp.alloc(1, s->dev_bytes);
-    size_t max_send = 0, max_recv = 0;
-    s->launches_per_substep = 0;
-    s->halo_bytes_per_substep = 0;
-    for (size_t ph = 0; ph < L.phases.size(); ++ph) {
-        const sbp::LocalPhase &LP = L.phases[ph];
-        auto D = std::make_unique<DevPhase>();
-        D->kind = LP.kind; D->type = LP.type; D->fused_integrate = LP.fused_integrate;
-        if (LP.kind == 1) {
-            std::vector<sbk::ClusterDesc> cl;
-            std::vector<int2> runs;
-            std::vector<sbk::ColourDesc> cols;
-            std::vector<uint32_t> d_idx; std::vector<float> d_rest;
-            std::vector<uint2> q_idx; std::vector<float2> q_rest;
-            int32_t max_local = 0;
-            for (size_t ci = 0; ci < LP.cluster_ids.size(); ++ci) {
-                const sbp::Cluster &G = P.clusters[LP.cluster_ids[ci]];
-                sbk::ClusterDesc cd{};
-                cd.run_begin = (int32_t)runs.size();
-                cd.run_count = LP.run_begin[ci + 1] - LP.run_begin[ci];
-                int32_t lstart = 0;
-                for (int32_t r = LP.run_begin[ci]; r < LP.run_begin[ci + 1]; ++r) {
-                    runs.push_back(make_int2(LP.runs[r].start, lstart));
-                    lstart += LP.runs[r].len;
-                }
-                cd.n_local = lstart;
-                max_local = std::max(max_local, lstart);
-                cd.col_begin = (int32_t)cols.size();
-                cd.col_count = G.col_count;
-                for (int32_t c = 0; c < G.col_count; ++c) {
-                    const sbp::ColourEntry &ce = P.colours[G.col_begin + c];
-                    sbk::ColourDesc dc{};
-                    dc.type = ce.type; dc.count = ce.count;
-                    if (ce.type == 0) {
-                        dc.begin = (uint32_t)d_idx.size();
-                        for (int32_t k = 0; k < ce.count; ++k) {
-                            d_idx.push_back(P.t_dist[ce.begin + k]);
-                            d_rest.push_back(s->dist_rest[P.t_dist_id[ce.begin + k]]);
-                        }
-                    } else {
-                        dc.begin = (uint32_t)q_idx.size();
-                        for (int32_t k = 0; k < ce.count; ++k) {
-                            q_idx.push_back(make_uint2(P.t_quad[2 * (ce.begin + k)], P.t_quad[2 * (ce.begin + k) + 1]));
-                            int32_t id = P.t_quad_id[ce.begin + k];
-                            if (ce.type == 1) {
-                                volatile float r6 = 6.0f * s->vol_rest[id];
-                                q_rest.push_back(make_float2(r6, 0.0f));
-                            } else {
-                                q_rest.push_back(make_float2(s->bend_rest[2 * (size_t)id], s->bend_rest[2 * (size_t)id + 1]));
-                            }
-                        }
-                    }
-                    D->n_cons += ce.count;
-                    cols.push_back(dc);
-                }
-                cl.push_back(cd);
+    // tilings: re-base this rank's tiles onto compact device arrays
+    for (int tl = 0; tl < 2; ++tl) {
+        const sbp::Tiling &G = P.T[tl];
+        const sbp::LocalTiling &LT = L.T[tl];
+        DevTiling &D = s->tiling[tl];
+        std::vector<sbk::TileDesc> tiles;
+        std::vector<int2> overflow;
+        std::vector<uint32_t> rounds, d_idx;
+        std::vector<float> d_rest;
+        std::vector<uint2> q_idx;
+        std::vector<float2> q_rest;
+        int32_t max_local = 0;
+        for (size_t ci = 0; ci < LT.tile_ids.size(); ++ci) {
+            const sbp::Tile &T = G.tiles[LT.tile_ids[ci]];
+            sbk::TileDesc td{};
+            td.n_local = T.n_local;
+            td.run_count = LT.run_begin[ci + 1] - LT.run_begin[ci];
+            td.run_overflow = (int32_t)overflow.size();
+            int32_t lstart = 0;
+            for (int32_t r = 0; r < td.run_count; ++r) {
+                const sbp::Run &rn = LT.runs[LT.run_begin[ci] + r];
+                if (r < sbk::kInlineRuns) td.runs[r] = make_int2(rn.start, lstart);
+                else overflow.push_back(make_int2(rn.start, lstart));
+                lstart += rn.len;
             }
-            if (d_idx.size() > 0xffffffffull || q_idx.size() > 0xffffffffull) throw std::runtime_error("tile constraint offsets overflow");
-            D->n_clusters = (int32_t)cl.size();
-            D->lds_bytes = (size_t)std::max(max_local, 1) * sizeof(float4);
-            D->cl.upload(cl, s->dev_bytes); D->runs.upload(runs, s->dev_bytes); D->cols.upload(cols, s->dev_bytes);
-            D->d_idx.upload(d_idx, s->dev_bytes); D->d_rest.upload(d_rest, s->dev_bytes);
-            D->q_idx.upload(q_idx, s->dev_bytes); D->q_rest.upload(q_rest, s->dev_bytes);
-        } else {
-            D->g_count = (int32_t)LP.g_id.size();
-            D->n_cons = D->g_count;
-            if (LP.type == 0) {
-                std::vector<int2> ij(LP.g_id.size()); std::vector<float> rest(LP.g_id.size());
-                for (size_t k = 0; k < LP.g_id.size(); ++k) {
-                    ij[k] = make_int2(LP.g_idx[2 * k], LP.g_idx[2 * k + 1]);
-                    rest[k] = s->dist_rest[LP.g_id[k]];
-                }
-                D->g_ij.upload(ij, s->dev_bytes); D->g_rest.upload(rest, s->dev_bytes);
-            } else {
-                std::vector<int4> q(LP.g_id.size()); std::vector<float2> rest(LP.g_id.size());
-                for (size_t k = 0; k < LP.g_id.size(); ++k) {
-                    q[k] = make_int4(LP.g_idx[4 * k], LP.g_idx[4 * k + 1], LP.g_idx[4 * k + 2], LP.g_idx[4 * k + 3]);
-                    int32_t id = LP.g_id[k];
-                    if (LP.type == 1) { volatile float r6 = 6.0f * s->vol_rest[id]; rest[k] = make_float2(r6, 0.0f); }
-                    else rest[k] = make_float2(s->bend_rest[2 * (size_t)id], s->bend_rest[2 * (size_t)id + 1]);
-                }
-                D->g_quad.upload(q, s->dev_bytes); D->g_rest2.upload(rest, s->dev_bytes);
+            if (lstart != T.n_local) throw std::runtime_error("internal: tile run lengths do not add up");
+            max_local = std::max(max_local, T.n_local);
+            td.round_begin = (int32_t)rounds.size();
+            td.n_pre = T.n_pre; td.n_rounds = T.n_rounds;
+            rounds.insert(rounds.end(), G.rounds.begin() + T.round_begin, G.rounds.begin() + T.round_begin + T.n_rounds);
+            td.d_begin = (uint32_t)d_idx.size(); td.q_begin = (uint32_t)q_idx.size();
+            td.d_mid = td.d_begin + (uint32_t)(T.d_mid - T.d_begin);
+            td.q_mid = td.q_begin + (uint32_t)(T.q_mid - T.q_begin);
+            for (int64_t k = T.d_begin; k < T.d_end; ++k) {
+                d_idx.push_back(G.t_dist[k]);
+                d_rest.push_back(s->dist_rest[G.t_dist_id[k]]);
             }
+            for (int64_t k = T.q_begin; k < T.q_end; ++k) {
+                q_idx.push_back(make_uint2(G.t_quad[2 * k], G.t_quad[2 * k + 1]));
+                const int32_t id = G.t_quad_id[k];
+                if (G.t_quad_type[k] == 1) { volatile float r6 = 6.0f * s->vol_rest[id]; q_rest.push_back(make_float2(r6, 0.0f)); }
+                else q_rest.push_back(make_float2(s->bend_rest[2 * (size_t)id], s->bend_rest[2 * (size_t)id + 1]));
+            }
+            tiles.push_back(td);
         }
-        // halo lists
+        if (d_idx.size() > 0xfffffff0ull || q_idx.size() > 0xfffffff0ull) throw std::runtime_error("tile constraint offsets overflow");
+        D.n_tiles = (int32_t)tiles.size();
+        D.lds_bytes = (size_t)std::max(max_local, 1) * sizeof(float4);
+        D.n_slots = (int64_t)d_idx.size() + (int64_t)q_idx.size();
+        D.tiles.upload(tiles, s->dev_bytes); D.runs_overflow.upload(overflow, s->dev_bytes);
+        D.rounds.upload(rounds, s->dev_bytes);
+        D.d_idx.upload(d_idx, s->dev_bytes); D.d_rest.upload(d_rest, s->dev_bytes);
+        D.q_idx.upload(q_idx, s->dev_bytes); D.q_rest.upload(q_rest, s->dev_bytes);
+    }
+    for (const sbp::LocalGColour &LG : L.gcolours) {
+        auto D = std::make_unique<DevGColour>();
+        D->type = LG.type; D->count = (int32_t)LG.id.size();
+        if (LG.type == 0) {
+            std::vector<int2> ij(LG.id.size()); std::vector<float> rest(LG.id.size());
+            for (size_t k = 0; k < LG.id.size(); ++k) { ij[k] = make_int2(LG.idx[2 * k], LG.idx[2 * k + 1]); rest[k] = s->dist_rest[LG.id[k]]; }
+            D->ij.upload(ij, s->dev_bytes); D->rest.upload(rest, s->dev_bytes);
+        } else {
+            std::vector<int4> q(LG.id.size()); std::vector<float2> rest(LG.id.size());
+            for (size_t k = 0; k < LG.id.size(); ++k) {
+                q[k] = make_int4(LG.idx[4 * k], LG.idx[4 * k + 1], LG.idx[4 * k + 2], LG.idx[4 * k + 3]);
+                const int32_t id = LG.id[k];
+                if (LG.type == 1) { volatile float r6 = 6.0f * s->vol_rest[id]; rest[k] = make_float2(r6, 0.0f); }
+                else rest[k] = make_float2(s->bend_rest[2 * (size_t)id], s->bend_rest[2 * (size_t)id + 1]);
+            }
+            D->quad.upload(q, s->dev_bytes); D->rest2.upload(rest, s->dev_bytes);
+        }
+        s->gcolours.push_back(std::move(D));
+    }
+    size_t max_send = 0, max_recv = 0;
+    for (size_t slot = 0; slot < L.halo.size(); ++slot) {
+        const sbp::HaloSlot &H = L.halo[slot];
+        auto D = std::make_unique<DevHalo>();
         std::vector<int32_t> sidx, ridx;
         D->send_off.push_back(0); D->recv_off.push_back(0);
         for (int peer = 0; peer < L.world; ++peer) {
-            if (LP.send_idx[peer].empty() && LP.recv_idx[peer].empty()) continue;
+            if (H.send_idx[peer].empty() && H.recv_idx[peer].empty()) continue;
             D->peers.push_back(peer);
-            sidx.insert(sidx.end(), LP.send_idx[peer].begin(), LP.send_idx[peer].end());
-            ridx.insert(ridx.end(), LP.recv_idx[peer].begin(), LP.recv_idx[peer].end());
+            sidx.insert(sidx.end(), H.send_idx[peer].begin(), H.send_idx[peer].end());
+            ridx.insert(ridx.end(), H.recv_idx[peer].begin(), H.recv_idx[peer].end());
             D->send_off.push_back((int32_t)sidx.size()); D->recv_off.push_back((int32_t)ridx.size());
         }
-        D->needs_halo = !D->peers.empty();
         D->send_idx.upload(sidx, s->dev_bytes); D->recv_idx.upload(ridx, s->dev_bytes);
-        max_send = std::max(max_send, sidx.size()); max_recv = std::max(max_recv, ridx.size());
-        s->halo_bytes_per_substep += (int64_t)sidx.size() * 16;
-        if (D->kind == 1 ? D->n_clusters > 0 : D->g_count > 0) ++s->launches_per_substep;
-        if (D->needs_halo) s->launches_per_substep += 2;
-        s->phases.push_back(std::move(D));
+        const size_t mult = slot == 1 ? 2 : 1;   // slot 1 also carries previous positions
+        max_send = std::max(max_send, sidx.size() * mult); max_recv = std::max(max_recv, ridx.size() * mult);
+        s->halos.push_back(std::move(D));
     }
     s->d_sendbuf.alloc(max_send, s->dev_bytes);
     s->d_recvbuf.alloc(max_recv, s->dev_bytes);
 }
 
-void halo_exchange(sb_solver *s, DevPhase &D) {
-    if (!D.needs_halo) return;
+// Ghost refresh for one halo slot. Buffers hold [positions of all peers][previous positions of all peers];
+// each peer's share is sent as one message per block.
+void halo_exchange(sb_solver *s, int slot) {
+    if (slot < 0 || slot >= (int)s->halos.size()) return;
+    DevHalo &D = *s->halos[slot];
+    if (!D.active()) return;
     if (!s->comm) throw HipError(SB_ERR_STATE, "world > 1 needs sb_comm_init before sb_finalize");
+    const bool with_prev = slot == 1;
     const int ns = D.send_off.back(), nr = D.recv_off.back();
-    if (ns) hipLaunchKernelGGL(sbk::halo_pack_kernel, dim3((ns + 255) / 256), dim3(256), 0, s->stream, s->d_pos.p,
-                               D.send_idx.p, s->d_sendbuf.p, ns);
+    if (ns) {
+        if (with_prev)
+            hipLaunchKernelGGL(sbk::halo_pack_kernel<true>, dim3((ns + 255) / 256), dim3(256), 0, s->stream, s->d_pos.p,
+                               s->d_prev.p, D.send_idx.p, s->d_sendbuf.p, ns);
+        else
+            hipLaunchKernelGGL(sbk::halo_pack_kernel<false>, dim3((ns + 255) / 256), dim3(256), 0, s->stream, s->d_pos.p,
+                               s->d_prev.p, D.send_idx.p, s->d_sendbuf.p, ns);
+    }
     NCCL_CHECK(ncclGroupStart());
     for (size_t k = 0; k < D.peers.size(); ++k) {
-        int cs = D.send_off[k + 1] - D.send_off[k], cr = D.recv_off[k + 1] - D.recv_off[k];
-        if (cs) NCCL_CHECK(ncclSend(s->d_sendbuf.p + D.send_off[k], (size_t)cs * 4, ncclFloat, D.peers[k], s->comm, s->stream));
-        if (cr) NCCL_CHECK(ncclRecv(s->d_recvbuf.p + D.recv_off[k], (size_t)cr * 4, ncclFloat, D.peers[k], s->comm, s->stream));
+        const int cs = D.send_off[k + 1] - D.send_off[k], cr = D.recv_off[k + 1] - D.recv_off[k];
+        for (int blk = 0; blk < (with_prev ? 2 : 1); ++blk) {
+            if (cs) NCCL_CHECK(ncclSend(s->d_sendbuf.p + (size_t)blk * ns + D.send_off[k], (size_t)cs * 4, ncclFloat, D.peers[k], s->comm, s->stream));
+            if (cr) NCCL_CHECK(ncclRecv(s->d_recvbuf.p + (size_t)blk * nr + D.recv_off[k], (size_t)cr * 4, ncclFloat, D.peers[k], s->comm, s->stream));
+        }
     }
     NCCL_CHECK(ncclGroupEnd());
-    if (nr) hipLaunchKernelGGL(sbk::halo_unpack_kernel, dim3((nr + 255) / 256), dim3(256), 0, s->stream, s->d_pos.p,
-                               D.recv_idx.p, s->d_recvbuf.p, nr);
+    if (nr) {
+        if (with_prev)
+            hipLaunchKernelGGL(sbk::halo_unpack_kernel<true>, dim3((nr + 255) / 256), dim3(256), 0, s->stream, s->d_pos.p,
+                               s->d_prev.p, D.recv_idx.p, s->d_recvbuf.p, nr);
+        else
+            hipLaunchKernelGGL(sbk::halo_unpack_kernel<false>, dim3((nr + 255) / 256), dim3(256), 0, s->stream, s->d_pos.p,
+                               s->d_prev.p, D.recv_idx.p, s->d_recvbuf.p, nr);
+    }
 }
 
-template <int MODE>
-void launch_tile(sb_solver *s, DevPhase &D) {
-    if (D.n_clusters == 0) return;
+template <int KIND>
+void launch_tile(sb_solver *s, DevTiling &D) {
+    if (D.n_tiles == 0) return;
     sbk::TileArgs A{};
     A.pos = s->d_pos.p; A.prev = s->d_prev.p; A.vel = s->d_vel.p;
-    A.cl = D.cl.p; A.runs = D.runs.p; A.cols = D.cols.p;
+    A.tiles = D.tiles.p; A.runs_overflow = D.runs_overflow.p; A.rounds = D.rounds.p;
     A.d_idx = D.d_idx.p; A.d_rest = D.d_rest.p; A.q_idx = D.q_idx.p; A.q_rest = D.q_rest.p;
     A.tp = s->d_tp.p;
-    hipLaunchKernelGGL(sbk::tile_kernel<MODE>, dim3(D.n_clusters), dim3(sbk::kTileThreads), D.lds_bytes, s->stream, A);
+    if (D.q_idx.count)
+        hipLaunchKernelGGL((sbk::tile_kernel<KIND, true>), dim3(D.n_tiles), dim3(sbk::kTileThreads), D.lds_bytes, s->stream, A);
+    else
+        hipLaunchKernelGGL((sbk::tile_kernel<KIND, false>), dim3(D.n_tiles), dim3(sbk::kTileThreads), D.lds_bytes, s->stream, A);
 }
 
 struct LaunchTimer {            // optional HIP-event pair around every launch of one tick (sb_step_profiled)
     std::vector<hipEvent_t> ev;
-    std::vector<int> slot;      // phase index per pair; n_phases = velocity kernel
+    std::vector<int> slot;      // see sb_step_profiled in softbody.h
     hipStream_t stream;
-    void begin(int phase_slot) {
+    void begin(int which) {
         hipEvent_t a, b;
         HIP_CHECK(hipEventCreate(&a)); HIP_CHECK(hipEventCreate(&b));
-        ev.push_back(a); ev.push_back(b); slot.push_back(phase_slot);
+        ev.push_back(a); ev.push_back(b); slot.push_back(which);
         HIP_CHECK(hipEventRecord(a, stream));
     }
     void end() { HIP_CHECK(hipEventRecord(ev.back(), stream)); }
     ~LaunchTimer() { for (auto e : ev) (void)hipEventDestroy(e); }
 };
 
+// One tick (SPEC.md §2/§3): kernel K_s runs on the tiles of tiling T_(s&1) and fuses
+// cross(T) of substep s-1, the velocity update + integrate, and full(T) of substep s.
 void enqueue_substeps(sb_solver *s, int substeps, LaunchTimer *lt = nullptr) {
-    for (int it = 0; it < substeps; ++it) {
-        int pi = -1;
-        for (auto &Dp : s->phases) {
-            DevPhase &D = *Dp;
-            ++pi;
-            halo_exchange(s, D);
-            const bool has_work = D.kind == 1 ? D.n_clusters > 0 : D.g_count > 0;
-            if (lt && has_work) lt->begin(pi);
-            if (D.kind == 1) {
-                if (D.fused_integrate) { if (it == 0) launch_tile<0>(s, D); else launch_tile<1>(s, D); }
-                else launch_tile<2>(s, D);
-            } else if (D.g_count > 0) {
-                dim3 grid((D.g_count + 255) / 256);
-                if (D.type == 0)
-                    hipLaunchKernelGGL(sbk::global_distance_kernel, grid, dim3(256), 0, s->stream, s->d_pos.p, D.g_ij.p,
-                                       D.g_rest.p, D.g_count, s->d_tp.p);
-                else
-                    hipLaunchKernelGGL(sbk::global_quad_kernel, grid, dim3(256), 0, s->stream, s->d_pos.p, D.g_quad.p,
-                                       D.g_rest2.p, D.g_count, D.type, s->d_tp.p);
-            }
-            if (lt && has_work) lt->end();
+    const bool two = s->plan->plan.tiling;
+    for (int it = 0; it <= substeps; ++it) {
+        const int tl = two ? (it & 1) : 0;
+        DevTiling &D = s->tiling[tl];
+        if (tl == 1) halo_exchange(s, 1);
+        if (lt && D.n_tiles) lt->begin(it == 0 ? 2 + (int)s->gcolours.size() : (it == substeps ? 3 + (int)s->gcolours.size() : tl));
+        if (it == 0) launch_tile<0>(s, D);
+        else if (it < substeps) launch_tile<1>(s, D);
+        else launch_tile<2>(s, D);
+        if (lt && D.n_tiles) lt->end();
+        if (it == substeps) break;
+        for (size_t gc = 0; gc < s->gcolours.size(); ++gc) {
+            DevGColour &G = *s->gcolours[gc];
+            halo_exchange(s, 2 + (int)gc);
+            if (G.count == 0) continue;
+            if (lt) lt->begin(2 + (int)gc);
+            dim3 grid((G.count + 255) / 256);
+            if (G.type == 0)
+                hipLaunchKernelGGL(sbk::global_distance_kernel, grid, dim3(256), 0, s->stream, s->d_pos.p, G.ij.p, G.rest.p,
+                                   G.count, s->d_tp.p);
+            else
+                hipLaunchKernelGGL(sbk::global_quad_kernel, grid, dim3(256), 0, s->stream, s->d_pos.p, G.quad.p, G.rest2.p,
+                                   G.count, G.type, s->d_tp.p);
+            if (lt) lt->end();
         }
-    }
-    if (s->n_owned) {
-        if (lt) lt->begin((int)s->phases.size());
-        hipLaunchKernelGGL(sbk::velocity_kernel, dim3((unsigned)((s->n_owned + 255) / 256)), dim3(256), 0, s->stream,
-                           s->d_pos.p, s->d_prev.p, s->d_vel.p, (int)s->n_owned, s->d_tp.p);
-        if (lt) lt->end();
     }
     HIP_CHECK(hipGetLastError());
 }
@@ -537,12 +552,7 @@ int sb_finalize(sb_solver *s) {
         build_device(s);
         // opt in to the LDS size the largest tile needs
         size_t max_lds = 0;
-        for (auto &D : s->phases) if (D->kind == 1) max_lds = std::max(max_lds, D->lds_bytes);
-        if (max_lds > 48 * 1024) {
-            HIP_CHECK(hipFuncSetAttribute((const void *)sbk::tile_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));
-            HIP_CHECK(hipFuncSetAttribute((const void *)sbk::tile_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));
-            HIP_CHECK(hipFuncSetAttribute((const void *)sbk::tile_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)max_lds));
-        }
+        for (int tl = 0; tl < 2; ++tl) max_lds = std::max(max_lds, s->tiling[tl].lds_bytes);
         HIP_CHECK(hipDeviceSynchronize());
         // authoring copies are no longer needed (keep rest values out of memory for 50M-constraint meshes)
         std::vector<float>().swap(s->pos); std::vector<float>().swap(s->vel); std::vector<float>().swap(s->rest);
@@ -589,7 +599,7 @@ int sb_step_profiled(sb_solver *s, float dt, int32_t substeps, float *slot_ms, i
     if (!s || !slot_ms || !slot_launches) return fail(SB_ERR_INVALID_ARG, "sb_step_profiled: null argument");
     if (!s->finalized) return fail(SB_ERR_STATE, "sb_step_profiled before sb_finalize");
     if (!(dt > 0.0f) || substeps <= 0) return fail(SB_ERR_INVALID_ARG, "sb_step_profiled: dt and substeps must be positive");
-    if (n_slots != (int32_t)s->phases.size() + 1) return fail(SB_ERR_INVALID_ARG, "sb_step_profiled: n_slots must be n_phases + 1");
+    if (n_slots != (int32_t)s->gcolours.size() + 4) return fail(SB_ERR_INVALID_ARG, "sb_step_profiled: n_slots must be 4 + n_global_colours");
     return guarded([&]() -> int {
         int rc = set_device(s); if (rc) return rc;
         upload_tick_params(s, dt, substeps);
@@ -700,20 +710,19 @@ int sb_get_stats(sb_solver *s, sb_stats *out) {
     if (!s->finalized) return fail(SB_ERR_STATE, "sb_get_stats before sb_finalize");
     std::memset(out, 0, sizeof(*out));
     const sbp::Plan &P = s->plan->plan;
+    const sbp::LocalPlan &L = s->plan->local;
     out->n_particles_owned = s->n_owned;
     out->n_particles_local = s->n_local;
-    for (auto &D : s->phases) {
-        if (D->kind == 1) out->n_clusters += D->n_clusters;
-    }
-    const sbp::LocalPlan &L = s->plan->local;
-    for (size_t k = 0; k < L.order_mask.size(); ++k) if (L.order_mask[k]) ++out->n_constraints_local[P.order_type[k]];
-    out->n_phases = (int32_t)P.phases.size();
-    out->n_tile_phases = P.n_tile_phases;
-    out->n_global_colours = P.n_global_colours;
+    for (size_t k = 0; k < L.order_mask[0].size(); ++k) if (L.order_mask[0][k]) ++out->n_constraints_local[P.order_type[0][k]];
+    out->n_tilings = P.tiling ? 2 : 1;
+    out->n_global_colours = (int32_t)P.gcolours.size();
+    for (int tl = 0; tl < 2; ++tl) { out->n_tiles[tl] = s->tiling[tl].n_tiles; out->tile_constraints[tl] = s->tiling[tl].n_slots; }
     out->constraints_in_tiles = P.cons_in_tiles;
     out->constraints_in_global = P.cons_in_global;
-    out->kernel_launches_per_substep = s->launches_per_substep;
-    out->halo_bytes_per_substep = s->halo_bytes_per_substep;
+    for (size_t slot = 0; slot < s->halos.size(); ++slot) {
+        const int64_t cnt = s->halos[slot]->send_off.back();
+        if (slot == 1) out->halo_particles_t1 = cnt; else out->halo_particles_global += cnt;
+    }
     out->device_bytes = s->dev_bytes;
     return SB_OK;
 }
@@ -750,35 +759,48 @@ int sb_get_plan(sb_solver *s, const sb_plan **out) {
     *out = s->plan.get();
     return SB_OK;
 }
-int64_t sb_plan_order_count(const sb_plan *p) { return p ? (int64_t)p->plan.order_id.size() : -1; }
-int sb_plan_get_order(const sb_plan *p, uint8_t *type_out, int32_t *id_out) {
-    if (!p || !type_out || !id_out) return fail(SB_ERR_INVALID_ARG, "sb_plan_get_order: null");
-    std::memcpy(type_out, p->plan.order_type.data(), p->plan.order_type.size());
-    std::memcpy(id_out, p->plan.order_id.data(), p->plan.order_id.size() * sizeof(int32_t));
+#define PARITY_OK(fn) if (!p || parity < 0 || parity > 1) return fail(SB_ERR_INVALID_ARG, fn ": null plan or parity not 0/1")
+int64_t sb_plan_order_count(const sb_plan *p) { return p ? (int64_t)p->plan.order_id[0].size() : -1; }
+int sb_plan_get_order(const sb_plan *p, int32_t parity, uint8_t *type_out, int32_t *id_out) {
+    PARITY_OK("sb_plan_get_order");
+    if (!type_out || !id_out) return fail(SB_ERR_INVALID_ARG, "sb_plan_get_order: null");
+    std::memcpy(type_out, p->plan.order_type[parity].data(), p->plan.order_type[parity].size());
+    std::memcpy(id_out, p->plan.order_id[parity].data(), p->plan.order_id[parity].size() * sizeof(int32_t));
     return SB_OK;
 }
-int32_t sb_plan_phase_count(const sb_plan *p) { return p ? (int32_t)p->plan.phases.size() : -1; }
-int sb_plan_get_phases(const sb_plan *p, sb_phase_info *out) {
-    if (!p || !out) return fail(SB_ERR_INVALID_ARG, "sb_plan_get_phases: null");
-    for (size_t k = 0; k < p->plan.phases.size(); ++k) {
-        const sbp::Phase &F = p->plan.phases[k];
-        out[k].kind = F.kind; out[k].type = F.type;
+int32_t sb_plan_phase_count(const sb_plan *p, int32_t parity) {
+    if (!p || parity < 0 || parity > 1) return -1;
+    return (int32_t)p->plan.phases[parity].size();
+}
+int sb_plan_get_phases(const sb_plan *p, int32_t parity, sb_phase_info *out) {
+    PARITY_OK("sb_plan_get_phases");
+    if (!out) return fail(SB_ERR_INVALID_ARG, "sb_plan_get_phases: null");
+    for (size_t k = 0; k < p->plan.phases[parity].size(); ++k) {
+        const sbp::Phase &F = p->plan.phases[parity][k];
+        out[k].kind = F.kind; out[k].type = F.type; out[k].tiling = F.tiling; out[k].halo_slot = F.halo_slot;
         out[k].order_begin = F.order_begin; out[k].order_end = F.order_end;
         out[k].task_begin = F.task_begin; out[k].task_end = F.task_end;
-        out[k].needs_halo = F.needs_halo ? 1 : 0;
     }
     return SB_OK;
 }
-int64_t sb_plan_task_count(const sb_plan *p) { return p ? (int64_t)p->plan.task_off.size() - 1 : -1; }
-int sb_plan_get_tasks(const sb_plan *p, int64_t *out) {
-    if (!p || !out) return fail(SB_ERR_INVALID_ARG, "sb_plan_get_tasks: null");
-    std::memcpy(out, p->plan.task_off.data(), p->plan.task_off.size() * sizeof(int64_t));
+int64_t sb_plan_task_count(const sb_plan *p, int32_t parity) {
+    if (!p || parity < 0 || parity > 1) return -1;
+    return (int64_t)p->plan.task_off[parity].size() - 1;
+}
+int sb_plan_get_tasks(const sb_plan *p, int32_t parity, int64_t *out) {
+    PARITY_OK("sb_plan_get_tasks");
+    if (!out) return fail(SB_ERR_INVALID_ARG, "sb_plan_get_tasks: null");
+    std::memcpy(out, p->plan.task_off[parity].data(), p->plan.task_off[parity].size() * sizeof(int64_t));
     return SB_OK;
 }
-int64_t sb_plan_group_count(const sb_plan *p) { return p ? (int64_t)p->plan.group_off.size() - 1 : -1; }
-int sb_plan_get_groups(const sb_plan *p, int64_t *out) {
-    if (!p || !out) return fail(SB_ERR_INVALID_ARG, "sb_plan_get_groups: null");
-    std::memcpy(out, p->plan.group_off.data(), p->plan.group_off.size() * sizeof(int64_t));
+int64_t sb_plan_group_count(const sb_plan *p, int32_t parity) {
+    if (!p || parity < 0 || parity > 1) return -1;
+    return (int64_t)p->plan.group_off[parity].size() - 1;
+}
+int sb_plan_get_groups(const sb_plan *p, int32_t parity, int64_t *out) {
+    PARITY_OK("sb_plan_get_groups");
+    if (!out) return fail(SB_ERR_INVALID_ARG, "sb_plan_get_groups: null");
+    std::memcpy(out, p->plan.group_off[parity].data(), p->plan.group_off[parity].size() * sizeof(int64_t));
     return SB_OK;
 }
 int sb_plan_get_owner(const sb_plan *p, int32_t *out) {
@@ -796,29 +818,31 @@ int sb_plan_get_local_particles(const sb_plan *p, int32_t *out) {
     std::memcpy(out, p->local.local_to_old.data(), p->local.local_to_old.size() * sizeof(int32_t));
     return SB_OK;
 }
-int sb_plan_halo_counts(const sb_plan *p, int32_t phase, int32_t *send_cnt, int32_t *recv_cnt) {
+int32_t sb_plan_halo_slot_count(const sb_plan *p) { return p ? (int32_t)p->local.halo.size() : -1; }
+int sb_plan_halo_counts(const sb_plan *p, int32_t slot, int32_t *send_cnt, int32_t *recv_cnt) {
     if (!p || !send_cnt || !recv_cnt) return fail(SB_ERR_INVALID_ARG, "sb_plan_halo_counts: null");
-    if (phase < 0 || phase >= (int32_t)p->local.phases.size()) return fail(SB_ERR_INVALID_ARG, "sb_plan_halo_counts: bad phase");
-    const sbp::LocalPhase &LP = p->local.phases[phase];
+    if (slot < 0 || slot >= (int32_t)p->local.halo.size()) return fail(SB_ERR_INVALID_ARG, "sb_plan_halo_counts: bad slot");
+    const sbp::HaloSlot &H = p->local.halo[slot];
     for (int r = 0; r < p->local.world; ++r) {
-        send_cnt[r] = (int32_t)LP.send_idx[r].size();
-        recv_cnt[r] = (int32_t)LP.recv_idx[r].size();
+        send_cnt[r] = (int32_t)H.send_idx[r].size();
+        recv_cnt[r] = (int32_t)H.recv_idx[r].size();
     }
     return SB_OK;
 }
-int sb_plan_get_halo(const sb_plan *p, int32_t phase, int32_t peer, int32_t *send_ids, int32_t *recv_ids) {
+int sb_plan_get_halo(const sb_plan *p, int32_t slot, int32_t peer, int32_t *send_ids, int32_t *recv_ids) {
     if (!p) return fail(SB_ERR_INVALID_ARG, "sb_plan_get_halo: null");
-    if (phase < 0 || phase >= (int32_t)p->local.phases.size() || peer < 0 || peer >= p->local.world)
-        return fail(SB_ERR_INVALID_ARG, "sb_plan_get_halo: bad phase/peer");
-    const sbp::LocalPhase &LP = p->local.phases[phase];
+    if (slot < 0 || slot >= (int32_t)p->local.halo.size() || peer < 0 || peer >= p->local.world)
+        return fail(SB_ERR_INVALID_ARG, "sb_plan_get_halo: bad slot/peer");
+    const sbp::HaloSlot &H = p->local.halo[slot];
     // published as caller-numbering (global) particle ids
-    if (send_ids) for (size_t k = 0; k < LP.send_idx[peer].size(); ++k) send_ids[k] = p->local.local_to_old[LP.send_idx[peer][k]];
-    if (recv_ids) for (size_t k = 0; k < LP.recv_idx[peer].size(); ++k) recv_ids[k] = p->local.local_to_old[LP.recv_idx[peer][k]];
+    if (send_ids) for (size_t k = 0; k < H.send_idx[peer].size(); ++k) send_ids[k] = p->local.local_to_old[H.send_idx[peer][k]];
+    if (recv_ids) for (size_t k = 0; k < H.recv_idx[peer].size(); ++k) recv_ids[k] = p->local.local_to_old[H.recv_idx[peer][k]];
     return SB_OK;
 }
-int sb_plan_get_local_order_mask(const sb_plan *p, uint8_t *out) {
-    if (!p || !out) return fail(SB_ERR_INVALID_ARG, "sb_plan_get_local_order_mask: null");
-    std::memcpy(out, p->local.order_mask.data(), p->local.order_mask.size());
+int sb_plan_get_local_order_mask(const sb_plan *p, int32_t parity, uint8_t *out) {
+    PARITY_OK("sb_plan_get_local_order_mask");
+    if (!out) return fail(SB_ERR_INVALID_ARG, "sb_plan_get_local_order_mask: null");
+    std::memcpy(out, p->local.order_mask[parity].data(), p->local.order_mask[parity].size());
     return SB_OK;
 }
 

@@ -27,10 +27,10 @@ class SbDesc(C.Structure):
 
 class SbStats(C.Structure):
     _fields_ = [("n_particles_owned", C.c_int64), ("n_particles_local", C.c_int64),
-                ("n_constraints_local", C.c_int64 * 3), ("n_phases", C.c_int32), ("n_tile_phases", C.c_int32),
-                ("n_global_colours", C.c_int32), ("n_clusters", C.c_int64), ("constraints_in_tiles", C.c_int64),
-                ("constraints_in_global", C.c_int64), ("kernel_launches_per_substep", C.c_int64),
-                ("halo_bytes_per_substep", C.c_int64), ("device_bytes", C.c_int64)]
+                ("n_constraints_local", C.c_int64 * 3), ("n_tilings", C.c_int32), ("n_global_colours", C.c_int32),
+                ("n_tiles", C.c_int64 * 2), ("tile_constraints", C.c_int64 * 2), ("constraints_in_tiles", C.c_int64),
+                ("constraints_in_global", C.c_int64), ("halo_particles_t1", C.c_int64),
+                ("halo_particles_global", C.c_int64), ("device_bytes", C.c_int64)]
 
     def as_dict(self):
         out = {}
@@ -45,8 +45,8 @@ class SbPlanOpts(C.Structure):
 
 
 class SbPhaseInfo(C.Structure):
-    _fields_ = [("kind", C.c_int32), ("type", C.c_int32), ("order_begin", C.c_int64), ("order_end", C.c_int64),
-                ("task_begin", C.c_int64), ("task_end", C.c_int64), ("needs_halo", C.c_int32)]
+    _fields_ = [("kind", C.c_int32), ("type", C.c_int32), ("tiling", C.c_int32), ("halo_slot", C.c_int32),
+                ("order_begin", C.c_int64), ("order_end", C.c_int64), ("task_begin", C.c_int64), ("task_end", C.c_int64)]
 
 
 # name -> (restype, argtypes); this table is what tests/test_abi.py checks against include/softbody.h
@@ -78,19 +78,20 @@ SIGNATURES = {
     "sb_plan_destroy": (C.c_int, [_P]),
     "sb_get_plan": (C.c_int, [_P, C.POINTER(_P)]),
     "sb_plan_order_count": (C.c_int64, [_P]),
-    "sb_plan_get_order": (C.c_int, [_P, _P, _P]),
-    "sb_plan_phase_count": (C.c_int32, [_P]),
-    "sb_plan_get_phases": (C.c_int, [_P, C.POINTER(SbPhaseInfo)]),
-    "sb_plan_task_count": (C.c_int64, [_P]),
-    "sb_plan_get_tasks": (C.c_int, [_P, _P]),
-    "sb_plan_group_count": (C.c_int64, [_P]),
-    "sb_plan_get_groups": (C.c_int, [_P, _P]),
+    "sb_plan_get_order": (C.c_int, [_P, C.c_int32, _P, _P]),
+    "sb_plan_phase_count": (C.c_int32, [_P, C.c_int32]),
+    "sb_plan_get_phases": (C.c_int, [_P, C.c_int32, C.POINTER(SbPhaseInfo)]),
+    "sb_plan_task_count": (C.c_int64, [_P, C.c_int32]),
+    "sb_plan_get_tasks": (C.c_int, [_P, C.c_int32, _P]),
+    "sb_plan_group_count": (C.c_int64, [_P, C.c_int32]),
+    "sb_plan_get_groups": (C.c_int, [_P, C.c_int32, _P]),
     "sb_plan_get_owner": (C.c_int, [_P, _P]),
     "sb_plan_local_count": (C.c_int64, [_P, C.POINTER(C.c_int64)]),
     "sb_plan_get_local_particles": (C.c_int, [_P, _P]),
+    "sb_plan_halo_slot_count": (C.c_int32, [_P]),
     "sb_plan_halo_counts": (C.c_int, [_P, C.c_int32, _P, _P]),
     "sb_plan_get_halo": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
-    "sb_plan_get_local_order_mask": (C.c_int, [_P, _P]),
+    "sb_plan_get_local_order_mask": (C.c_int, [_P, C.c_int32, _P]),
     "sb_last_error": (C.c_char_p, []),
     "sb_abi_version": (C.c_int, []),
 }
@@ -175,37 +176,39 @@ class Plan:
         except Exception:
             pass
 
-    def order(self):
+    def order(self, parity=0):
         L = lib()
         m = L.sb_plan_order_count(self._h)
         t = np.zeros(m, np.uint8); ids = np.zeros(m, np.int32)
-        check(L.sb_plan_get_order(self._h, ptr(t), ptr(ids)))
+        check(L.sb_plan_get_order(self._h, parity, ptr(t), ptr(ids)))
         return t, ids
 
-    def phases(self):
+    def phases(self, parity=0):
         L = lib()
-        k = L.sb_plan_phase_count(self._h)
+        k = L.sb_plan_phase_count(self._h, parity)
         arr = (SbPhaseInfo * k)()
-        check(L.sb_plan_get_phases(self._h, arr))
-        return [dict(kind=a.kind, type=a.type, order_begin=a.order_begin, order_end=a.order_end,
-                     task_begin=a.task_begin, task_end=a.task_end, needs_halo=a.needs_halo) for a in arr]
+        check(L.sb_plan_get_phases(self._h, parity, arr))
+        return [dict(kind=a.kind, type=a.type, tiling=a.tiling, halo_slot=a.halo_slot, order_begin=a.order_begin,
+                     order_end=a.order_end, task_begin=a.task_begin, task_end=a.task_end) for a in arr]
 
-    def tasks(self):
+    def tasks(self, parity=0):
         L = lib()
-        k = L.sb_plan_task_count(self._h)
+        k = L.sb_plan_task_count(self._h, parity)
         out = np.zeros(k + 1, np.int64)
-        check(L.sb_plan_get_tasks(self._h, ptr(out)))
+        check(L.sb_plan_get_tasks(self._h, parity, ptr(out)))
         return out
 
-    def groups(self):
+    def groups(self, parity=0):
         L = lib()
-        k = L.sb_plan_group_count(self._h)
+        k = L.sb_plan_group_count(self._h, parity)
         out = np.zeros(k + 1, np.int64)
-        check(L.sb_plan_get_groups(self._h, ptr(out)))
+        check(L.sb_plan_get_groups(self._h, parity, ptr(out)))
         return out
 
-    def phase_task_offsets(self):
-        ph = self.phases()
+    def phase_task_offsets(self, parity=0):
+        ph = self.phases(parity)
+        if not ph:
+            return np.zeros(1, np.int64)
         return np.array([p["task_begin"] for p in ph] + [ph[-1]["task_end"]], np.int64)
 
     def owner(self, n):
@@ -221,23 +224,26 @@ class Plan:
         check(L.sb_plan_get_local_particles(self._h, ptr(out)))
         return out, owned.value
 
-    def halo(self, phase, world):
+    def halo_slot_count(self):
+        return lib().sb_plan_halo_slot_count(self._h)
+
+    def halo(self, slot, world):
         """-> {peer: (send_ids, recv_ids)} in caller particle numbering."""
         L = lib()
         sc = np.zeros(world, np.int32); rc = np.zeros(world, np.int32)
-        check(L.sb_plan_halo_counts(self._h, phase, ptr(sc), ptr(rc)))
+        check(L.sb_plan_halo_counts(self._h, slot, ptr(sc), ptr(rc)))
         out = {}
         for peer in range(world):
             if sc[peer] == 0 and rc[peer] == 0:
                 continue
             s = np.zeros(sc[peer], np.int32); r = np.zeros(rc[peer], np.int32)
-            check(L.sb_plan_get_halo(self._h, phase, peer, ptr(s), ptr(r)))
+            check(L.sb_plan_get_halo(self._h, slot, peer, ptr(s), ptr(r)))
             out[peer] = (s, r)
         return out
 
-    def local_order_mask(self):
+    def local_order_mask(self, parity=0):
         L = lib()
         m = L.sb_plan_order_count(self._h)
         out = np.zeros(m, np.uint8)
-        check(L.sb_plan_get_local_order_mask(self._h, ptr(out)))
+        check(L.sb_plan_get_local_order_mask(self._h, parity, ptr(out)))
         return out

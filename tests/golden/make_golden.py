@@ -24,8 +24,8 @@ def main():
     o = make_oracle(oracle, mesh, plan)
     for _ in range(5):
         o.step(0.02, 10)
-    t, ids = plan.order()
-    np.savez_compressed(os.path.join(HERE, "cube8_s10_t5.npz"), x=o.x, v=o.v, order_type=t, order_id=ids)
+    (t0, i0), (t1, i1) = plan.order(0), plan.order(1)
+    np.savez_compressed(os.path.join(HERE, "cube8_s10_t5.npz"), x=o.x, v=o.v, order_id0=i0, order_id1=i1)
     # natural-order variant (no planner involved): pins the oracle itself
     o = make_oracle(oracle, mesh, None)
     for _ in range(5):

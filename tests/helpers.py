@@ -13,8 +13,9 @@ def make_oracle(oracle_mod, mesh, plan=None, gravity=(0.0, -9.81, 0.0), damping=
     if len(mesh.bend_rest):
         o.set_bending(mesh.bend_ijkl, mesh.bend_rest, compliance[2])
     if plan is not None:
-        t, ids = plan.order()
-        o.set_order(t, ids, plan.phase_task_offsets(), plan.tasks())
+        for parity in (0, 1):
+            t, ids = plan.order(parity)
+            o.set_order(t, ids, plan.phase_task_offsets(parity), plan.tasks(parity), parity=parity)
     return o
 
 
@@ -22,61 +23,98 @@ def build_plan(mesh, **kw):
     return native.Plan.build(mesh.rest_pos, mesh.dist_ij, mesh.vol_ijkl, mesh.bend_ijkl, **kw)
 
 
-def cons_vertices(mesh, t, i):
-    return (mesh.dist_ij[i] if t == 0 else (mesh.vol_ijkl[i] if t == 1 else mesh.bend_ijkl[i]))
-
-
 class RankSim:
-    """One rank of the partitioned oracle: full-size arrays, only local entries meaningful."""
+    """One rank of the partitioned oracle: full-size arrays, only local entries meaningful.
+
+    Mirrors the GPU kernel sequence of one tick: kernel K_s runs on tiling T_(s&1) and does
+    cross(T) of substep s-1, the velocity update + integrate, full(T) of substep s; the global colours of
+    substep s follow. Ghosts are refreshed before every T1 kernel (slot 1: x and xprev) and before every
+    cut global colour (slot 2+c: x)."""
 
     def __init__(self, oracle_mod, mesh, rank, world, dims, tile, gravity, damping, compliance):
         self.plan = build_plan(mesh, rank=rank, world=world, part_dims=dims, tile_particles=tile)
         self.rank, self.world = rank, world
         self.o = make_oracle(oracle_mod, mesh, None, gravity, damping, compliance)
-        t, ids = self.plan.order()
-        mask = self.plan.local_order_mask().astype(bool)
-        self.phases = self.plan.phases()
-        # compacted local order + per-phase offsets
-        self.lt, self.lid = t[mask], ids[mask]
-        csum = np.concatenate([[0], np.cumsum(mask)])
-        self.ph_off = [(int(csum[p["order_begin"]]), int(csum[p["order_end"]])) for p in self.phases]
-        self.o.order_type = np.ascontiguousarray(self.lt); self.o.order_id = np.ascontiguousarray(self.lid)
+        self.local = []      # per parity: (type, id) of executed entries + phase offsets into them
+        for parity in (0, 1):
+            t, ids = self.plan.order(parity)
+            mask = self.plan.local_order_mask(parity).astype(bool)
+            csum = np.concatenate([[0], np.cumsum(mask)])
+            phases = self.plan.phases(parity)
+            off = [(int(csum[p["order_begin"]]), int(csum[p["order_end"]])) for p in phases]
+            self.local.append((np.ascontiguousarray(t[mask]), np.ascontiguousarray(ids[mask]), phases, off))
+        self.tiling_on = any(p["kind"] != 0 for par in (0, 1) for p in self.local[par][2]) and tile > 0
         self.owner = self.plan.owner(mesh.n)
         self.owned = self.owner == rank
-        self.halos = [self.plan.halo(k, world) for k in range(len(self.phases))]
+        self.halos = [self.plan.halo(k, world) for k in range(self.plan.halo_slot_count())]
         loc, n_owned = self.plan.local_particles()
         self.local_ids, self.n_owned = loc, n_owned
         # poison everything this rank does not hold, so a missing halo entry shows up as NaN
         held = np.zeros(mesh.n, bool); held[loc] = True
         self.o.x[~held] = np.nan
 
+    def project(self, s, parity, kinds, tiling=None):
+        t, ids, phases, off = self.local[parity]
+        self.o.order_type, self.o.order_id = t, ids
+        for ph, (b, e) in zip(phases, off):
+            if ph["kind"] in kinds and (tiling is None or ph["tiling"] == tiling):
+                self.o.project_range(s, b, e)
+
+    def gcolour_phases(self, parity):
+        t, ids, phases, off = self.local[parity]
+        return [(ph, be) for ph, be in zip(phases, off) if ph["kind"] == 0]
+
+
+def _exchange_memcpy(ranks, slot, with_prev):
+    staged = []
+    for R in ranks:
+        if slot >= len(R.halos):
+            continue
+        for peer, (send_ids, recv_ids) in R.halos[slot].items():
+            if len(recv_ids):
+                ps, _ = ranks[peer].halos[slot][R.rank]
+                assert np.array_equal(ps, recv_ids), "send/recv lists of a halo slot differ between the two ranks"
+                staged.append((R, recv_ids, ranks[peer].o.x[recv_ids].copy(),
+                               ranks[peer].o.xprev[recv_ids].copy() if with_prev else None))
+    for R, ids, vals, prev in staged:
+        R.o.x[ids] = vals
+        if prev is not None:
+            R.o.xprev[ids] = prev
+
+
+def run_tick(ranks, s, substeps, tiling_on, exchange):
+    """One tick of the kernel sequence on every rank. exchange(slot, with_prev) refreshes ghosts."""
+    for it in range(substeps + 1):
+        tl = (it & 1) if tiling_on else 0
+        if tl == 1:
+            exchange(1, True)
+        for R in ranks:
+            if it > 0:
+                R.project(s, (it - 1) & 1, kinds=(2,), tiling=tl)   # cross(T_tl) finishes substep it-1
+                R.o.velocity(s)
+            if it < substeps:
+                R.o.integrate(s)
+                R.project(s, it & 1, kinds=(1,), tiling=tl)         # full(T_tl) starts substep it
+        if it == substeps:
+            break
+        n_g = len(ranks[0].gcolour_phases(it & 1))
+        for gi in range(n_g):
+            ph0 = ranks[0].gcolour_phases(it & 1)[gi][0]
+            if ph0["halo_slot"] >= 0:
+                exchange(ph0["halo_slot"], False)
+            for R in ranks:
+                ph, (b, e) = R.gcolour_phases(it & 1)[gi]
+                R.o.order_type, R.o.order_id = R.local[it & 1][0], R.local[it & 1][1]
+                R.o.project_range(s, b, e)
+
 
 def run_partitioned(oracle_mod, mesh, world, dims=(0, 0, 0), ticks=1, substeps=10, dt=0.02, tile=512,
-                    gravity=(0.0, -9.81, 0.0), damping=0.0, compliance=(0.0, 0.0, 0.0), exchange=None):
+                    gravity=(0.0, -9.81, 0.0), damping=0.0, compliance=(0.0, 0.0, 0.0)):
     """Partitioned oracle with memcpy halo. Returns merged positions/velocities."""
     ranks = [RankSim(oracle_mod, mesh, r, world, dims, tile, gravity, damping, compliance) for r in range(world)]
     for _ in range(ticks):
         s = ranks[0].o.scalars(dt, substeps)
-        for _ in range(substeps):
-            for R in ranks:
-                R.o.integrate(s)
-            for k in range(len(ranks[0].phases)):
-                # halo before phase k: every rank receives from the owner's current values
-                staged = []
-                for R in ranks:
-                    for peer, (send_ids, recv_ids) in R.halos[k].items():
-                        if len(recv_ids):
-                            # the peer's send list for me must be the same ids in the same order
-                            ps, _ = ranks[peer].halos[k][R.rank]
-                            assert np.array_equal(ps, recv_ids)
-                            staged.append((R, recv_ids, ranks[peer].o.x[recv_ids].copy()))
-                for R, ids, vals in staged:
-                    R.o.x[ids] = vals
-                for R in ranks:
-                    b, e = R.ph_off[k]
-                    R.o.project_range(s, b, e)
-            for R in ranks:
-                R.o.velocity(s)
+        run_tick(ranks, s, substeps, tile > 0, lambda slot, wp: _exchange_memcpy(ranks, slot, wp))
     x = np.zeros_like(ranks[0].o.x); v = np.zeros_like(x)
     for R in ranks:
         x[R.owned] = R.o.x[R.owned]; v[R.owned] = R.o.v[R.owned]

@@ -3,32 +3,38 @@ import numpy as np
 import pytest
 
 from softbodyunity_amd.mesh import bunny_surrogate, jelly_cube
-from helpers import build_plan, cons_vertices, make_oracle, run_partitioned
+from helpers import build_plan, make_oracle, run_partitioned
 
 
 def _check_plan(mesh, plan):
-    t, ids = plan.order()
     m = [len(mesh.dist_rest), len(mesh.vol_rest), len(mesh.bend_rest)]
-    assert len(ids) == sum(m)
-    for ty in range(3):   # a permutation of every type's constraints
-        assert np.array_equal(np.sort(ids[t == ty]), np.arange(m[ty]))
     arr = [mesh.dist_ij, mesh.vol_ijkl, mesh.bend_ijkl]
-    # groups are vertex-disjoint (the GPU runs a group's constraints concurrently)
-    g = plan.groups()
-    assert g[0] == 0 and g[-1] == len(ids) and np.all(np.diff(g) > 0)
-    for a, b in zip(g[:-1], g[1:]):
-        assert len(set(t[a:b])) == 1
-        vs = arr[t[a]][ids[a:b]].ravel()
-        assert len(np.unique(vs)) == len(vs), "colour class is not a matching"
-    # tasks of one phase touch disjoint particles (the GPU runs tiles of a phase concurrently)
-    tasks = plan.tasks()
-    for ph in plan.phases():
-        seen = np.zeros(mesh.n, np.int64) - 1
-        for tk in range(ph["task_begin"], ph["task_end"]):
-            a, b = tasks[tk], tasks[tk + 1]
-            vs = np.unique(np.concatenate([arr[ty][ids[a:b][t[a:b] == ty]].ravel() for ty in range(3)]))
-            assert np.all((seen[vs] == -1)), "two tasks of one phase share a particle"
-            seen[vs] = tk
+    for parity in (0, 1):
+        t, ids = plan.order(parity)
+        assert len(ids) == sum(m)
+        for ty in range(3):   # every parity's order is a permutation of every type's constraints
+            assert np.array_equal(np.sort(ids[t == ty]), np.arange(m[ty]))
+        # groups are vertex-disjoint (the GPU runs a group's constraints concurrently)
+        g = plan.groups(parity)
+        assert g[0] == 0 and g[-1] == len(ids) and np.all(np.diff(g) > 0) and np.all(np.diff(g) <= 256)
+        for a, b in zip(g[:-1], g[1:]):
+            assert len(set(t[a:b])) == 1
+            vs = arr[t[a]][ids[a:b]].ravel()
+            assert len(np.unique(vs)) == len(vs), "a round is not a matching"
+        # tasks of one phase touch disjoint particles (the GPU runs tiles of a phase concurrently)
+        tasks = plan.tasks(parity)
+        phases = plan.phases(parity)
+        assert phases[0]["order_begin"] == 0 and phases[-1]["order_end"] == len(ids)
+        for pa, pb in zip(phases[:-1], phases[1:]):
+            assert pa["order_end"] == pb["order_begin"] and pa["task_end"] == pb["task_begin"]
+        for ph in phases:
+            seen = np.zeros(mesh.n, np.int64) - 1
+            assert tasks[ph["task_begin"]] == ph["order_begin"] and tasks[ph["task_end"]] == ph["order_end"]
+            for tk in range(ph["task_begin"], ph["task_end"]):
+                a, b = tasks[tk], tasks[tk + 1]
+                vs = np.unique(np.concatenate([arr[ty][ids[a:b][t[a:b] == ty]].ravel() for ty in range(3)]))
+                assert np.all((seen[vs] == -1)), "two tasks of one phase share a particle"
+                seen[vs] = tk
 
 
 @pytest.mark.parametrize("n,tile", [(8, 512), (12, 64), (17, 512), (20, -1)])
@@ -40,18 +46,24 @@ def test_cube_plan_invariants(n, tile):
 def test_cube_64_structure():
     mesh = jelly_cube(64)
     plan = build_plan(mesh)
-    ph = plan.phases()
-    assert [p["kind"] for p in ph] == [1, 1]                     # two tile phases, nothing left for global colours
-    assert ph[0]["task_end"] - ph[0]["task_begin"] == 512        # 8^3 cells of 8^3 particles
-    assert ph[0]["order_end"] == 512 * 1344                      # all in-cell springs
-    assert ph[1]["order_end"] == 3 * 64 * 64 * 63
+    p0, p1 = plan.phases(0), plan.phases(1)
+    # parity 0: full(T0) then cross(T1); parity 1: full(T1) then cross(T0); nothing left for global colours
+    assert [(p["kind"], p["tiling"]) for p in p0] == [(1, 0), (2, 1)]
+    assert [(p["kind"], p["tiling"]) for p in p1] == [(1, 1), (2, 0)]
+    assert p0[0]["task_end"] - p0[0]["task_begin"] == 512        # 8^3 aligned cells of 8^3 particles
+    assert p0[0]["order_end"] == 512 * 1344                      # all in-cell springs
+    assert p1[0]["task_end"] - p1[0]["task_begin"] == 729        # 9^3 shifted cells
+    assert p1[1]["order_end"] - p1[1]["order_begin"] == 512 * 192  # springs over the mid-planes of aligned cells
+    assert p0[1]["order_end"] == 3 * 64 * 64 * 63 == p1[1]["order_end"]
 
 
 def test_full_stencil_cube_uses_global_colours_and_stays_valid():
     mesh = jelly_cube(10, stencil="full")
     plan = build_plan(mesh, tile_particles=64)
     _check_plan(mesh, plan)
-    assert any(p["kind"] == 0 for p in plan.phases())            # diagonal springs crossing two cut planes
+    assert any(p["kind"] == 0 for p in plan.phases(0))           # diagonal springs inside neither tiling
+    assert [p["order_end"] - p["order_begin"] for p in plan.phases(0) if p["kind"] == 0] == \
+           [p["order_end"] - p["order_begin"] for p in plan.phases(1) if p["kind"] == 0]
 
 
 @pytest.fixture(scope="module")
@@ -69,8 +81,8 @@ def test_parallel_oracle_equals_sequential(oracle_mod, small_bunny):
     for mesh, tile in ((jelly_cube(12), 64), (small_bunny, 128)):
         plan = build_plan(mesh, tile_particles=tile)
         a = make_oracle(oracle_mod, mesh, plan); b = make_oracle(oracle_mod, mesh, plan)
-        for _ in range(2):
-            a.step(0.02, 10); b.step(0.02, 10, parallel=True)
+        for S in (10, 7):
+            a.step(0.02, S); b.step(0.02, S, parallel=True)
         assert np.array_equal(a.x.view(np.uint32), b.x.view(np.uint32))
 
 
@@ -88,10 +100,11 @@ def test_kat9_partition_invariance_cube(oracle_mod, world, dims, tile):
     owned = np.stack([r.owned for r in ranks])
     assert np.all(owned.sum(0) == 1)
     # published order is rank independent
-    t0, i0 = ranks[0].plan.order()
-    for r in ranks[1:]:
-        t1, i1 = r.plan.order()
-        assert np.array_equal(t0, t1) and np.array_equal(i0, i1)
+    for parity in (0, 1):
+        t0, i0 = ranks[0].plan.order(parity)
+        for r in ranks[1:]:
+            t1, i1 = r.plan.order(parity)
+            assert np.array_equal(t0, t1) and np.array_equal(i0, i1)
 
 
 def test_kat9_partition_invariance_irregular(oracle_mod, small_bunny):
