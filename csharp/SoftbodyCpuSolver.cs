@@ -86,8 +86,8 @@ namespace SoftbodyMI355X
             float ws = (float)((float)(wi + wj) + at);
             if (!(L > 0f) || !(ws > 0f)) return;
             float C = (float)(L - L0);
-            float dl = (float)((-C) / ws);
-            float s = (float)(dl / L);
+            float wl = (float)(ws * L);
+            float s = (float)((-C) / wl);
             float si = (float)(wi * s), sj = (float)(wj * s);
             float ax = (float)(si * dx), ay = (float)(si * dy), az = (float)(si * dz);
             float bx = (float)(sj * dx), by = (float)(sj * dy), bz = (float)(sj * dz);

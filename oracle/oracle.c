@@ -79,8 +79,8 @@ void orc_project_distance(float *x, const float *w, int i, int j, float L0, floa
     float ws = (wi + wj) + at;
     if (!(L > 0.0f) || !(ws > 0.0f)) return;
     float C = L - L0;
-    float dl = (-C) / ws;
-    float s = dl / L;
+    float wl = ws * L;
+    float s = (-C) / wl;
     float si = wi * s, sj = wj * s;
     float ax = si * dx, ay = si * dy, az = si * dz;
     float bx = sj * dx, by = sj * dy, bz = sj * dz;

@@ -15,17 +15,24 @@ struct TickParams {           // SPEC.md §2 host-side scalars, uploaded once pe
     float pad[7];
 };
 
-struct TileDesc {             // one LDS tile = one workgroup; 128 B, read with scalar loads
-    int32_t n_local, run_count, round_begin, n_pre;
-    int32_t n_rounds;          // cross rounds, the marker, full rounds
-    uint32_t d_begin, q_begin; // first distance / 4-vertex constraint of the cross part
-    uint32_t d_mid;            // first distance constraint of the full part
-    uint32_t q_mid;
+// One LDS tile = one workgroup. 128 B, read with scalar loads.
+// The tile's constraint stream lives at stream[s_begin ...], 16-byte aligned, in dwords:
+//   [round words, padded to 4] [cross rounds' data] [full rounds' data]
+// round word: bits 0-9 count, bits 10-11 type (0 distance, 1 volume, 2 bending, 3 = velocity/integrate marker);
+// a distance round stores count x {i | j<<16, rest length} (padded to 4 dwords), a 4-vertex round stores
+// count x {i0|i1<<16, i2|i3<<16, rest.x, rest.y}; the marker stores nothing.
+struct TileDesc {
+    int32_t n_local, run_count, n_pre, n_rounds;   // n_rounds = cross rounds + marker + full rounds
+    uint32_t s_begin;          // dword offset of the tile's stream
+    uint32_t s_hdr;            // dwords of round words (padded): cross data starts at s_begin + s_hdr
+    uint32_t s_mid;            // dword offset (from s_begin) of the full part's data
+    uint32_t s_len;            // total dwords (multiple of 4)
     int32_t run_overflow;      // runs beyond kInlineRuns live at runs_overflow[run_overflow ...]
-    int32_t pad0, pad1;
+    int32_t pad0, pad1, pad2;
     int2 runs[10];             // {first particle (device numbering), first tile-local index}
 };
 constexpr int kInlineRuns = 10;
+constexpr int kMaxRoundsLds = 128;   // round words cached in LDS; longer programs read them from memory
 
 struct TileArgs {
     float4 *pos;              // (x,y,z,w) per local particle
@@ -33,17 +40,14 @@ struct TileArgs {
     float *vel;               // packed xyz (read by KIND 0, written by KIND 2)
     const TileDesc *tiles;
     const int2 *runs_overflow;
-    const uint32_t *rounds;   // bits 0-9 count, bits 10-11 type (3 = velocity/integrate marker)
-    const uint32_t *d_idx;    // distance: lo16 = i, hi16 = j (tile-local)
-    const float *d_rest;
-    const uint2 *q_idx;       // 4-vertex: {i0|i1<<16, i2|i3<<16}
-    const float2 *q_rest;     // volume: (6*V0, -), bending: (cos, sin)
+    const uint32_t *stream;
     const TickParams *tp;
+    int32_t max_local;        // LDS carve: [max_local float4][kMaxRoundsLds dwords][win_dwords dwords]
+    int32_t win_dwords;       // constraint window held in LDS (multiple of 4, >= the largest round)
 };
 
 constexpr int kTileThreads = 256;
-constexpr int kPPT = 4;        // particles per lane (tile <= 1024 particles)
-constexpr int kRB = 8;         // rounds of constraint data kept in flight per lane
+constexpr int kMaxPPT = 4;     // particles per lane (tile <= 1024 particles)
 
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 sub3(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
@@ -70,8 +74,8 @@ __device__ __forceinline__ bool project_distance(float4 &a, float4 &b, float L0,
     float ws = (a.w + b.w) + at;
     if (!(L > 0.0f) || !(ws > 0.0f)) return false;
     float C = L - L0;
-    float dl = (-C) / ws;
-    float s = dl / L;
+    float wl = ws * L;
+    float s = (-C) / wl;
     float si = a.w * s, sj = b.w * s;
     float ax = si * dx, ay = si * dy, az = si * dz;
     float bx = sj * dx, by = sj * dy, bz = sj * dz;
@@ -143,25 +147,26 @@ __device__ __forceinline__ bool project_bending(float4 &pa, float4 &pb, float4 &
 //   KIND 1 (every other substep)     : cross rounds (finish substep s-1), MARK: v = (x-xprev)/h, integrate
 //                                      (start substep s), full rounds
 //   KIND 2 (after the last substep)  : cross rounds, MARK: write v, stop
-// Particles are staged in LDS once; each lane keeps ownership of up to kPPT particles for the MARK step.
-// Constraint words of the next kRB rounds are kept in flight in registers (rolling prefetch) so that a
-// tile pays the HBM latency once instead of once per colour.
-// QUADS = the tiling stores 4-vertex (volume/bending) rounds: that variant keeps fewer rounds in flight
-// (the 4-vertex code is large) and loads 4-vertex words without prefetch.
-template <int KIND, bool QUADS>
+// Particles AND the tile's constraint stream are staged in LDS with wide coalesced loads issued together,
+// so a tile pays the HBM latency once; rounds then run LDS-to-LDS with one barrier each. Each lane keeps
+// ownership of up to PPT particles for the MARK step. QUADS = the tiling stores 4-vertex rounds.
+template <int KIND, bool QUADS, int PPT>
 __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileArgs A) {
-    constexpr int RB = QUADS ? 2 : kRB;
-    extern __shared__ float4 lds_pos[];
+    extern __shared__ uint4 lds_raw[];
+    float4 *lds_pos = reinterpret_cast<float4 *>(lds_raw);
+    uint32_t *s_rounds = reinterpret_cast<uint32_t *>(lds_pos + A.max_local);
+    uint32_t *cbuf = s_rounds + kMaxRoundsLds;
     const TileDesc &td = A.tiles[blockIdx.x];
     const int tid = threadIdx.x;
     const int n_local = td.n_local;
     const int run_count = td.run_count;
     const TickParams tp = *A.tp;
+    const uint32_t *tstream = A.stream + td.s_begin;
 
     // ---- particle ownership: lane tid owns tile-local particles tid + 256*m -----------------------
-    int g[kPPT];
+    int g[PPT];
 #pragma unroll
-    for (int m = 0; m < kPPT; ++m) {
+    for (int m = 0; m < PPT; ++m) {
         const int l = tid + m * kTileThreads;
         int gi = -1;
         if (l < n_local) {
@@ -175,104 +180,125 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
         }
         g[m] = gi;
     }
-    float pvx[kPPT], pvy[kPPT], pvz[kPPT];
+    // ---- the stretch of the stream this kernel needs, staged through an LDS window -----------------
+    const int r_begin = KIND == 0 ? td.n_pre : 0;
+    const int r_end = KIND == 2 ? td.n_pre + 1 : td.n_rounds;
+    const uint32_t d_lo = KIND == 0 ? td.s_mid : td.s_hdr;
+    const uint32_t d_hi = KIND == 2 ? td.s_mid : td.s_len;
+    const uint32_t win = (uint32_t)A.win_dwords;
+    uint32_t win_lo = d_lo;
+    auto load_window = [&](uint32_t lo) {
+        const uint32_t n4 = (min(lo + win, d_hi) - lo) >> 2;
+        const uint4 *src = reinterpret_cast<const uint4 *>(tstream + lo);
+        uint4 *dst = reinterpret_cast<uint4 *>(cbuf);
+        for (uint32_t i = tid; i < n4; i += 4 * kTileThreads) {
+            uint4 v0 = src[i], v1, v2, v3;
+            const bool b1 = i + kTileThreads < n4, b2 = i + 2 * kTileThreads < n4, b3 = i + 3 * kTileThreads < n4;
+            if (b1) v1 = src[i + kTileThreads];
+            if (b2) v2 = src[i + 2 * kTileThreads];
+            if (b3) v3 = src[i + 3 * kTileThreads];
+            dst[i] = v0;
+            if (b1) dst[i + kTileThreads] = v1;
+            if (b2) dst[i + 2 * kTileThreads] = v2;
+            if (b3) dst[i + 3 * kTileThreads] = v3;
+        }
+    };
+    // issue everything the tile needs from HBM back to back: positions, previous positions, round words, window
+    float4 X[PPT];
+    float pvx[PPT], pvy[PPT], pvz[PPT];
 #pragma unroll
-    for (int m = 0; m < kPPT; ++m) {
+    for (int m = 0; m < PPT; ++m) {
         pvx[m] = pvy[m] = pvz[m] = 0.0f;
+        X[m] = make_float4(0.f, 0.f, 0.f, 0.f);
         if (g[m] >= 0) {
-            lds_pos[tid + m * kTileThreads] = A.pos[g[m]];
+            X[m] = A.pos[g[m]];
             if (KIND != 0) {
                 pvx[m] = A.prev[3 * (size_t)g[m] + 0]; pvy[m] = A.prev[3 * (size_t)g[m] + 1]; pvz[m] = A.prev[3 * (size_t)g[m] + 2];
             }
         }
     }
-
-    // ---- rolling prefetch of constraint words ------------------------------------------------------
-    const int r_begin = KIND == 0 ? td.n_pre : 0;
-    const int r_end = KIND == 2 ? td.n_pre + 1 : td.n_rounds;
-    const uint32_t *rounds = A.rounds + td.round_begin;
-    uint32_t pf_d = KIND == 0 ? td.d_mid : td.d_begin;     // data offset of the next round to prefetch
-    uint32_t cur_q = KIND == 0 ? td.q_mid : td.q_begin;
-    int pf_r = r_begin;
-    uint32_t s_idx[RB];
-    float s_rest[RB];
-    auto prefetch = [&](int slot) {
-        if (pf_r < r_end) {
-            const uint32_t w = rounds[pf_r];
-            const int cnt = w & 1023u, type = (w >> 10) & 3u;
-            if (type == 0) {
-                if (tid < cnt) { s_idx[slot] = A.d_idx[pf_d + tid]; s_rest[slot] = A.d_rest[pf_d + tid]; }
-                pf_d += cnt;
-            }
-            ++pf_r;
-        }
-    };
+    const bool rounds_in_lds = td.n_rounds <= kMaxRoundsLds;
+    if (rounds_in_lds && tid < td.n_rounds) s_rounds[tid] = tstream[tid];
+    load_window(win_lo);
 #pragma unroll
-    for (int j = 0; j < RB; ++j) prefetch(j);
+    for (int m = 0; m < PPT; ++m)
+        if (g[m] >= 0) lds_pos[tid + m * kTileThreads] = X[m];
     __syncthreads();
 
-    int r = r_begin;
-    while (r < r_end) {
+    uint32_t off = d_lo;    // dword offset (from the tile's stream start) of the current round's data
+#if defined(SB_ABLATE) && SB_ABLATE == 1   // timing experiment only: memory traffic without the rounds
+    for (int r = r_begin; r < r_end; r += 1000) {
+#else
+    for (int r = r_begin; r < r_end; ++r) {
+#endif
+        const uint32_t w = rounds_in_lds ? s_rounds[r] : tstream[r];
+        const int cnt = w & 1023u, type = (w >> 10) & 3u;
+        if (type == 3) {
+            // velocity update of the substep that just finished + integrate of the next one (SPEC.md §2)
 #pragma unroll
-        for (int j = 0; j < RB; ++j) {
-            if (r < r_end) {
-                const uint32_t w = rounds[r];
-                const int cnt = w & 1023u, type = (w >> 10) & 3u;
-                if (type == 0) {
-                    if (tid < cnt) {
-                        const uint32_t pr = s_idx[j];
-                        const int i = pr & 0xffffu, k = pr >> 16;
-                        float4 a = lds_pos[i], b = lds_pos[k];
-                        if (project_distance(a, b, s_rest[j], tp.at_d)) { lds_pos[i] = a; lds_pos[k] = b; }
+            for (int m = 0; m < PPT; ++m)
+                if (g[m] >= 0) {
+                    const int l = tid + m * kTileThreads;
+                    float4 P = lds_pos[l];
+                    float vx, vy, vz;
+                    const size_t o = 3 * (size_t)g[m];
+                    if (KIND == 0) {
+                        vx = A.vel[o + 0]; vy = A.vel[o + 1]; vz = A.vel[o + 2];
+                    } else {
+                        float dx = P.x - pvx[m], dy = P.y - pvy[m], dz = P.z - pvz[m];
+                        float qx = dx * tp.inv_h, qy = dy * tp.inv_h, qz = dz * tp.inv_h;
+                        vx = qx * tp.kd; vy = qy * tp.kd; vz = qz * tp.kd;
                     }
-                } else if (type == 3) {
-                    // velocity update of the substep that just finished + integrate of the next one (SPEC.md §2)
-#pragma unroll
-                    for (int m = 0; m < kPPT; ++m)
-                        if (g[m] >= 0) {
-                            const int l = tid + m * kTileThreads;
-                            float4 P = lds_pos[l];
-                            float vx, vy, vz;
-                            const size_t o = 3 * (size_t)g[m];
-                            if (KIND == 0) {
-                                vx = A.vel[o + 0]; vy = A.vel[o + 1]; vz = A.vel[o + 2];
-                            } else {
-                                float dx = P.x - pvx[m], dy = P.y - pvy[m], dz = P.z - pvz[m];
-                                float qx = dx * tp.inv_h, qy = dy * tp.inv_h, qz = dz * tp.inv_h;
-                                vx = qx * tp.kd; vy = qy * tp.kd; vz = qz * tp.kd;
-                            }
-                            if (KIND == 2) {
-                                A.vel[o + 0] = vx; A.vel[o + 1] = vy; A.vel[o + 2] = vz;
-                            } else {
-                                A.prev[o + 0] = P.x; A.prev[o + 1] = P.y; A.prev[o + 2] = P.z;
-                                if (P.w > 0.0f) {
-                                    vx = vx + tp.hgx; vy = vy + tp.hgy; vz = vz + tp.hgz;
-                                    float hx = tp.h * vx, hy = tp.h * vy, hz = tp.h * vz;
-                                    P.x = P.x + hx; P.y = P.y + hy; P.z = P.z + hz;
-                                    lds_pos[l] = P;
-                                }
-                            }
+                    if (KIND == 2) {
+                        A.vel[o + 0] = vx; A.vel[o + 1] = vy; A.vel[o + 2] = vz;
+                    } else {
+                        A.prev[o + 0] = P.x; A.prev[o + 1] = P.y; A.prev[o + 2] = P.z;
+                        if (P.w > 0.0f) {
+                            vx = vx + tp.hgx; vy = vy + tp.hgy; vz = vz + tp.hgz;
+                            float hx = tp.h * vx, hy = tp.h * vy, hz = tp.h * vz;
+                            P.x = P.x + hx; P.y = P.y + hy; P.z = P.z + hz;
+                            lds_pos[l] = P;
                         }
-                } else if (QUADS) {
-                    if (tid < cnt) {
-                        const uint2 pr = A.q_idx[cur_q + tid];
-                        const float2 rest = A.q_rest[cur_q + tid];
-                        const int i0 = pr.x & 0xffffu, i1 = pr.x >> 16, i2 = pr.y & 0xffffu, i3 = pr.y >> 16;
-                        float4 p0 = lds_pos[i0], p1 = lds_pos[i1], p2 = lds_pos[i2], p3 = lds_pos[i3];
-                        bool ok = type == 1 ? project_volume(p0, p1, p2, p3, rest.x, tp.at_v)
-                                            : project_bending(p0, p1, p2, p3, rest, tp.at_b);
-                        if (ok) { lds_pos[i0] = p0; lds_pos[i1] = p1; lds_pos[i2] = p2; lds_pos[i3] = p3; }
                     }
-                    cur_q += cnt;
                 }
-                prefetch(j);
+        } else {
+            const uint32_t size = type == 0 ? ((2u * cnt + 3u) & ~3u) : 4u * cnt;
+            if (off + size > win_lo + win || off < win_lo) {   // refill the window (uniform; rare for small tiles)
                 __syncthreads();
-                ++r;
+                win_lo = off;
+                load_window(win_lo);
+                __syncthreads();
             }
+            const uint32_t *base = cbuf + (off - win_lo);
+            if (type == 0) {
+                if (tid < cnt) {
+                    const uint2 e = *reinterpret_cast<const uint2 *>(base + 2 * tid);
+                    const int i = e.x & 0xffffu, k = e.x >> 16;
+                    float4 a = lds_pos[i], b = lds_pos[k];
+#if defined(SB_ABLATE) && SB_ABLATE == 2   // timing experiment only: LDS traffic + barriers without the arithmetic
+                    a.x += __uint_as_float(e.y); b.x -= tp.at_d;
+                    lds_pos[i] = a; lds_pos[k] = b;
+#else
+                    if (project_distance(a, b, __uint_as_float(e.y), tp.at_d)) { lds_pos[i] = a; lds_pos[k] = b; }
+#endif
+                }
+            } else if (QUADS) {
+                if (tid < cnt) {
+                    const uint4 e = *reinterpret_cast<const uint4 *>(base + 4 * tid);
+                    const int i0 = e.x & 0xffffu, i1 = e.x >> 16, i2 = e.y & 0xffffu, i3 = e.y >> 16;
+                    const float2 rest = make_float2(__uint_as_float(e.z), __uint_as_float(e.w));
+                    float4 p0 = lds_pos[i0], p1 = lds_pos[i1], p2 = lds_pos[i2], p3 = lds_pos[i3];
+                    bool ok = type == 1 ? project_volume(p0, p1, p2, p3, rest.x, tp.at_v)
+                                        : project_bending(p0, p1, p2, p3, rest, tp.at_b);
+                    if (ok) { lds_pos[i0] = p0; lds_pos[i1] = p1; lds_pos[i2] = p2; lds_pos[i3] = p3; }
+                }
+            }
+            off += size;
         }
+        __syncthreads();
     }
 #pragma unroll
-    for (int m = 0; m < kPPT; ++m)
+    for (int m = 0; m < PPT; ++m)
         if (g[m] >= 0) A.pos[g[m]] = lds_pos[tid + m * kTileThreads];
 }
 

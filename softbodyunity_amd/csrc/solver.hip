@@ -70,13 +70,11 @@ struct DevTiling {
     int32_t n_tiles = 0;
     size_t lds_bytes = 0;
     int64_t n_slots = 0;         // constraint slots stored (cross + full)
+    int32_t max_local = 0, win_dwords = 4;
+    bool has_quads = false;
     DevBuf<sbk::TileDesc> tiles;
     DevBuf<int2> runs_overflow;
-    DevBuf<uint32_t> rounds;
-    DevBuf<uint32_t> d_idx;
-    DevBuf<float> d_rest;
-    DevBuf<uint2> q_idx;
-    DevBuf<float2> q_rest;
+    DevBuf<uint32_t> stream;     // per tile: [round words][cross data][full data], see kernels.hip.hpp
 };
 
 struct DevGColour {
@@ -192,11 +190,10 @@ void build_device(sb_solver *s) {
         DevTiling &D = s->tiling[tl];
         std::vector<sbk::TileDesc> tiles;
         std::vector<int2> overflow;
-        std::vector<uint32_t> rounds, d_idx;
-        std::vector<float> d_rest;
-        std::vector<uint2> q_idx;
-        std::vector<float2> q_rest;
+        std::vector<uint32_t> stream;
         int32_t max_local = 0;
+        uint32_t max_data = 4;
+        auto fbits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
         for (size_t ci = 0; ci < LT.tile_ids.size(); ++ci) {
             const sbp::Tile &T = G.tiles[LT.tile_ids[ci]];
             sbk::TileDesc td{};
@@ -212,32 +209,52 @@ void build_device(sb_solver *s) {
             }
             if (lstart != T.n_local) throw std::runtime_error("internal: tile run lengths do not add up");
             max_local = std::max(max_local, T.n_local);
-            td.round_begin = (int32_t)rounds.size();
             td.n_pre = T.n_pre; td.n_rounds = T.n_rounds;
-            rounds.insert(rounds.end(), G.rounds.begin() + T.round_begin, G.rounds.begin() + T.round_begin + T.n_rounds);
-            td.d_begin = (uint32_t)d_idx.size(); td.q_begin = (uint32_t)q_idx.size();
-            td.d_mid = td.d_begin + (uint32_t)(T.d_mid - T.d_begin);
-            td.q_mid = td.q_begin + (uint32_t)(T.q_mid - T.q_begin);
-            for (int64_t k = T.d_begin; k < T.d_end; ++k) {
-                d_idx.push_back(G.t_dist[k]);
-                d_rest.push_back(s->dist_rest[G.t_dist_id[k]]);
+            if (stream.size() > 0xfffffff0ull - 4ull * (size_t)(T.d_end - T.d_begin + T.q_end - T.q_begin))
+                throw std::runtime_error("tile constraint stream exceeds 2^32 dwords");
+            td.s_begin = (uint32_t)stream.size();
+            const size_t s0 = stream.size();
+            for (int32_t r = 0; r < T.n_rounds; ++r) stream.push_back(G.rounds[T.round_begin + r]);
+            while ((stream.size() - s0) & 3) stream.push_back(0);
+            td.s_hdr = (uint32_t)(stream.size() - s0);
+            int64_t dk = T.d_begin, qk = T.q_begin;
+            for (int32_t r = 0; r < T.n_rounds; ++r) {
+                const uint32_t w = G.rounds[T.round_begin + r];
+                const int cnt = w & 1023u, type = (w >> 10) & 3u;
+                if (r == T.n_pre) td.s_mid = (uint32_t)(stream.size() - s0);
+                if (type == 3) continue;
+                if (type == 0) {
+                    for (int k = 0; k < cnt; ++k, ++dk) {
+                        stream.push_back(G.t_dist[dk]);
+                        stream.push_back(fbits(s->dist_rest[G.t_dist_id[dk]]));
+                    }
+                    while ((stream.size() - s0) & 3) stream.push_back(0);
+                } else {
+                    D.has_quads = true;
+                    for (int k = 0; k < cnt; ++k, ++qk) {
+                        stream.push_back(G.t_quad[2 * qk]); stream.push_back(G.t_quad[2 * qk + 1]);
+                        const int32_t id = G.t_quad_id[qk];
+                        if (G.t_quad_type[qk] == 1) { volatile float r6 = 6.0f * s->vol_rest[id]; stream.push_back(fbits(r6)); stream.push_back(0); }
+                        else { stream.push_back(fbits(s->bend_rest[2 * (size_t)id])); stream.push_back(fbits(s->bend_rest[2 * (size_t)id + 1])); }
+                    }
+                }
             }
-            for (int64_t k = T.q_begin; k < T.q_end; ++k) {
-                q_idx.push_back(make_uint2(G.t_quad[2 * k], G.t_quad[2 * k + 1]));
-                const int32_t id = G.t_quad_id[k];
-                if (G.t_quad_type[k] == 1) { volatile float r6 = 6.0f * s->vol_rest[id]; q_rest.push_back(make_float2(r6, 0.0f)); }
-                else q_rest.push_back(make_float2(s->bend_rest[2 * (size_t)id], s->bend_rest[2 * (size_t)id + 1]));
-            }
+            if (dk != T.d_end || qk != T.q_end) throw std::runtime_error("internal: tile stream does not match its rounds");
+            td.s_len = (uint32_t)(stream.size() - s0);
+            max_data = std::max(max_data, td.s_len - td.s_hdr);
             tiles.push_back(td);
         }
-        if (d_idx.size() > 0xfffffff0ull || q_idx.size() > 0xfffffff0ull) throw std::runtime_error("tile constraint offsets overflow");
         D.n_tiles = (int32_t)tiles.size();
-        D.lds_bytes = (size_t)std::max(max_local, 1) * sizeof(float4);
-        D.n_slots = (int64_t)d_idx.size() + (int64_t)q_idx.size();
+        D.max_local = std::max(max_local, 1);
+        D.win_dwords = (int32_t)std::min<uint32_t>(max_data, 8192u);     // <= 32 KiB of LDS; >= one round (4 KiB)
+        D.lds_bytes = (size_t)D.max_local * sizeof(float4) + sbk::kMaxRoundsLds * 4 + (size_t)D.win_dwords * 4;
+        D.n_slots = 0;
+        for (size_t ci = 0; ci < LT.tile_ids.size(); ++ci) {
+            const sbp::Tile &T = G.tiles[LT.tile_ids[ci]];
+            D.n_slots += (T.d_end - T.d_begin) + (T.q_end - T.q_begin);
+        }
         D.tiles.upload(tiles, s->dev_bytes); D.runs_overflow.upload(overflow, s->dev_bytes);
-        D.rounds.upload(rounds, s->dev_bytes);
-        D.d_idx.upload(d_idx, s->dev_bytes); D.d_rest.upload(d_rest, s->dev_bytes);
-        D.q_idx.upload(q_idx, s->dev_bytes); D.q_rest.upload(q_rest, s->dev_bytes);
+        D.stream.upload(stream, s->dev_bytes);
     }
     for (const sbp::LocalGColour &LG : L.gcolours) {
         auto D = std::make_unique<DevGColour>();
@@ -321,13 +338,18 @@ void launch_tile(sb_solver *s, DevTiling &D) {
     if (D.n_tiles == 0) return;
     sbk::TileArgs A{};
     A.pos = s->d_pos.p; A.prev = s->d_prev.p; A.vel = s->d_vel.p;
-    A.tiles = D.tiles.p; A.runs_overflow = D.runs_overflow.p; A.rounds = D.rounds.p;
-    A.d_idx = D.d_idx.p; A.d_rest = D.d_rest.p; A.q_idx = D.q_idx.p; A.q_rest = D.q_rest.p;
+    A.tiles = D.tiles.p; A.runs_overflow = D.runs_overflow.p; A.stream = D.stream.p;
     A.tp = s->d_tp.p;
-    if (D.q_idx.count)
-        hipLaunchKernelGGL((sbk::tile_kernel<KIND, true>), dim3(D.n_tiles), dim3(sbk::kTileThreads), D.lds_bytes, s->stream, A);
-    else
-        hipLaunchKernelGGL((sbk::tile_kernel<KIND, false>), dim3(D.n_tiles), dim3(sbk::kTileThreads), D.lds_bytes, s->stream, A);
+    A.max_local = D.max_local; A.win_dwords = D.win_dwords;
+    const dim3 grid(D.n_tiles), block(sbk::kTileThreads);
+    const bool small = D.max_local <= 2 * sbk::kTileThreads;   // every tile <= 512 particles
+    if (D.has_quads) {
+        if (small) hipLaunchKernelGGL((sbk::tile_kernel<KIND, true, 2>), grid, block, D.lds_bytes, s->stream, A);
+        else hipLaunchKernelGGL((sbk::tile_kernel<KIND, true, 4>), grid, block, D.lds_bytes, s->stream, A);
+    } else {
+        if (small) hipLaunchKernelGGL((sbk::tile_kernel<KIND, false, 2>), grid, block, D.lds_bytes, s->stream, A);
+        else hipLaunchKernelGGL((sbk::tile_kernel<KIND, false, 4>), grid, block, D.lds_bytes, s->stream, A);
+    }
 }
 
 struct LaunchTimer {            // optional HIP-event pair around every launch of one tick (sb_step_profiled)
@@ -551,8 +573,8 @@ int sb_finalize(sb_solver *s) {
         sbp::extract_local(s->plan->plan, in, o.rank, s->plan->local);
         build_device(s);
         // opt in to the LDS size the largest tile needs
-        size_t max_lds = 0;
-        for (int tl = 0; tl < 2; ++tl) max_lds = std::max(max_lds, s->tiling[tl].lds_bytes);
+        for (int tl = 0; tl < 2; ++tl)
+            if (s->tiling[tl].lds_bytes > 64 * 1024) throw std::runtime_error("internal: tile LDS budget exceeded");
         HIP_CHECK(hipDeviceSynchronize());
         // authoring copies are no longer needed (keep rest values out of memory for 50M-constraint meshes)
         std::vector<float>().swap(s->pos); std::vector<float>().swap(s->vel); std::vector<float>().swap(s->rest);

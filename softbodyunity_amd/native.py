@@ -11,7 +11,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsoftbody_mi355x.so")
+# SB_LIB_VARIANT=name selects libsoftbody_mi355x_name.so (A/B timing builds, see csrc/Makefile); default = the product
+_VARIANT = os.environ.get("SB_LIB_VARIANT", "")
+LIB_PATH = os.path.join(_HERE, f"libsoftbody_mi355x{'_' + _VARIANT if _VARIANT else ''}.so")
 
 SB_UNIQUE_ID_BYTES = 128
 SB_OK = 0
