@@ -77,6 +77,9 @@ namespace SoftbodyMI355X
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_profile_end(IntPtr s, out float elapsedMs);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_synchronize(IntPtr s);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_step_profiled(IntPtr s, float dt, int substeps, IntPtr slotMsOut, IntPtr slotLaunchesOut, int nSlots);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_debug_launch(IntPtr s, float dt, int substeps, int it, int gcolour);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_debug_halo_pack(IntPtr s, int slot, IntPtr hostOut, long capacityFloats, out long countFloats);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_debug_halo_unpack(IntPtr s, int slot, IntPtr hostIn, long countFloats);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_get_stats(IntPtr s, out SbStats stats);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_build(IntPtr restXyz, int n, IntPtr distIj, int mD, IntPtr volIjkl, int mV, IntPtr bendIjkl, int mB, ref SbPlanOpts opts, out IntPtr plan);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_destroy(IntPtr plan);

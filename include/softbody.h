@@ -106,6 +106,14 @@ int sb_synchronize(sb_solver *s);
  * n_slots must be 4 + n_global_colours (sb_get_stats). Same results as sb_step. */
 int sb_step_profiled(sb_solver *s, float dt, int32_t substeps, float *slot_ms_out, int32_t *slot_launches_out,
                      int32_t n_slots);
+/* Test hooks (used by tests/test_gpu_multirank.py to check the multi-rank device path on a box with one
+ * GPU, where RCCL cannot form a communicator): run ONE launch of a tick — tile kernel K_it (gcolour = -1)
+ * or global colour `gcolour` of the substep that K_it started — without any ghost exchange, and move one
+ * halo slot's send / receive buffer through host memory. Buffer layout = what goes over the wire: for
+ * every peer in increasing rank order its float4 positions, then (slot 1 only) the same for xprev. */
+int sb_debug_launch(sb_solver *s, float dt, int32_t substeps, int32_t it, int32_t gcolour);
+int sb_debug_halo_pack(sb_solver *s, int32_t slot, float *host_out, int64_t capacity_floats, int64_t *count_floats_out);
+int sb_debug_halo_unpack(sb_solver *s, int32_t slot, const float *host_in, int64_t count_floats);
 typedef struct {
     int64_t n_particles_owned, n_particles_local;   /* local = owned + ghost */
     int64_t n_constraints_local[3];                 /* distance, volume, bending (incl. redundant cut copies) */

@@ -9,6 +9,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -368,31 +369,42 @@ struct LaunchTimer {            // optional HIP-event pair around every launch o
 
 // One tick (SPEC.md §2/§3): kernel K_s runs on the tiles of tiling T_(s&1) and fuses
 // cross(T) of substep s-1, the velocity update + integrate, and full(T) of substep s.
+// Launch the tile kernel K_it of a tick of `substeps` substeps (no halo).
+void launch_tick_kernel(sb_solver *s, int it, int substeps, LaunchTimer *lt) {
+    const int tl = s->plan->plan.tiling ? (it & 1) : 0;
+    DevTiling &D = s->tiling[tl];
+    if (lt && D.n_tiles) lt->begin(it == 0 ? 2 + (int)s->gcolours.size() : (it == substeps ? 3 + (int)s->gcolours.size() : tl));
+    if (it == 0) launch_tile<0>(s, D);
+    else if (it < substeps) launch_tile<1>(s, D);
+    else launch_tile<2>(s, D);
+    if (lt && D.n_tiles) lt->end();
+}
+
+void launch_gcolour(sb_solver *s, int gc, LaunchTimer *lt) {
+    DevGColour &G = *s->gcolours[gc];
+    if (G.count == 0) return;
+    if (lt) lt->begin(2 + gc);
+    dim3 grid((G.count + 255) / 256);
+    if (G.type == 0)
+        hipLaunchKernelGGL(sbk::global_distance_kernel, grid, dim3(256), 0, s->stream, s->d_pos.p, G.ij.p, G.rest.p, G.count,
+                           s->d_tp.p);
+    else
+        hipLaunchKernelGGL(sbk::global_quad_kernel, grid, dim3(256), 0, s->stream, s->d_pos.p, G.quad.p, G.rest2.p, G.count,
+                           G.type, s->d_tp.p);
+    if (lt) lt->end();
+}
+
+// One tick (SPEC.md §2/§3): kernel K_s runs on the tiles of tiling T_(s&1) and fuses
+// cross(T) of substep s-1, the velocity update + integrate, and full(T) of substep s.
 void enqueue_substeps(sb_solver *s, int substeps, LaunchTimer *lt = nullptr) {
     const bool two = s->plan->plan.tiling;
     for (int it = 0; it <= substeps; ++it) {
-        const int tl = two ? (it & 1) : 0;
-        DevTiling &D = s->tiling[tl];
-        if (tl == 1) halo_exchange(s, 1);
-        if (lt && D.n_tiles) lt->begin(it == 0 ? 2 + (int)s->gcolours.size() : (it == substeps ? 3 + (int)s->gcolours.size() : tl));
-        if (it == 0) launch_tile<0>(s, D);
-        else if (it < substeps) launch_tile<1>(s, D);
-        else launch_tile<2>(s, D);
-        if (lt && D.n_tiles) lt->end();
+        if (two && (it & 1)) halo_exchange(s, 1);
+        launch_tick_kernel(s, it, substeps, lt);
         if (it == substeps) break;
         for (size_t gc = 0; gc < s->gcolours.size(); ++gc) {
-            DevGColour &G = *s->gcolours[gc];
             halo_exchange(s, 2 + (int)gc);
-            if (G.count == 0) continue;
-            if (lt) lt->begin(2 + (int)gc);
-            dim3 grid((G.count + 255) / 256);
-            if (G.type == 0)
-                hipLaunchKernelGGL(sbk::global_distance_kernel, grid, dim3(256), 0, s->stream, s->d_pos.p, G.ij.p, G.rest.p,
-                                   G.count, s->d_tp.p);
-            else
-                hipLaunchKernelGGL(sbk::global_quad_kernel, grid, dim3(256), 0, s->stream, s->d_pos.p, G.quad.p, G.rest2.p,
-                                   G.count, G.type, s->d_tp.p);
-            if (lt) lt->end();
+            launch_gcolour(s, (int)gc, lt);
         }
     }
     HIP_CHECK(hipGetLastError());
@@ -558,7 +570,9 @@ int sb_finalize(sb_solver *s) {
     if (!s) return fail(SB_ERR_INVALID_ARG, "sb_finalize: null handle");
     if (s->finalized) return fail(SB_ERR_STATE, "sb_finalize called twice");
     if (s->n <= 0) return fail(SB_ERR_STATE, "sb_finalize before sb_set_particles");
-    if (s->desc.world > 1 && !s->comm) return fail(SB_ERR_STATE, "sb_finalize: world > 1 needs sb_comm_init first");
+    // SB_TEST_NO_COMM: the hosted-halo test hooks (sb_debug_*) drive world > 1 without an RCCL communicator
+    if (s->desc.world > 1 && !s->comm && !std::getenv("SB_TEST_NO_COMM"))
+        return fail(SB_ERR_STATE, "sb_finalize: world > 1 needs sb_comm_init first");
     return guarded([&]() -> int {
         int rc = set_device(s); if (rc) return rc;
         const std::vector<float> &rest = s->rest.empty() ? s->pos : s->rest;
@@ -634,6 +648,72 @@ int sb_step_profiled(sb_solver *s, float dt, int32_t substeps, float *slot_ms, i
             HIP_CHECK(hipEventElapsedTime(&ms, lt.ev[2 * k], lt.ev[2 * k + 1]));
             slot_ms[lt.slot[k]] += ms; ++slot_launches[lt.slot[k]];
         }
+        return SB_OK;
+    });
+}
+
+/* ---- test hooks: drive one tick launch by launch with the halo carried by the host -------------------- */
+
+int sb_debug_launch(sb_solver *s, float dt, int32_t substeps, int32_t it, int32_t gcolour) {
+    if (!s) return fail(SB_ERR_INVALID_ARG, "sb_debug_launch: null handle");
+    if (!s->finalized) return fail(SB_ERR_STATE, "sb_debug_launch before sb_finalize");
+    if (!(dt > 0.0f) || substeps <= 0 || it < 0 || it > substeps || gcolour >= (int32_t)s->gcolours.size())
+        return fail(SB_ERR_INVALID_ARG, "sb_debug_launch: bad argument");
+    return guarded([&]() -> int {
+        int rc = set_device(s); if (rc) return rc;
+        upload_tick_params(s, dt, substeps);
+        if (gcolour < 0) launch_tick_kernel(s, it, substeps, nullptr);
+        else launch_gcolour(s, gcolour, nullptr);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        return SB_OK;
+    });
+}
+
+int sb_debug_halo_pack(sb_solver *s, int32_t slot, float *host_out, int64_t capacity_floats, int64_t *count_floats) {
+    if (!s || !count_floats) return fail(SB_ERR_INVALID_ARG, "sb_debug_halo_pack: null argument");
+    if (!s->finalized) return fail(SB_ERR_STATE, "sb_debug_halo_pack before sb_finalize");
+    if (slot < 0 || slot >= (int32_t)s->halos.size()) return fail(SB_ERR_INVALID_ARG, "sb_debug_halo_pack: bad slot");
+    return guarded([&]() -> int {
+        int rc = set_device(s); if (rc) return rc;
+        DevHalo &D = *s->halos[slot];
+        const int ns = D.send_off.back();
+        const int64_t need = (int64_t)ns * 4 * (slot == 1 ? 2 : 1);
+        *count_floats = need;
+        if (need == 0) return SB_OK;
+        if (!host_out || capacity_floats < need) return fail(SB_ERR_INVALID_ARG, "sb_debug_halo_pack: buffer too small");
+        if (slot == 1)
+            hipLaunchKernelGGL(sbk::halo_pack_kernel<true>, dim3((ns + 255) / 256), dim3(256), 0, s->stream, s->d_pos.p, s->d_prev.p,
+                               D.send_idx.p, s->d_sendbuf.p, ns);
+        else
+            hipLaunchKernelGGL(sbk::halo_pack_kernel<false>, dim3((ns + 255) / 256), dim3(256), 0, s->stream, s->d_pos.p, s->d_prev.p,
+                               D.send_idx.p, s->d_sendbuf.p, ns);
+        HIP_CHECK(hipMemcpyAsync(host_out, s->d_sendbuf.p, (size_t)need * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        return SB_OK;
+    });
+}
+
+int sb_debug_halo_unpack(sb_solver *s, int32_t slot, const float *host_in, int64_t count_floats) {
+    if (!s) return fail(SB_ERR_INVALID_ARG, "sb_debug_halo_unpack: null handle");
+    if (!s->finalized) return fail(SB_ERR_STATE, "sb_debug_halo_unpack before sb_finalize");
+    if (slot < 0 || slot >= (int32_t)s->halos.size()) return fail(SB_ERR_INVALID_ARG, "sb_debug_halo_unpack: bad slot");
+    return guarded([&]() -> int {
+        int rc = set_device(s); if (rc) return rc;
+        DevHalo &D = *s->halos[slot];
+        const int nr = D.recv_off.back();
+        const int64_t need = (int64_t)nr * 4 * (slot == 1 ? 2 : 1);
+        if (count_floats != need) return fail(SB_ERR_INVALID_ARG, "sb_debug_halo_unpack: wrong element count");
+        if (need == 0) return SB_OK;
+        if (!host_in) return fail(SB_ERR_INVALID_ARG, "sb_debug_halo_unpack: null buffer");
+        HIP_CHECK(hipMemcpyAsync(s->d_recvbuf.p, host_in, (size_t)need * sizeof(float), hipMemcpyHostToDevice, s->stream));
+        if (slot == 1)
+            hipLaunchKernelGGL(sbk::halo_unpack_kernel<true>, dim3((nr + 255) / 256), dim3(256), 0, s->stream, s->d_pos.p, s->d_prev.p,
+                               D.recv_idx.p, s->d_recvbuf.p, nr);
+        else
+            hipLaunchKernelGGL(sbk::halo_unpack_kernel<false>, dim3((nr + 255) / 256), dim3(256), 0, s->stream, s->d_pos.p, s->d_prev.p,
+                               D.recv_idx.p, s->d_recvbuf.p, nr);
+        HIP_CHECK(hipStreamSynchronize(s->stream));
         return SB_OK;
     });
 }

@@ -74,6 +74,9 @@ SIGNATURES = {
     "sb_profile_end": (C.c_int, [_P, C.POINTER(C.c_float)]),
     "sb_synchronize": (C.c_int, [_P]),
     "sb_step_profiled": (C.c_int, [_P, C.c_float, C.c_int32, _P, _P, C.c_int32]),
+    "sb_debug_launch": (C.c_int, [_P, C.c_float, C.c_int32, C.c_int32, C.c_int32]),
+    "sb_debug_halo_pack": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.POINTER(C.c_int64)]),
+    "sb_debug_halo_unpack": (C.c_int, [_P, C.c_int32, _P, C.c_int64]),
     "sb_get_stats": (C.c_int, [_P, C.POINTER(SbStats)]),
     "sb_plan_build": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, C.c_int32, C.POINTER(SbPlanOpts),
                                 C.POINTER(_P)]),
