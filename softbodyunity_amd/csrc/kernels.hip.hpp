@@ -49,6 +49,9 @@ struct TileArgs {
 constexpr int kTileThreads = 256;
 constexpr int kMaxPPT = 4;     // particles per lane (tile <= 1024 particles)
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vectors: one 16-byte load/store, no struct copies
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 struct V3 { float x, y, z; };
 __device__ __forceinline__ V3 sub3(V3 a, V3 b) { return {a.x - b.x, a.y - b.y, a.z - b.z}; }
 __device__ __forceinline__ V3 cross3(V3 a, V3 b) {
@@ -150,13 +153,21 @@ __device__ __forceinline__ bool project_bending(float4 &pa, float4 &pb, float4 &
 // Particles AND the tile's constraint stream are staged in LDS with wide coalesced loads issued together,
 // so a tile pays the HBM latency once; rounds then run LDS-to-LDS with one barrier each. Each lane keeps
 // ownership of up to PPT particles for the MARK step. QUADS = the tiling stores 4-vertex rounds.
+// Workgroup barrier that orders LDS only (global memory is never exchanged between lanes inside a launch);
+// __syncthreads() would also drain vmcnt, i.e. wait for the xprev stores of the MARK step.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 template <int KIND, bool QUADS, int PPT>
 __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileArgs A) {
     extern __shared__ uint4 lds_raw[];
     float4 *lds_pos = reinterpret_cast<float4 *>(lds_raw);
     uint32_t *s_rounds = reinterpret_cast<uint32_t *>(lds_pos + A.max_local);
     uint32_t *cbuf = s_rounds + kMaxRoundsLds;
-    const TileDesc &td = A.tiles[blockIdx.x];
+    // the tile tables are never written by a kernel: read the descriptor through the constant address space so it
+    // stays on the scalar-memory path (s_load), one wide read
+    typedef const TileDesc __attribute__((address_space(4))) *ConstTileDescPtr;
+    const TileDesc __attribute__((address_space(4))) &td = *((ConstTileDescPtr)(uintptr_t)A.tiles + blockIdx.x);
+    const int n_rounds_all = td.n_rounds;
     const int tid = threadIdx.x;
     const int n_local = td.n_local;
     const int run_count = td.run_count;
@@ -182,7 +193,7 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
     }
     // ---- the stretch of the stream this kernel needs, staged through an LDS window -----------------
     const int r_begin = KIND == 0 ? td.n_pre : 0;
-    const int r_end = KIND == 2 ? td.n_pre + 1 : td.n_rounds;
+    const int r_end = KIND == 2 ? td.n_pre + 1 : n_rounds_all;
     const uint32_t d_lo = KIND == 0 ? td.s_mid : td.s_hdr;
     const uint32_t d_hi = KIND == 2 ? td.s_mid : td.s_len;
     const uint32_t win = (uint32_t)A.win_dwords;
@@ -203,27 +214,50 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
             if (b3) dst[i + 3 * kTileThreads] = v3;
         }
     };
-    // issue everything the tile needs from HBM back to back: positions, previous positions, round words, window
-    float4 X[PPT];
+    // Issue everything the tile needs from HBM back to back and BRANCH-FREE (a lane without work reads a valid
+    // dummy address): a divergent `if` around a load makes the compiler wait for it at the end of the block,
+    // which would serialise the tile's loads into several HBM round trips.
+    f32x4 X[PPT];
     float pvx[PPT], pvy[PPT], pvz[PPT];
 #pragma unroll
     for (int m = 0; m < PPT; ++m) {
+        const int gc = max(g[m], 0);
+        X[m] = *reinterpret_cast<const f32x4 *>(A.pos + gc);
         pvx[m] = pvy[m] = pvz[m] = 0.0f;
-        X[m] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (g[m] >= 0) {
-            X[m] = A.pos[g[m]];
-            if (KIND != 0) {
-                pvx[m] = A.prev[3 * (size_t)g[m] + 0]; pvy[m] = A.prev[3 * (size_t)g[m] + 1]; pvz[m] = A.prev[3 * (size_t)g[m] + 2];
-            }
-        }
+        if (KIND != 0) { pvx[m] = A.prev[3 * (size_t)gc + 0]; pvy[m] = A.prev[3 * (size_t)gc + 1]; pvz[m] = A.prev[3 * (size_t)gc + 2]; }
     }
-    const bool rounds_in_lds = td.n_rounds <= kMaxRoundsLds;
-    if (rounds_in_lds && tid < td.n_rounds) s_rounds[tid] = tstream[tid];
-    load_window(win_lo);
+    const bool rounds_in_lds = n_rounds_all <= kMaxRoundsLds;
+    const uint32_t rw = tstream[min(tid, n_rounds_all - 1)];
+    constexpr int kW = 4;    // uint4 per lane in the first sweep of the window (16 KiB); longer windows loop below
+    const uint32_t n4_first = (min(win_lo + win, d_hi) - win_lo) >> 2;
+    const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(tstream + win_lo);
+    u32x4 wv[kW];
+#pragma unroll
+    for (int q = 0; q < kW; ++q) {
+        const uint32_t i = tid + q * kTileThreads;
+        wv[q] = wsrc[i < n4_first ? i : 0u];
+    }
+    // One common use of every loaded value: the scheduler cannot sink a load below it, so all loads are issued
+    // first and a single wait follows (left alone it emits load, wait, LDS write, load, wait, ... to save registers).
+#pragma unroll
+    for (int m = 0; m < PPT; ++m) asm volatile("" ::"v"(X[m].x), "v"(pvx[m]));
+#pragma unroll
+    for (int q = 0; q < kW; ++q) asm volatile("" ::"v"(wv[q].x));
+    asm volatile("" ::"v"(rw));
 #pragma unroll
     for (int m = 0; m < PPT; ++m)
-        if (g[m] >= 0) lds_pos[tid + m * kTileThreads] = X[m];
-    __syncthreads();
+        if (g[m] >= 0) *reinterpret_cast<f32x4 *>(lds_pos + tid + m * kTileThreads) = X[m];
+    if (rounds_in_lds && tid < n_rounds_all) s_rounds[tid] = rw;
+    {
+        u32x4 *dst = reinterpret_cast<u32x4 *>(cbuf);
+#pragma unroll
+        for (int q = 0; q < kW; ++q) {
+            const uint32_t i = tid + q * kTileThreads;
+            if (i < n4_first) dst[i] = wv[q];
+        }
+        for (uint32_t i = tid + kW * kTileThreads; i < n4_first; i += kTileThreads) dst[i] = wsrc[i];
+    }
+    __syncthreads();   // also covers the staging loads
 
     uint32_t off = d_lo;    // dword offset (from the tile's stream start) of the current round's data
 #if defined(SB_ABLATE) && SB_ABLATE == 1   // timing experiment only: memory traffic without the rounds
@@ -231,7 +265,9 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
 #else
     for (int r = r_begin; r < r_end; ++r) {
 #endif
-        const uint32_t w = rounds_in_lds ? s_rounds[r] : tstream[r];
+        uint32_t w;
+        if (rounds_in_lds) w = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rounds[r]);
+        else w = (uint32_t)__builtin_amdgcn_readfirstlane((int)tstream[r]);
         const int cnt = w & 1023u, type = (w >> 10) & 3u;
         if (type == 3) {
             // velocity update of the substep that just finished + integrate of the next one (SPEC.md §2)
@@ -264,7 +300,7 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
         } else {
             const uint32_t size = type == 0 ? ((2u * cnt + 3u) & ~3u) : 4u * cnt;
             if (off + size > win_lo + win || off < win_lo) {   // refill the window (uniform; rare for small tiles)
-                __syncthreads();
+                lds_barrier();
                 win_lo = off;
                 load_window(win_lo);
                 __syncthreads();
@@ -295,7 +331,7 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
             }
             off += size;
         }
-        __syncthreads();
+        lds_barrier();
     }
 #pragma unroll
     for (int m = 0; m < PPT; ++m)
