@@ -36,7 +36,7 @@ def main():
     ap.add_argument("--fetch")
     ap.add_argument("--write")
     ap.add_argument("--key", required=True, help="e.g. n256_tile512_gpus1")
-    ap.add_argument("--slots", default="tile_kernel<1>=0,tile_kernel<2>=1", help="kernel substring = bench slot index")
+    ap.add_argument("--slots", default="tile_kernel<1,=0;tile_kernel<1,=1", help="kernel substring = bench slot index")
     args = ap.parse_args()
     out_dir = os.path.join(ROOT, "profiles")
     os.makedirs(out_dir, exist_ok=True)
@@ -63,7 +63,7 @@ def main():
             us = avg_ns.get(k, 0) / 1e3
             tbs = b / (us * 1e-6) / 1e12 if us else float("nan")
             md.append(f"| `{k[:60]}` | {fe[k][0]:.1f} | {wr[k][0]:.1f} | {b / 1e6:.1f} MB | {us:.2f} | {tbs:.2f} |")
-            for spec in args.slots.split(","):
+            for spec in args.slots.split(";"):
                 sub, slot = spec.split("=")
                 if sub in k:
                     traffic[slot] = b
