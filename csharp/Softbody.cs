@@ -27,6 +27,9 @@ namespace SoftbodyMI355X
         [SerializeField] float distanceCompliance = 0f;
         [SerializeField] float volumeCompliance = 0f;
         [SerializeField] float bendingCompliance = 0f;
+        [SerializeField] bool groundPlane = false;
+        [SerializeField] Vector3 groundNormal = new Vector3(0f, 1f, 0f);
+        [SerializeField] float groundOffset = 0f;
         [Header("Device")]
         [SerializeField] bool useGpu = true;
         [SerializeField] int device = 0;
@@ -75,6 +78,8 @@ namespace SoftbodyMI355X
             if (bendingRestCosSin != null && bendingRestCosSin.Length > 0)
                 Pin(bendingIJKL, i => Pin(bendingRestCosSin, r => SoftbodyNative.Check(
                     SoftbodyNative.sb_set_bending_constraints(handle, i, r, bendingRestCosSin.Length / 2, bendingCompliance), "sb_set_bending_constraints")));
+            if (groundPlane)
+                SoftbodyNative.Check(SoftbodyNative.sb_set_ground_plane(handle, groundNormal.x, groundNormal.y, groundNormal.z, groundOffset, 1), "sb_set_ground_plane");
             SoftbodyNative.Check(SoftbodyNative.sb_finalize(handle), "sb_finalize");
 
             if (!useGpu)
@@ -121,6 +126,9 @@ namespace SoftbodyMI355X
         internal float ComplianceD => distanceCompliance;
         internal float ComplianceV => volumeCompliance;
         internal float ComplianceB => bendingCompliance;
+        internal bool GroundPlane => groundPlane;
+        internal Vector3 GroundNormal => groundNormal;
+        internal float GroundOffset => groundOffset;
 
         static void Pin<T>(T[] a, Action<IntPtr> f)
         {

@@ -66,6 +66,18 @@ namespace SoftbodyMI355X
                         default: ProjectBending(x, w, sb.bendingIJKL, 4 * id, sb.bendingRestCosSin[2 * id], sb.bendingRestCosSin[2 * id + 1], atB); break;
                     }
                 }
+                if (sb.GroundPlane)   // SPEC.md §2 step 2b
+                {
+                    Vector3 pn = sb.GroundNormal; float pd = sb.GroundOffset;
+                    for (int p = 0; p < n; ++p)
+                    {
+                        if (!(w[p] > 0f)) continue;
+                        float a = (float)(pn.x * x[p].x), b = (float)(pn.y * x[p].y), c = (float)(pn.z * x[p].z);
+                        float pen = (float)((float)((float)(a + b) + c) - pd);
+                        if (pen < 0f)
+                            x[p] = new Vector3((float)(x[p].x - (float)(pen * pn.x)), (float)(x[p].y - (float)(pen * pn.y)), (float)(x[p].z - (float)(pen * pn.z)));
+                    }
+                }
                 for (int p = 0; p < n; ++p)
                 {
                     float dx = (float)(x[p].x - prev[p].x), dy = (float)(x[p].y - prev[p].y), dz = (float)(x[p].z - prev[p].z);

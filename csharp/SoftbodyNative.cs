@@ -65,6 +65,7 @@ namespace SoftbodyMI355X
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_distance_constraints(IntPtr s, IntPtr ij, IntPtr restLen, int m, float compliance);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_volume_constraints(IntPtr s, IntPtr ijkl, IntPtr restVol, int m, float compliance);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_bending_constraints(IntPtr s, IntPtr ijkl, IntPtr restCosSin, int m, float compliance);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_ground_plane(IntPtr s, float nx, float ny, float nz, float d, int enabled);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_finalize(IntPtr s);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_comm_unique_id(IntPtr outId128);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_comm_init(IntPtr s, IntPtr id128);

@@ -74,6 +74,9 @@ int sb_set_distance_constraints(sb_solver *s, const int32_t *ij, const float *re
 int sb_set_volume_constraints(sb_solver *s, const int32_t *ijkl, const float *rest_vol, int32_t m, float compliance);
 /* rest_cs: 2 floats per hinge = (cos, sin) of the rest dihedral angle (SPEC.md §6). */
 int sb_set_bending_constraints(sb_solver *s, const int32_t *ijkl, const float *rest_cs, int32_t m, float compliance);
+/* Optional frictionless ground plane n.x >= d applied at the end of every substep (SPEC.md §2 step 2b);
+ * n should be unit length. May be called before or after sb_finalize; takes effect at the next sb_step. */
+int sb_set_ground_plane(sb_solver *s, float nx, float ny, float nz, float d, int32_t enabled);
 /* Plan (colour + tile + partition), upload, capture. After this the authoring calls are rejected. */
 int sb_finalize(sb_solver *s);
 

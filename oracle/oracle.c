@@ -22,6 +22,8 @@ typedef struct {
     float gravity[3];
     float damping;
     float compliance[3]; /* distance, volume, bending */
+    float plane[4];      /* ground plane n.x n.y n.z d  (n.x >= d) */
+    int32_t plane_on;
 } orc_params;
 
 typedef struct {
@@ -65,6 +67,22 @@ void orc_velocity(const float *x, const float *xprev, float *v, int n, const orc
         float dx = x[k] - xprev[k];
         float q = dx * s->inv_h;
         v[k] = q * s->kd;
+    }
+}
+
+/* SPEC.md §2 step 2b. */
+void orc_collide(float *x, const float *w, int n, const orc_params *p) {
+    if (!p->plane_on) return;
+    const float *pl = p->plane;
+    for (int k = 0; k < n; ++k) {
+        if (!(w[k] > 0.0f)) continue;
+        float *xp = x + 3 * (int64_t)k;
+        float a = pl[0] * xp[0], b = pl[1] * xp[1], c = pl[2] * xp[2];
+        float pen = ((a + b) + c) - pl[3];
+        if (pen < 0.0f) {
+            float dx = pen * pl[0], dy = pen * pl[1], dz = pen * pl[2];
+            xp[0] = xp[0] - dx; xp[1] = xp[1] - dy; xp[2] = xp[2] - dz;
+        }
     }
 }
 
@@ -205,6 +223,7 @@ void orc_step(float *x, float *v, const float *w, float *xprev, int n, const orc
         const orc_schedule *sc = &sched[it & 1];
         orc_integrate(x, xprev, v, w, n, &s);
         orc_project_range(x, w, c, sc->order_type, sc->order_id, 0, total, &s);
+        orc_collide(x, w, n, p);
         orc_velocity(x, xprev, v, n, &s);
     }
 }
@@ -235,6 +254,7 @@ void orc_step_tasks(float *x, float *v, const float *w, float *xprev, int n, con
 #pragma omp for schedule(static)
             for (int blk = 0; blk < (n + 4095) / 4096; ++blk) {
                 int b = blk * 4096, e = b + 4096 > n ? n : b + 4096;
+                orc_collide(x + 3 * (int64_t)b, w + b, e - b, p);
                 orc_velocity(x + 3 * (int64_t)b, xprev + 3 * (int64_t)b, v + 3 * (int64_t)b, e - b, &s);
             }
         }

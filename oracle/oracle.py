@@ -22,7 +22,8 @@ def build(force=False):
 
 
 class OrcParams(C.Structure):
-    _fields_ = [("gravity", C.c_float * 3), ("damping", C.c_float), ("compliance", C.c_float * 3)]
+    _fields_ = [("gravity", C.c_float * 3), ("damping", C.c_float), ("compliance", C.c_float * 3),
+                ("plane", C.c_float * 4), ("plane_on", C.c_int32)]
 
 
 class OrcScalars(C.Structure):
@@ -54,6 +55,7 @@ def lib():
         _lib.orc_integrate.restype = None
         _lib.orc_velocity.restype = None
         _lib.orc_scalars_for.restype = None
+        _lib.orc_collide.restype = None
     return _lib
 
 
@@ -105,6 +107,14 @@ class Oracle:
         """rest_cs: (m,2) = (cos phi0, sin phi0) per hinge (SPEC.md §6)."""
         self.bend_ijkl = _i32(ijkl).reshape(-1, 4).copy(); self.bend_rest = _f32(rest_cs, (-1, 2)).copy()
         self.params.compliance[2] = float(compliance)
+
+    def set_ground_plane(self, normal, d, enabled=True):
+        """SPEC.md §2 step 2b: n.x >= d."""
+        self.params.plane[:] = [float(normal[0]), float(normal[1]), float(normal[2]), float(d)]
+        self.params.plane_on = 1 if enabled else 0
+
+    def collide(self):
+        lib().orc_collide(_p(self.x), _p(self.w), C.c_int(self.n), C.byref(self.params))
 
     def set_order(self, order_type, order_id, phase_task_off=None, task_off=None, parity=None):
         """Schedule published by the planner (SPEC.md §3). parity=None sets both parities to the same order."""

@@ -12,7 +12,9 @@ namespace sbk {
 
 struct TickParams {           // SPEC.md §2 host-side scalars, uploaded once per (dt, S)
     float h, inv_h, hgx, hgy, hgz, kd, at_d, at_v, at_b;
-    float pad[7];
+    float pnx, pny, pnz, pd;  // ground plane n.x >= d (SPEC.md §2 step 2b)
+    int32_t plane_on;
+    float pad[2];
 };
 
 // One LDS tile = one workgroup. 128 B, read with scalar loads.
@@ -276,6 +278,15 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
                 if (g[m] >= 0) {
                     const int l = tid + m * kTileThreads;
                     float4 P = lds_pos[l];
+                    if (KIND != 0 && tp.plane_on && P.w > 0.0f) {   // collide: end of the substep that just finished
+                        float a = tp.pnx * P.x, b = tp.pny * P.y, c = tp.pnz * P.z;
+                        float pen = ((a + b) + c) - tp.pd;
+                        if (pen < 0.0f) {
+                            float dx = pen * tp.pnx, dy = pen * tp.pny, dz = pen * tp.pnz;
+                            P.x = P.x - dx; P.y = P.y - dy; P.z = P.z - dz;
+                            if (KIND == 2) lds_pos[l] = P;
+                        }
+                    }
                     float vx, vy, vz;
                     const size_t o = 3 * (size_t)g[m];
                     if (KIND == 0) {

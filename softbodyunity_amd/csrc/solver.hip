@@ -108,6 +108,8 @@ struct sb_solver {
     std::vector<int32_t> dist_ij, vol_ijkl, bend_ijkl;
     std::vector<float> dist_rest, vol_rest, bend_rest;
     float compliance[3] = {0, 0, 0};
+    float plane[4] = {0, 1, 0, 0};
+    int32_t plane_on = 0;
     // plan
     std::unique_ptr<sb_plan> plan;
     // device state
@@ -163,6 +165,7 @@ sbk::TickParams tick_params(const sb_solver *s, float dt, int substeps) {
     volatile float av36 = 36.0f * av;
     volatile float ab = s->compliance[2] / h2;
     t.at_d = ad; t.at_v = av36; t.at_b = ab;
+    t.pnx = s->plane[0]; t.pny = s->plane[1]; t.pnz = s->plane[2]; t.pd = s->plane[3]; t.plane_on = s->plane_on;
     return t;
 }
 
@@ -539,6 +542,14 @@ int sb_set_volume_constraints(sb_solver *s, const int32_t *ijkl, const float *re
 }
 int sb_set_bending_constraints(sb_solver *s, const int32_t *ijkl, const float *rest_cs, int32_t m, float compliance) {
     return set_cons(s, "sb_set_bending_constraints", ijkl, rest_cs, m, compliance, 2, 4, 2);
+}
+
+int sb_set_ground_plane(sb_solver *s, float nx, float ny, float nz, float d, int32_t enabled) {
+    if (!s) return fail(SB_ERR_INVALID_ARG, "sb_set_ground_plane: null handle");
+    if (!(nx == nx) || !(ny == ny) || !(nz == nz) || !(d == d)) return fail(SB_ERR_INVALID_ARG, "sb_set_ground_plane: NaN");
+    s->plane[0] = nx; s->plane[1] = ny; s->plane[2] = nz; s->plane[3] = d;
+    s->plane_on = enabled ? 1 : 0;
+    return SB_OK;   // picked up by the next sb_step (tick parameters are re-uploaded when they change)
 }
 
 int sb_comm_unique_id(uint8_t out_id[SB_UNIQUE_ID_BYTES]) {

@@ -62,6 +62,7 @@ SIGNATURES = {
     "sb_set_distance_constraints": (C.c_int, [_P, _P, _P, C.c_int32, C.c_float]),
     "sb_set_volume_constraints": (C.c_int, [_P, _P, _P, C.c_int32, C.c_float]),
     "sb_set_bending_constraints": (C.c_int, [_P, _P, _P, C.c_int32, C.c_float]),
+    "sb_set_ground_plane": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32]),
     "sb_finalize": (C.c_int, [_P]),
     "sb_comm_unique_id": (C.c_int, [_P]),
     "sb_comm_init": (C.c_int, [_P, _P]),

@@ -18,7 +18,7 @@ class Softbody:
     # [SerializeField] block of csharp/Softbody.cs
     def __init__(self, mesh, substeps=20, fixed_delta_time=0.02, gravity=(0.0, -9.81, 0.0), damping=0.0,
                  distance_compliance=0.0, volume_compliance=0.0, bending_compliance=0.0, device=0, rank=0, world=1,
-                 part_dims=(0, 0, 0), tile_particles=512, use_graph=True, unique_id=None):
+                 part_dims=(0, 0, 0), tile_particles=512, use_graph=True, unique_id=None, ground_plane=None):
         self.mesh = mesh
         self.substeps = int(substeps)
         self.fixed_delta_time = float(fixed_delta_time)
@@ -30,6 +30,7 @@ class Softbody:
         self.tile_particles = int(tile_particles)
         self.use_graph = bool(use_graph)
         self.unique_id = unique_id
+        self.ground_plane = ground_plane   # None or (nx, ny, nz, d): n.x >= d
         self._h = None
         self.vertices = None  # what the C# component assigns to mesh.vertices after each FixedUpdate
 
@@ -67,6 +68,8 @@ class Softbody:
             assert self.unique_id is not None and len(self.unique_id) == native.SB_UNIQUE_ID_BYTES
             buf = (C.c_uint8 * native.SB_UNIQUE_ID_BYTES)(*self.unique_id)
             check(L.sb_comm_init(h, buf))
+        if self.ground_plane is not None:
+            check(L.sb_set_ground_plane(h, *[float(c) for c in self.ground_plane], 1))
         check(L.sb_finalize(h))
         self.vertices = pos.copy()
         return self

@@ -175,3 +175,33 @@ def test_large_cube_properties():
         assert np.abs(d1).mean() < 0.5 * np.abs(d0).mean()
     finally:
         sb.OnDestroy()
+
+
+@pytest.mark.parametrize("tile", [512, -1])
+def test_ground_plane_drop(oracle_mod, tile):
+    # a 12^3 jelly cube dropped on the plane y >= -0.5: collide step fused into the tile kernel's MARK round
+    mesh = jelly_cube(12)
+    plane = (0.0, 1.0, 0.0, -0.5)
+    sb = Softbody(mesh, substeps=10, tile_particles=tile, ground_plane=plane, distance_compliance=1e-6).Start()
+    try:
+        o = make_oracle(oracle_mod, mesh, sb.plan(), compliance=(1e-6, 0, 0), ground_plane=plane)
+        for _ in range(40):
+            sb.step(); o.step(0.02, 10)
+        x = sb.get_positions(); v = sb.get_velocities()
+    finally:
+        sb.OnDestroy()
+    rel, mabs, bit = oracle_mod.parity_error(x, o.x, mesh.pos)
+    assert x[:, 1].min() >= -0.5 and (x[:, 1] < -0.49).sum() > 10      # it landed and rests on the plane
+    assert rel <= TOL and bit, (rel, mabs)
+    assert np.array_equal(v.view(np.uint32), o.v.view(np.uint32))
+
+
+def test_cfg5_surrogate_100k(oracle_mod):
+    # BASELINE.json:11 at its stated size (~100k vertices), single GPU: distance + volume + bending, bit-exact
+    mesh = bunny_surrogate(target_verts=100_000, seed=1234)
+    assert 80_000 < mesh.n < 125_000
+    comp = (1e-7, 1e-7, 1e-4)
+    rel, mabs, bit, x, v, o, st = _run_pair(oracle_mod, mesh, ticks=3, substeps=20, compliance=comp, tile_particles=256)
+    assert st["constraints_in_tiles"] > 0.6 * (len(mesh.dist_rest) + len(mesh.vol_rest) + len(mesh.bend_rest))
+    assert np.isfinite(x).all()
+    assert rel <= TOL and bit, (rel, mabs)

@@ -204,3 +204,22 @@ def test_cube_counts():
     m = jelly_cube(8)
     assert m.n == 512 and len(m.dist_rest) == 1344  # BASELINE.json:7 "~1.4k springs"
     assert np.all(m.dist_rest == 1.0)
+
+
+def test_kat10_ground_plane(oracle_mod):
+    # a free particle dropped on the plane y >= 0 ends up exactly on it with zero normal velocity
+    x0 = np.array([[0.3, 0.05, -0.2], [1.0, 2.0, 0.0]], f32)
+    o = oracle_mod.Oracle(x0, None, np.array([1.0, 0.0], f32), gravity=(0, -9.81, 0))
+    o.set_ground_plane((0, 1, 0), 0.0)
+    for _ in range(20):
+        o.step(0.02, 10)
+    assert o.x[0, 1] == 0.0 and abs(o.v[0, 1]) < 1e-6
+    assert np.array_equal(o.x[0, [0, 2]], x0[0, [0, 2]])        # frictionless: tangential position untouched
+    assert np.array_equal(o.x[1], x0[1])                         # pinned particles ignore the plane
+    # a tilted plane: penetration is removed along the normal
+    n = np.array([0.6, 0.8, 0.0]); p = np.array([[0.0, -1.0, 0.0]], f32)
+    o = oracle_mod.Oracle(p, None, np.ones(1, f32), gravity=(0, 0, 0))
+    o.set_ground_plane(n, 0.5)
+    o.collide()
+    assert abs(np.dot(n, o.x[0].astype(np.float64)) - 0.5) < 1e-6
+    assert np.allclose(np.cross(o.x[0] - p[0], n), 0, atol=1e-6)
