@@ -4,5 +4,6 @@ Product package: HIP kernels + C-ABI plugin (csrc/, libsoftbody_mi355x.so), the 
 P/Invoke layer (native.py), the Softbody component mirror (softbody.py) and the synthetic mesh
 generators (mesh.py). The CPU oracle lives in /oracle and is never imported from here.
 """
-from .mesh import SoftbodyMesh, bunny_surrogate, jelly_cube  # noqa: F401
+from .mesh import (SoftbodyMesh, bunny_surrogate, from_tet_mesh, from_triangle_mesh, jelly_cube,  # noqa: F401
+                   read_tetgen)
 from .softbody import Softbody, comm_unique_id  # noqa: F401

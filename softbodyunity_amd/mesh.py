@@ -115,34 +115,34 @@ def bunny_surrogate(target_verts=100_000, seed=1234, perturb=0.01):
     used = np.unique(T)
     remap = -np.ones(P.shape[0], np.int64); remap[used] = np.arange(used.size)
     P = P[used]; T = remap[T]
-    rest = P.astype(np.float32)
-    # edges
-    pairs = np.concatenate([T[:, [a, b]] for a, b in ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))])
-    pairs.sort(axis=1)
-    ij = np.unique(pairs, axis=0).astype(np.int32)
-    r64 = rest.astype(np.float64)
-    dist_rest = np.linalg.norm(r64[ij[:, 0]] - r64[ij[:, 1]], axis=1).astype(np.float32)
-    vol_rest = (np.einsum("ij,ij->i", r64[T[:, 1]] - r64[T[:, 0]],
-                          np.cross(r64[T[:, 2]] - r64[T[:, 0]], r64[T[:, 3]] - r64[T[:, 0]])) / 6.0).astype(np.float32)
-    # boundary triangles = faces seen once
-    faces = np.concatenate([T[:, [1, 2, 3]], T[:, [0, 3, 2]], T[:, [0, 1, 3]], T[:, [0, 2, 1]]])
-    key = np.sort(faces, axis=1)
-    _, inv, cnt = np.unique(key, axis=0, return_inverse=True, return_counts=True)
-    bfaces = faces[cnt[inv] == 1]
-    # hinges: boundary edges shared by two boundary triangles
-    he = np.concatenate([bfaces[:, [0, 1, 2]], bfaces[:, [1, 2, 0]], bfaces[:, [2, 0, 1]]])  # (a,b,opp)
+    m = from_tet_mesh(P, T, label="bunny_SURROGATE")
+    rest = m.rest_pos; r64 = rest.astype(np.float64)
+    jitter = rng.uniform(-perturb, perturb, size=rest.shape) * pitch
+    pos = (r64 + jitter).astype(np.float32)
+    m.pos = pos
+    m.label = f"bunny_SURROGATE_{rest.shape[0]}v"
+    return m
+
+
+# ---- authoring: render / tet meshes -> particles + constraint graph -------------------
+
+def _hinges(r64, tris):
+    """Bending hinges (SPEC.md §6) for every manifold edge shared by exactly two triangles of `tris`.
+    Returns (ijkl, rest_cos_sin): shared edge (i0,i1), wings i2,i3."""
+    he = np.concatenate([tris[:, [0, 1, 2]], tris[:, [1, 2, 0]], tris[:, [2, 0, 1]]])  # (a,b,opp)
     ek = np.sort(he[:, :2], axis=1)
     order = np.lexsort((ek[:, 1], ek[:, 0]))
     ek = ek[order]; he = he[order]
     same = (ek[1:] == ek[:-1]).all(axis=1)
     first = np.nonzero(same)[0]
-    # keep only manifold pairs (edge seen exactly twice)
     ok = np.ones(first.size, bool)
-    if first.size > 1:
+    if first.size > 1:   # keep only edges seen exactly twice
         ok[1:] &= first[1:] != first[:-1] + 1
         ok[:-1] &= first[1:] != first[:-1] + 1
     first = first[ok]
     bend = np.stack([ek[first, 0], ek[first, 1], he[first, 2], he[first + 1, 2]], axis=1).astype(np.int32)
+    if bend.shape[0] == 0:
+        return bend.reshape(0, 4), np.zeros((0, 2), np.float32)
     A, B, Cw, D = (r64[bend[:, k]] for k in range(4))
     e = B - A
     n1 = np.cross(A - Cw, B - Cw); n2 = np.cross(B - D, A - D)
@@ -151,9 +151,81 @@ def bunny_surrogate(target_verts=100_000, seed=1234, perturb=0.01):
     bend = bend[good]; n1 = n1[good] / l1[good, None]; n2 = n2[good] / l2[good, None]; e = e[good] / le[good, None]
     cs = np.einsum("ij,ij->i", n1, n2)
     sn = -np.einsum("ij,ij->i", np.cross(n1, n2), e)
-    c0 = np.stack([cs, sn], axis=1).astype(np.float32)   # SPEC.md §6 rest pair (cos phi0, sin phi0)
-    jitter = rng.uniform(-perturb, perturb, size=rest.shape) * pitch
-    pos = (r64 + jitter).astype(np.float32)
-    return SoftbodyMesh(rest_pos=rest, pos=pos, vel=np.zeros_like(pos), inv_mass=np.ones(rest.shape[0], np.float32),
-                        dist_ij=ij, dist_rest=dist_rest, vol_ijkl=T.astype(np.int32), vol_rest=vol_rest,
-                        bend_ijkl=bend, bend_rest=c0, label=f"bunny_SURROGATE_{rest.shape[0]}v")
+    return bend, np.stack([cs, sn], axis=1).astype(np.float32)
+
+
+def from_tet_mesh(nodes, tets, mass_density=None, label="tet_mesh"):
+    """Tetrahedral mesh -> particles, edge springs, tet volume constraints, surface-hinge bending.
+
+    Tets are re-oriented to positive volume. inv_mass = 1 unless mass_density is given (then lumped tet masses)."""
+    P = np.asarray(nodes, np.float64).reshape(-1, 3)
+    T = np.asarray(tets, np.int64).reshape(-1, 4).copy()
+    vol6 = np.einsum("ij,ij->i", P[T[:, 1]] - P[T[:, 0]], np.cross(P[T[:, 2]] - P[T[:, 0]], P[T[:, 3]] - P[T[:, 0]]))
+    neg = vol6 < 0
+    T[neg] = T[neg][:, [0, 2, 1, 3]]
+    rest = P.astype(np.float32)
+    r64 = rest.astype(np.float64)
+    pairs = np.concatenate([T[:, [a, b]] for a, b in ((0, 1), (0, 2), (0, 3), (1, 2), (1, 3), (2, 3))])
+    pairs.sort(axis=1)
+    ij = np.unique(pairs, axis=0).astype(np.int32)
+    dist_rest = np.linalg.norm(r64[ij[:, 0]] - r64[ij[:, 1]], axis=1).astype(np.float32)
+    vol = np.einsum("ij,ij->i", r64[T[:, 1]] - r64[T[:, 0]], np.cross(r64[T[:, 2]] - r64[T[:, 0]], r64[T[:, 3]] - r64[T[:, 0]])) / 6.0
+    faces = np.concatenate([T[:, [1, 2, 3]], T[:, [0, 3, 2]], T[:, [0, 1, 3]], T[:, [0, 2, 1]]])
+    key = np.sort(faces, axis=1)
+    _, inv, cnt = np.unique(key, axis=0, return_inverse=True, return_counts=True)
+    bfaces = faces[cnt[inv.ravel()] == 1]
+    bend, c0 = _hinges(r64, bfaces)
+    w = np.ones(rest.shape[0], np.float32)
+    if mass_density is not None:
+        mass = np.zeros(rest.shape[0])
+        np.add.at(mass, T.ravel(), np.repeat(np.abs(vol) * mass_density / 4.0, 4))
+        w = (1.0 / np.maximum(mass, 1e-30)).astype(np.float32)
+    return SoftbodyMesh(rest_pos=rest, pos=rest.copy(), vel=np.zeros_like(rest), inv_mass=w, dist_ij=ij,
+                        dist_rest=dist_rest, vol_ijkl=T.astype(np.int32), vol_rest=vol.astype(np.float32),
+                        bend_ijkl=bend, bend_rest=c0, label=label)
+
+
+def from_triangle_mesh(vertices, triangles, weld_eps=1e-6, label="surface_mesh"):
+    """Render mesh (Unity Mesh.vertices / Mesh.triangles) -> welded particles, edge springs, hinge bending.
+
+    Unity duplicates vertices along UV/normal seams; particles are the welded positions. Returns
+    (SoftbodyMesh, particle_of_vertex) so the component can scatter particle positions back to mesh.vertices."""
+    V = np.asarray(vertices, np.float64).reshape(-1, 3)
+    F = np.asarray(triangles, np.int64).reshape(-1, 3)
+    q = np.round(V / max(weld_eps, 1e-30)).astype(np.int64)
+    _, first, particle_of_vertex = np.unique(q, axis=0, return_index=True, return_inverse=True)
+    particle_of_vertex = particle_of_vertex.ravel()
+    rest = V[first].astype(np.float32)
+    r64 = rest.astype(np.float64)
+    Fp = particle_of_vertex[F]
+    Fp = Fp[(Fp[:, 0] != Fp[:, 1]) & (Fp[:, 1] != Fp[:, 2]) & (Fp[:, 0] != Fp[:, 2])]     # drop degenerate triangles
+    pairs = np.concatenate([Fp[:, [0, 1]], Fp[:, [1, 2]], Fp[:, [2, 0]]])
+    pairs.sort(axis=1)
+    ij = np.unique(pairs, axis=0).astype(np.int32)
+    dist_rest = np.linalg.norm(r64[ij[:, 0]] - r64[ij[:, 1]], axis=1).astype(np.float32)
+    bend, c0 = _hinges(r64, Fp)
+    m = SoftbodyMesh(rest_pos=rest, pos=rest.copy(), vel=np.zeros_like(rest), inv_mass=np.ones(rest.shape[0], np.float32),
+                     dist_ij=ij, dist_rest=dist_rest, bend_ijkl=bend, bend_rest=c0, label=label)
+    return m, particle_of_vertex.astype(np.int32)
+
+
+def read_tetgen(node_path, ele_path):
+    """TetGen .node/.ele pair -> from_tet_mesh (so a real Stanford-bunny tet mesh can replace the surrogate)."""
+    def rows(path):
+        out = []
+        for line in open(path):
+            line = line.split("#", 1)[0].strip()
+            if line:
+                out.append(line.split())
+        return out
+    nr = rows(node_path); er = rows(ele_path)
+    n_nodes, dim = int(nr[0][0]), int(nr[0][1])
+    assert dim == 3, "3-D .node file expected"
+    ids = np.array([int(r[0]) for r in nr[1:1 + n_nodes]])
+    nodes = np.array([[float(c) for c in r[1:4]] for r in nr[1:1 + n_nodes]])
+    base = ids.min()      # TetGen files are 0- or 1-based
+    assert np.array_equal(ids, np.arange(base, base + n_nodes)), "node ids must be consecutive"
+    n_tets, npt = int(er[0][0]), int(er[0][1])
+    assert npt >= 4
+    tets = np.array([[int(c) - base for c in r[1:5]] for r in er[1:1 + n_tets]])
+    return from_tet_mesh(nodes, tets, label=f"tetgen:{node_path}")

@@ -1,0 +1,115 @@
+"""Mesh -> constraint-graph authoring: Unity-style render meshes and TetGen tet meshes."""
+import numpy as np
+import pytest
+
+from softbodyunity_amd.mesh import from_tet_mesh, from_triangle_mesh, read_tetgen
+from helpers import build_plan, make_oracle
+
+
+def unity_cube():
+    """24 vertices / 12 triangles like Unity's built-in cube: every face has its own 4 vertices."""
+    faces = [((0, 0, 0), (1, 0, 0), (1, 1, 0), (0, 1, 0)), ((0, 0, 1), (0, 1, 1), (1, 1, 1), (1, 0, 1)),
+             ((0, 0, 0), (0, 1, 0), (0, 1, 1), (0, 0, 1)), ((1, 0, 0), (1, 0, 1), (1, 1, 1), (1, 1, 0)),
+             ((0, 0, 0), (0, 0, 1), (1, 0, 1), (1, 0, 0)), ((0, 1, 0), (1, 1, 0), (1, 1, 1), (0, 1, 1))]
+    V, F = [], []
+    for f in faces:
+        b = len(V); V += list(f); F += [(b, b + 2, b + 1), (b, b + 3, b + 2)]   # outward winding
+    return np.array(V, np.float32), np.array(F, np.int32)
+
+
+def grid_cloth(n):
+    xs, ys = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
+    V = np.stack([xs.ravel(), np.zeros(n * n), ys.ravel()], axis=1).astype(np.float32)
+    idx = lambda i, j: i * n + j
+    F = []
+    for i in range(n - 1):
+        for j in range(n - 1):
+            F += [(idx(i, j), idx(i + 1, j), idx(i + 1, j + 1)), (idx(i, j), idx(i + 1, j + 1), idx(i, j + 1))]
+    return V, np.array(F, np.int32)
+
+
+def test_unity_cube_welds_to_8_particles():
+    V, F = unity_cube()
+    m, pov = from_triangle_mesh(V, F)
+    assert m.n == 8 and len(pov) == 24
+    assert np.allclose(m.rest_pos[pov], V)
+    assert len(m.dist_rest) == 18                      # 12 cube edges + 6 face diagonals
+    assert len(m.bend_rest) == 18                      # every edge is shared by exactly two triangles
+    c = m.bend_rest[:, 0]; s = m.bend_rest[:, 1]
+    assert np.allclose(c * c + s * s, 1, atol=1e-6)
+    assert np.sum(np.isclose(c, 1, atol=1e-6)) == 6    # the six face diagonals are flat hinges
+    assert np.sum(np.isclose(np.abs(s), 1, atol=1e-6)) == 12   # cube edges: 90 degree hinges (sign follows the hinge vertex order)
+
+
+def test_cloth_rest_state_is_a_fixed_point_and_bending_resists_folding(oracle_mod):
+    V, F = grid_cloth(10)
+    m, _ = from_triangle_mesh(V, F)
+    assert m.n == 100 and len(m.bend_rest) == 9 * 9 + 2 * 9 * 8     # one hinge per interior edge
+    assert np.allclose(m.bend_rest, [1, 0], atol=1e-6)
+    o = make_oracle(oracle_mod, m, build_plan(m, tile_particles=64), gravity=(0, 0, 0))
+    o.step(0.02, 10)
+    assert np.allclose(o.x, m.rest_pos, atol=1e-6)
+    # fold one half up by 40 degrees about the line x = 4.5; bending pulls the sheet back towards flat
+    th = np.deg2rad(40.0)
+    m.pos = m.rest_pos.copy()
+    up = m.rest_pos[:, 0] > 4.5
+    dx = m.rest_pos[up, 0] - 4.5
+    m.pos[up, 0] = 4.5 + dx * np.cos(th); m.pos[up, 1] = dx * np.sin(th)
+
+    def fold_height(x):      # mean (1 - cos phi) over all hinges: 0 = flat, independent of rigid motion
+        x = x.astype(np.float64); h = m.bend_ijkl
+        A, B, Cw, D = (x[h[:, k]] for k in range(4))
+        n1 = np.cross(A - Cw, B - Cw); n2 = np.cross(B - D, A - D)
+        cs = np.einsum("ij,ij->i", n1, n2) / np.linalg.norm(n1, axis=1) / np.linalg.norm(n2, axis=1)
+        return float((1 - cs).mean())
+    res = {}
+    for name, comp in (("springs only", None), ("with bending", 0.0)):
+        mm = m if comp is not None else type(m)(rest_pos=m.rest_pos, pos=m.pos, vel=m.vel, inv_mass=m.inv_mass,
+                                                 dist_ij=m.dist_ij, dist_rest=m.dist_rest)
+        o = make_oracle(oracle_mod, mm, build_plan(mm, tile_particles=64), gravity=(0, 0, 0), damping=20.0)
+        for _ in range(5):
+            o.step(0.02, 10)
+        assert np.isfinite(o.x).all()
+        res[name] = fold_height(o.x)
+    assert res["with bending"] < 0.5 * res["springs only"], res
+
+
+def test_tet_mesh_and_tetgen_reader(tmp_path, oracle_mod):
+    nodes = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [1, 1, 0], [0, 0, 1], [1, 0, 1], [0, 1, 1], [1, 1, 1]], float)
+    tets = np.array([[0, 1, 3, 7], [0, 1, 7, 5], [0, 5, 7, 4], [0, 3, 2, 7], [0, 2, 6, 7], [0, 6, 4, 7]])   # 6-tet cube
+    m = from_tet_mesh(nodes, tets)
+    assert np.all(m.vol_rest > 0) and abs(m.vol_rest.sum() - 1.0) < 1e-6
+    assert len(m.dist_rest) == 12 + 6 + 1 and len(m.bend_rest) == 18
+    (tmp_path / "c.node").write_text("8 3 0 0\n" + "\n".join(f"{i + 1} {p[0]} {p[1]} {p[2]}" for i, p in enumerate(nodes)) + "\n# end\n")
+    (tmp_path / "c.ele").write_text("6 4 0\n" + "\n".join(f"{i + 1} " + " ".join(str(v + 1) for v in t) for i, t in enumerate(tets)) + "\n")
+    m2 = read_tetgen(tmp_path / "c.node", tmp_path / "c.ele")
+    assert np.array_equal(m2.vol_ijkl, m.vol_ijkl) and np.array_equal(m2.dist_ij, m.dist_ij)
+    # squash the cube: volume constraints restore the volume
+    m.pos = m.rest_pos * np.array([1, 0.8, 1], np.float32)
+    o = make_oracle(oracle_mod, m, build_plan(m), gravity=(0, 0, 0))
+
+    def vol(x):
+        t = m.vol_ijkl
+        return (np.einsum("ij,ij->i", x[t[:, 1]] - x[t[:, 0]], np.cross(x[t[:, 2]] - x[t[:, 0]], x[t[:, 3]] - x[t[:, 0]])) / 6).sum()
+    for _ in range(10):
+        o.step(0.02, 10)
+    assert abs(vol(o.x.astype(np.float64)) - 1.0) < 0.02
+
+
+@pytest.mark.gpu
+def test_cloth_through_the_plugin(oracle_mod):
+    from softbodyunity_amd import Softbody
+    V, F = grid_cloth(40)
+    m, _ = from_triangle_mesh(V, F)
+    m.inv_mass[m.rest_pos[:, 0] == 0] = 0.0           # pin one edge, let it swing under gravity
+    sb = Softbody(m, substeps=10, tile_particles=128, distance_compliance=1e-7, bending_compliance=1e-3).Start()
+    try:
+        o = make_oracle(oracle_mod, m, sb.plan(), compliance=(1e-7, 0, 1e-3))
+        for _ in range(10):
+            sb.step(); o.step(0.02, 10)
+        x = sb.get_positions()
+    finally:
+        sb.OnDestroy()
+    rel, mabs, bit = oracle_mod.parity_error(x, o.x, m.pos)
+    assert rel <= 1e-4 and bit
+    assert x[:, 1].min() < -1.0                        # it did swing down
