@@ -112,4 +112,4 @@ def test_cloth_through_the_plugin(oracle_mod):
         sb.OnDestroy()
     rel, mabs, bit = oracle_mod.parity_error(x, o.x, m.pos)
     assert rel <= 1e-4 and bit
-    assert x[:, 1].min() < -1.0                        # it did swing down
+    assert x[:, 1].min() < -0.1                        # it did swing down (0.2 s of fall)
