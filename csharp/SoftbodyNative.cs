@@ -73,6 +73,8 @@ namespace SoftbodyMI355X
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_get_positions(IntPtr s, IntPtr posXyzOut, int n);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_get_velocities(IntPtr s, IntPtr velXyzOut, int n);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_state(IntPtr s, IntPtr posXyz, IntPtr velXyz, int n);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_readback_begin(IntPtr s);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_readback_end(IntPtr s, out IntPtr posXyz);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_get_owner(IntPtr s, IntPtr ownerRankOut, int n);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_profile_begin(IntPtr s);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_profile_end(IntPtr s, out float elapsedMs);

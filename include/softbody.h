@@ -96,6 +96,13 @@ int sb_step(sb_solver *s, float dt, int32_t substeps);
 int sb_get_positions(sb_solver *s, float *pos_xyz_out, int32_t n);
 int sb_get_velocities(sb_solver *s, float *vel_xyz_out, int32_t n);
 int sb_set_state(sb_solver *s, const float *pos_xyz, const float *vel_xyz, int32_t n); /* after finalize */
+/* Asynchronous render readback: sb_readback_begin snapshots the positions as of every sb_step issued so far
+ * (a small kernel on the compute stream) and starts a D2H copy into plugin-owned pinned memory on a second
+ * stream; the next sb_step overlaps with that copy. sb_readback_end waits for the OLDEST pending snapshot and
+ * returns a pointer to n*3 floats in caller numbering (entries of particles another rank owns stay 0), valid
+ * until the second sb_readback_begin after it. At most two snapshots may be pending. */
+int sb_readback_begin(sb_solver *s);
+int sb_readback_end(sb_solver *s, const float **pos_xyz_out);
 int sb_get_owner(sb_solver *s, int32_t *owner_rank_out, int32_t n);
 
 /* ---- measurement ----------------------------------------------------------------------------- */

@@ -371,6 +371,15 @@ __global__ __launch_bounds__(256) void global_quad_kernel(float4 *pos, const int
     if (ok) { pos[e.x] = p0; pos[e.y] = p1; pos[e.z] = p2; pos[e.w] = p3; }
 }
 
+// Render readback: owned positions (device order, float4) -> caller order, packed xyz.
+__global__ __launch_bounds__(256) void snapshot_kernel(const float4 *pos, const int32_t *local_to_old, float *out_xyz, int n_owned) {
+    const int l = blockIdx.x * 256 + threadIdx.x;
+    if (l >= n_owned) return;
+    const float4 p = pos[l];
+    const size_t o = 3 * (size_t)local_to_old[l];
+    out_xyz[o] = p.x; out_xyz[o + 1] = p.y; out_xyz[o + 2] = p.z;
+}
+
 // Halo pack / unpack: ghost positions travel as float4; with WITH_PREV the previous positions follow in a
 // second float4 block (needed by the T1 kernels, which run velocity + integrate on ghosts too).
 template <bool WITH_PREV>

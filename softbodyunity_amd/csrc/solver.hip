@@ -126,11 +126,24 @@ struct sb_solver {
     bool tp_valid = false;
     std::map<int, hipGraphExec_t> graphs;
     std::vector<float4> h_stage;
+    // asynchronous render readback (sb_readback_begin / sb_readback_end): two snapshot slots
+    hipStream_t copy_stream = nullptr;
+    DevBuf<int32_t> d_local_to_old;
+    DevBuf<float> d_snap[2];
+    float *h_snap[2] = {nullptr, nullptr};
+    hipEvent_t ev_snap[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
+    int snap_head = 0, snap_pending = 0;   // ring of at most two snapshots in flight
 
     ~sb_solver() {
         for (auto &g : graphs) (void)hipGraphExecDestroy(g.second);
         if (comm) (void)ncclCommDestroy(comm);
         gcolours.clear(); halos.clear();
+        for (int k = 0; k < 2; ++k) {
+            if (h_snap[k]) (void)hipHostFree(h_snap[k]);
+            if (ev_snap[k]) (void)hipEventDestroy(ev_snap[k]);
+            if (ev_copied[k]) (void)hipEventDestroy(ev_copied[k]);
+        }
+        if (copy_stream) (void)hipStreamDestroy(copy_stream);
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -787,6 +800,54 @@ int sb_set_state(sb_solver *s, const float *pos, const float *vel, int32_t n) {
         }
         HIP_CHECK(hipMemcpy(s->d_pos.p, hp.data(), hp.size() * sizeof(float4), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(s->d_vel.p, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice));
+        return SB_OK;
+    });
+}
+
+/* ---- asynchronous render readback -------------------------------------------- */
+
+int sb_readback_begin(sb_solver *s) {
+    if (!s) return fail(SB_ERR_INVALID_ARG, "sb_readback_begin: null handle");
+    if (!s->finalized) return fail(SB_ERR_STATE, "sb_readback_begin before sb_finalize");
+    if (s->snap_pending == 2) return fail(SB_ERR_STATE, "sb_readback_begin: two snapshots already pending, call sb_readback_end");
+    return guarded([&]() -> int {
+        int rc = set_device(s); if (rc) return rc;
+        if (!s->copy_stream) {
+            HIP_CHECK(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
+            s->d_local_to_old.upload(s->plan->local.local_to_old, s->dev_bytes);
+            for (int k = 0; k < 2; ++k) {
+                s->d_snap[k].alloc((size_t)s->n * 3, s->dev_bytes);
+                HIP_CHECK(hipMemset(s->d_snap[k].p, 0, (size_t)s->n * 3 * sizeof(float)));
+                HIP_CHECK(hipHostMalloc((void **)&s->h_snap[k], (size_t)s->n * 3 * sizeof(float), hipHostMallocDefault));
+                std::memset(s->h_snap[k], 0, (size_t)s->n * 3 * sizeof(float));
+                HIP_CHECK(hipEventCreateWithFlags(&s->ev_snap[k], hipEventDisableTiming));
+                HIP_CHECK(hipEventCreateWithFlags(&s->ev_copied[k], hipEventDisableTiming));
+            }
+        }
+        const int k = (s->snap_head + s->snap_pending) & 1;
+        // snapshot on the compute stream (ordered after every tick enqueued so far, before the next one) ...
+        if (s->n_owned)
+            hipLaunchKernelGGL(sbk::snapshot_kernel, dim3((unsigned)((s->n_owned + 255) / 256)), dim3(256), 0, s->stream,
+                               s->d_pos.p, s->d_local_to_old.p, s->d_snap[k].p, (int)s->n_owned);
+        HIP_CHECK(hipEventRecord(s->ev_snap[k], s->stream));
+        // ... D2H on the copy stream, overlapping whatever the compute stream does next
+        HIP_CHECK(hipStreamWaitEvent(s->copy_stream, s->ev_snap[k], 0));
+        HIP_CHECK(hipMemcpyAsync(s->h_snap[k], s->d_snap[k].p, (size_t)s->n * 3 * sizeof(float), hipMemcpyDeviceToHost, s->copy_stream));
+        HIP_CHECK(hipEventRecord(s->ev_copied[k], s->copy_stream));
+        ++s->snap_pending;
+        return SB_OK;
+    });
+}
+
+int sb_readback_end(sb_solver *s, const float **pos_xyz_out) {
+    if (!s || !pos_xyz_out) return fail(SB_ERR_INVALID_ARG, "sb_readback_end: null argument");
+    if (s->snap_pending == 0) return fail(SB_ERR_STATE, "sb_readback_end without a pending sb_readback_begin");
+    return guarded([&]() -> int {
+        int rc = set_device(s); if (rc) return rc;
+        const int k = s->snap_head;
+        HIP_CHECK(hipEventSynchronize(s->ev_copied[k]));
+        *pos_xyz_out = s->h_snap[k];
+        s->snap_head ^= 1; --s->snap_pending;
         return SB_OK;
     });
 }

@@ -109,6 +109,15 @@ class Softbody:
         check(native.lib().sb_get_velocities(self._h, ptr(out), self.n))
         return out
 
+    def readback_begin(self):
+        check(native.lib().sb_readback_begin(self._h))
+
+    def readback_end(self):
+        """-> (N,3) float32 view of the plugin's pinned snapshot (valid until the second readback_begin after it)."""
+        p = C.POINTER(C.c_float)()
+        check(native.lib().sb_readback_end(self._h, C.byref(p)))
+        return np.ctypeslib.as_array(p, shape=(self.n, 3))
+
     def set_state(self, pos, vel):
         pos = f32(pos, (-1, 3)); vel = f32(vel, (-1, 3))
         check(native.lib().sb_set_state(self._h, ptr(pos), ptr(vel), self.n))

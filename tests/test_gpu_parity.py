@@ -205,3 +205,26 @@ def test_cfg5_surrogate_100k(oracle_mod):
     assert st["constraints_in_tiles"] > 0.6 * (len(mesh.dist_rest) + len(mesh.vol_rest) + len(mesh.bend_rest))
     assert np.isfinite(x).all()
     assert rel <= TOL and bit, (rel, mabs)
+
+
+def test_async_readback_matches_blocking_readback():
+    # snapshots taken between ticks equal sb_get_positions at the same point, while later ticks
+    # are already enqueued behind them
+    mesh = jelly_cube(32)
+    sb = Softbody(mesh, substeps=10).Start()
+    try:
+        ref = []
+        for _ in range(3):
+            sb.step(); ref.append(sb.get_positions().copy())
+        sb.set_state(mesh.pos, mesh.vel)
+        sb.step(); sb.readback_begin()
+        sb.step(); sb.readback_begin()                 # two pending, both ticks enqueued before either is read
+        a = sb.readback_end().copy()
+        sb.step(); sb.readback_begin()
+        b = sb.readback_end().copy(); c = sb.readback_end().copy()
+        for got, want in zip((a, b, c), ref):
+            assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
+        with pytest.raises(native.SoftbodyError):
+            sb.readback_end()
+    finally:
+        sb.OnDestroy()
