@@ -1,0 +1,115 @@
+"""Edge cases through the C ABI on the GPU, each against the oracle (bit-exact): empty / tiny / degenerate inputs."""
+import numpy as np
+import pytest
+
+from softbodyunity_amd import Softbody, native
+from softbodyunity_amd.mesh import SoftbodyMesh, jelly_cube
+from helpers import make_oracle
+
+pytestmark = pytest.mark.gpu
+f32 = np.float32
+
+
+def _mesh(pos, ij=None, rest=None, w=None, vel=None):
+    pos = np.asarray(pos, f32).reshape(-1, 3)
+    n = pos.shape[0]
+    ij = np.zeros((0, 2), np.int32) if ij is None else np.asarray(ij, np.int32).reshape(-1, 2)
+    rest = np.zeros(0, f32) if rest is None else np.asarray(rest, f32)
+    return SoftbodyMesh(rest_pos=pos.copy(), pos=pos.copy(), vel=np.zeros_like(pos) if vel is None else np.asarray(vel, f32),
+                        inv_mass=np.ones(n, f32) if w is None else np.asarray(w, f32), dist_ij=ij, dist_rest=rest)
+
+
+def _pair(oracle_mod, mesh, ticks=3, S=7, **kw):
+    sb = Softbody(mesh, substeps=S, **kw).Start()
+    try:
+        o = make_oracle(oracle_mod, mesh, sb.plan())
+        for _ in range(ticks):
+            sb.step(); o.step(0.02, S)
+        x, v = sb.get_positions(), sb.get_velocities()
+    finally:
+        sb.OnDestroy()
+    assert np.array_equal(x.view(np.uint32), o.x.view(np.uint32))
+    assert np.array_equal(v.view(np.uint32), o.v.view(np.uint32))
+    return x, v
+
+
+def test_single_particle_no_constraints(oracle_mod):
+    x, v = _pair(oracle_mod, _mesh([[0, 1, 0]], vel=[[1, 0, 0]]))
+    assert x[0, 1] < 1.0 and x[0, 0] > 0.0
+
+
+def test_particles_without_any_constraint_and_tiling_off(oracle_mod):
+    rng = np.random.default_rng(0)
+    _pair(oracle_mod, _mesh(rng.uniform(-1, 1, (1000, 3))), tile_particles=-1)
+    _pair(oracle_mod, _mesh(rng.uniform(-1, 1, (1000, 3))), tile_particles=64)
+
+
+def test_zero_length_spring_is_skipped_and_everything_pinned_is_static(oracle_mod):
+    # coincident endpoints: L = 0 -> SPEC §4 skips the constraint (no NaN)
+    m = _mesh([[0, 0, 0], [0, 0, 0], [1, 0, 0]], ij=[[0, 1], [1, 2]], rest=[0.5, 1.0])
+    x, v = _pair(oracle_mod, m)
+    assert np.isfinite(x).all()
+    m = jelly_cube(6); m.inv_mass[:] = 0.0
+    x, v = _pair(oracle_mod, m)
+    assert np.array_equal(x, m.pos) and not v.any()
+
+
+def test_one_substep_and_odd_substep_counts(oracle_mod):
+    m = jelly_cube(9)
+    for S in (1, 2, 3, 5):
+        _pair(oracle_mod, m, ticks=4, S=S, tile_particles=64)
+
+
+def test_ragged_cells_non_cubic_block_and_duplicate_springs(oracle_mod):
+    # a 13 x 7 x 5 block (cells ragged at every face) with every x-spring listed twice
+    nx, ny, nz = 13, 7, 5
+    g = np.stack(np.meshgrid(np.arange(nx), np.arange(ny), np.arange(nz), indexing="ij"), -1).reshape(-1, 3).astype(f32)
+    idx = lambda i, j, k: (i * ny + j) * nz + k
+    ij = []
+    for i in range(nx):
+        for j in range(ny):
+            for k in range(nz):
+                if i + 1 < nx: ij += [(idx(i, j, k), idx(i + 1, j, k))] * 2
+                if j + 1 < ny: ij.append((idx(i, j, k), idx(i, j + 1, k)))
+                if k + 1 < nz: ij.append((idx(i, j, k), idx(i, j, k + 1)))
+    ij = np.array(ij, np.int32)
+    m = _mesh(g + np.random.default_rng(1).uniform(-0.05, 0.05, g.shape).astype(f32), ij=ij, rest=np.ones(len(ij), f32))
+    m.rest_pos = g
+    for tile in (64, 512, -1):
+        _pair(oracle_mod, m, tile_particles=tile)
+
+
+def test_long_range_springs_go_to_global_colours(oracle_mod):
+    m = jelly_cube(10)
+    rng = np.random.default_rng(2)
+    extra = rng.integers(0, m.n, (300, 2)).astype(np.int32)
+    extra = extra[extra[:, 0] != extra[:, 1]]
+    m.dist_ij = np.concatenate([m.dist_ij, extra])
+    m.dist_rest = np.concatenate([m.dist_rest, np.linalg.norm(m.rest_pos[extra[:, 0]] - m.rest_pos[extra[:, 1]], axis=1).astype(f32)])
+    sb = Softbody(m, substeps=5, tile_particles=64).Start()
+    try:
+        assert sb.stats()["n_global_colours"] > 0
+    finally:
+        sb.OnDestroy()
+    _pair(oracle_mod, m, S=5, tile_particles=64)
+
+
+def test_bad_calls_are_rejected():
+    import ctypes as C
+    m = jelly_cube(4)
+    sb = Softbody(m).Start()
+    try:
+        L = native.lib()
+        assert L.sb_step(sb._h, -0.02, 10) == native.SB_ERR_INVALID_ARG
+        assert L.sb_step(sb._h, 0.02, 0) == native.SB_ERR_INVALID_ARG
+        assert L.sb_set_particles(sb._h, native.ptr(m.pos), None, native.ptr(m.inv_mass), m.n) == native.SB_ERR_STATE
+        out = np.zeros((m.n + 1, 3), f32)
+        assert L.sb_get_positions(sb._h, native.ptr(out), m.n + 1) == native.SB_ERR_INVALID_ARG
+        assert L.sb_finalize(sb._h) == native.SB_ERR_STATE
+        p = C.POINTER(C.c_float)()
+        assert L.sb_readback_end(sb._h, C.byref(p)) == native.SB_ERR_STATE
+    finally:
+        sb.OnDestroy()
+    bad = jelly_cube(4); bad.inv_mass[3] = -1.0
+    with pytest.raises(native.SoftbodyError):
+        Softbody(bad).Start()
