@@ -43,7 +43,16 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-n", type=int, default=0, help="cube edge for the CPU baseline sample (0 = auto)")
+    ap.add_argument("--loopback-world", type=int, default=0,
+                    help="diagnostic: run as rank 0 of this many ranks with SB_TEST_LOOPBACK (RCCL self-exchange on one GPU); "
+                         "the reported value counts only the particles this rank owns")
     args = ap.parse_args()
+
+    # stdout carries exactly one JSON line: native libraries (RCCL prints a version banner on communicator
+    # creation) write to fd 1, so park fd 1 on stderr until the result is ready
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -74,7 +83,13 @@ def main():
         dist.broadcast(buf, src=0)
         uid = bytes(buf.tolist())
     dt = 0.02
-    sb = Softbody(mesh, substeps=args.substeps, fixed_delta_time=dt, device=local_rank, rank=rank, world=world,
+    sb_world = world
+    if args.loopback_world > 1:
+        assert world == 1, "--loopback-world is a single-process diagnostic"
+        os.environ["SB_TEST_LOOPBACK"] = "1"
+        sb_world = args.loopback_world
+        uid = comm_unique_id()
+    sb = Softbody(mesh, substeps=args.substeps, fixed_delta_time=dt, device=local_rank, rank=rank, world=sb_world,
                   tile_particles=args.tile, use_graph=not args.no_graph, unique_id=uid).Start()
     stats = sb.stats()
     setup_s = time.time() - t_setup
@@ -111,6 +126,8 @@ def main():
     slot_ms /= prof_ticks
     finite = bool(np.isfinite(sb.get_positions()[sb.owner() == rank]).all())
 
+    if args.loopback_world > 1:
+        N = int(stats["n_particles_owned"])      # diagnostic mode: only this rank's share is simulated
     value = N * args.substeps * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
     out = None
@@ -171,8 +188,10 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    sys.stdout.flush()
+    os.dup2(real_stdout, 1)
     if rank == 0:
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
 
 
 def _dims(world):

@@ -46,6 +46,7 @@ struct TileArgs {
     const TickParams *tp;
     int32_t max_local;        // LDS carve: [max_local float4][kMaxRoundsLds dwords][win_dwords dwords]
     int32_t win_dwords;       // constraint window held in LDS (multiple of 4, >= the largest round)
+    int32_t tile_base;        // this launch covers tiles tile_base + blockIdx.x (boundary / interior split)
 };
 
 constexpr int kTileThreads = 256;
@@ -168,7 +169,7 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
     // the tile tables are never written by a kernel: read the descriptor through the constant address space so it
     // stays on the scalar-memory path (s_load), one wide read
     typedef const TileDesc __attribute__((address_space(4))) *ConstTileDescPtr;
-    const TileDesc __attribute__((address_space(4))) &td = *((ConstTileDescPtr)(uintptr_t)A.tiles + blockIdx.x);
+    const TileDesc __attribute__((address_space(4))) &td = *((ConstTileDescPtr)(uintptr_t)A.tiles + (A.tile_base + blockIdx.x));
     const int n_rounds_all = td.n_rounds;
     const int tid = threadIdx.x;
     const int n_local = td.n_local;
@@ -380,16 +381,17 @@ __global__ __launch_bounds__(256) void snapshot_kernel(const float4 *pos, const 
     out_xyz[o] = p.x; out_xyz[o + 1] = p.y; out_xyz[o + 2] = p.z;
 }
 
-// Halo pack / unpack: ghost positions travel as float4; with WITH_PREV the previous positions follow in a
-// second float4 block (needed by the T1 kernels, which run velocity + integrate on ghosts too).
+// Halo pack / unpack: ghost positions travel as float4; with WITH_PREV every particle travels as a
+// {position, previous position} pair of float4 (the T1 kernels run velocity + integrate on ghosts too).
 template <bool WITH_PREV>
 __global__ __launch_bounds__(256) void halo_pack_kernel(const float4 *pos, const float *prev, const int32_t *idx,
                                                         float4 *buf, int count) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= count) return;
     const int g = idx[k];
-    buf[k] = pos[g];
-    if (WITH_PREV) buf[count + k] = make_float4(prev[3 * (size_t)g], prev[3 * (size_t)g + 1], prev[3 * (size_t)g + 2], 0.0f);
+    if (!WITH_PREV) { buf[k] = pos[g]; return; }
+    buf[2 * (size_t)k] = pos[g];   // {position, previous position} pairs: one contiguous message per peer
+    buf[2 * (size_t)k + 1] = make_float4(prev[3 * (size_t)g], prev[3 * (size_t)g + 1], prev[3 * (size_t)g + 2], 0.0f);
 }
 template <bool WITH_PREV>
 __global__ __launch_bounds__(256) void halo_unpack_kernel(float4 *pos, float *prev, const int32_t *idx, const float4 *buf,
@@ -397,9 +399,10 @@ __global__ __launch_bounds__(256) void halo_unpack_kernel(float4 *pos, float *pr
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= count) return;
     const int g = idx[k];
-    pos[g] = buf[k];
-    if (WITH_PREV) {
-        const float4 p = buf[count + k];
+    if (!WITH_PREV) { pos[g] = buf[k]; return; }
+    pos[g] = buf[2 * (size_t)k];
+    {
+        const float4 p = buf[2 * (size_t)k + 1];
         prev[3 * (size_t)g] = p.x; prev[3 * (size_t)g + 1] = p.y; prev[3 * (size_t)g + 2] = p.z;
     }
 }

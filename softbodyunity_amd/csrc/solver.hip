@@ -72,6 +72,7 @@ struct DevTiling {
     size_t lds_bytes = 0;
     int64_t n_slots = 0;         // constraint slots stored (cross + full)
     int32_t max_local = 0, win_dwords = 4;
+    int32_t n_boundary = 0;      // T0 with world > 1: the first n_boundary tiles hold every particle some peer needs
     bool has_quads = false;
     DevBuf<sbk::TileDesc> tiles;
     DevBuf<int2> runs_overflow;
@@ -102,6 +103,10 @@ struct sb_solver {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ncclComm_t comm = nullptr;
+    bool loopback = false;           // SB_TEST_LOOPBACK: every peer is this rank itself (1-GPU pipeline test)
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_boundary = nullptr, ev_halo = nullptr;
+    bool overlap_halo = false;       // T0 boundary tiles first, ghost exchange on comm_stream beside the interior
     // authoring copies
     int32_t n = 0;
     std::vector<float> pos, vel, invm, rest;
@@ -137,6 +142,9 @@ struct sb_solver {
     ~sb_solver() {
         for (auto &g : graphs) (void)hipGraphExecDestroy(g.second);
         if (comm) (void)ncclCommDestroy(comm);
+        if (ev_boundary) (void)hipEventDestroy(ev_boundary);
+        if (ev_halo) (void)hipEventDestroy(ev_halo);
+        if (comm_stream) (void)hipStreamDestroy(comm_stream);
         gcolours.clear(); halos.clear();
         for (int k = 0; k < 2; ++k) {
             if (h_snap[k]) (void)hipHostFree(h_snap[k]);
@@ -203,8 +211,29 @@ void build_device(sb_solver *s) {
     // tilings: re-base this rank's tiles onto compact device arrays
     for (int tl = 0; tl < 2; ++tl) {
         const sbp::Tiling &G = P.T[tl];
-        const sbp::LocalTiling &LT = L.T[tl];
+        sbp::LocalTiling LT = L.T[tl];     // copy: T0 is re-ordered boundary tiles first
         DevTiling &D = s->tiling[tl];
+        if (tl == 0 && L.world > 1 && L.halo.size() > 1) {
+            std::vector<uint8_t> sent((size_t)s->n_local, 0);
+            for (const auto &lst : L.halo[1].send_idx) for (int32_t li : lst) sent[li] = 1;
+            std::vector<int32_t> order(LT.tile_ids.size());
+            std::vector<uint8_t> is_b(LT.tile_ids.size(), 0);
+            for (size_t ci = 0; ci < LT.tile_ids.size(); ++ci) {
+                order[ci] = (int32_t)ci;
+                for (int32_t r = LT.run_begin[ci]; r < LT.run_begin[ci + 1] && !is_b[ci]; ++r)
+                    for (int32_t q = 0; q < LT.runs[r].len; ++q) if (sent[LT.runs[r].start + q]) { is_b[ci] = 1; break; }
+            }
+            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return is_b[a] > is_b[b]; });
+            sbp::LocalTiling R;
+            R.run_begin.push_back(0);
+            for (int32_t ci : order) {
+                R.tile_ids.push_back(LT.tile_ids[ci]);
+                for (int32_t r = LT.run_begin[ci]; r < LT.run_begin[ci + 1]; ++r) R.runs.push_back(LT.runs[r]);
+                R.run_begin.push_back((int32_t)R.runs.size());
+                D.n_boundary += is_b[ci];
+            }
+            LT = R;
+        }
         std::vector<sbk::TileDesc> tiles;
         std::vector<int2> overflow;
         std::vector<uint32_t> stream;
@@ -314,9 +343,10 @@ void build_device(sb_solver *s) {
     s->d_recvbuf.alloc(max_recv, s->dev_bytes);
 }
 
-// Ghost refresh for one halo slot. Buffers hold [positions of all peers][previous positions of all peers];
-// each peer's share is sent as one message per block.
-void halo_exchange(sb_solver *s, int slot) {
+// Ghost refresh for one halo slot. Buffers hold every peer's particles back to back (slot 1: {position, previous
+// position} pairs), so each peer gets exactly one message per direction.
+void halo_exchange(sb_solver *s, int slot, hipStream_t st = nullptr) {
+    if (!st) st = s->stream;
     if (slot < 0 || slot >= (int)s->halos.size()) return;
     DevHalo &D = *s->halos[slot];
     if (!D.active()) return;
@@ -325,40 +355,40 @@ void halo_exchange(sb_solver *s, int slot) {
     const int ns = D.send_off.back(), nr = D.recv_off.back();
     if (ns) {
         if (with_prev)
-            hipLaunchKernelGGL(sbk::halo_pack_kernel<true>, dim3((ns + 255) / 256), dim3(256), 0, s->stream, s->d_pos.p,
+            hipLaunchKernelGGL(sbk::halo_pack_kernel<true>, dim3((ns + 255) / 256), dim3(256), 0, st, s->d_pos.p,
                                s->d_prev.p, D.send_idx.p, s->d_sendbuf.p, ns);
         else
-            hipLaunchKernelGGL(sbk::halo_pack_kernel<false>, dim3((ns + 255) / 256), dim3(256), 0, s->stream, s->d_pos.p,
+            hipLaunchKernelGGL(sbk::halo_pack_kernel<false>, dim3((ns + 255) / 256), dim3(256), 0, st, s->d_pos.p,
                                s->d_prev.p, D.send_idx.p, s->d_sendbuf.p, ns);
     }
     NCCL_CHECK(ncclGroupStart());
     for (size_t k = 0; k < D.peers.size(); ++k) {
         const int cs = D.send_off[k + 1] - D.send_off[k], cr = D.recv_off[k + 1] - D.recv_off[k];
-        for (int blk = 0; blk < (with_prev ? 2 : 1); ++blk) {
-            if (cs) NCCL_CHECK(ncclSend(s->d_sendbuf.p + (size_t)blk * ns + D.send_off[k], (size_t)cs * 4, ncclFloat, D.peers[k], s->comm, s->stream));
-            if (cr) NCCL_CHECK(ncclRecv(s->d_recvbuf.p + (size_t)blk * nr + D.recv_off[k], (size_t)cr * 4, ncclFloat, D.peers[k], s->comm, s->stream));
-        }
+        const size_t m = with_prev ? 2 : 1;   // float4 per particle; one message per peer and direction
+        if (cs) NCCL_CHECK(ncclSend(s->d_sendbuf.p + m * D.send_off[k], m * (size_t)cs * 4, ncclFloat, s->loopback ? 0 : D.peers[k], s->comm, st));
+        if (cr) NCCL_CHECK(ncclRecv(s->d_recvbuf.p + m * D.recv_off[k], m * (size_t)cr * 4, ncclFloat, s->loopback ? 0 : D.peers[k], s->comm, st));
     }
     NCCL_CHECK(ncclGroupEnd());
     if (nr) {
         if (with_prev)
-            hipLaunchKernelGGL(sbk::halo_unpack_kernel<true>, dim3((nr + 255) / 256), dim3(256), 0, s->stream, s->d_pos.p,
+            hipLaunchKernelGGL(sbk::halo_unpack_kernel<true>, dim3((nr + 255) / 256), dim3(256), 0, st, s->d_pos.p,
                                s->d_prev.p, D.recv_idx.p, s->d_recvbuf.p, nr);
         else
-            hipLaunchKernelGGL(sbk::halo_unpack_kernel<false>, dim3((nr + 255) / 256), dim3(256), 0, s->stream, s->d_pos.p,
+            hipLaunchKernelGGL(sbk::halo_unpack_kernel<false>, dim3((nr + 255) / 256), dim3(256), 0, st, s->d_pos.p,
                                s->d_prev.p, D.recv_idx.p, s->d_recvbuf.p, nr);
     }
 }
 
 template <int KIND>
-void launch_tile(sb_solver *s, DevTiling &D) {
-    if (D.n_tiles == 0) return;
+void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = -1) {
+    if (tile_end < 0) tile_end = D.n_tiles;
+    if (tile_end <= tile_begin) return;
     sbk::TileArgs A{};
     A.pos = s->d_pos.p; A.prev = s->d_prev.p; A.vel = s->d_vel.p;
     A.tiles = D.tiles.p; A.runs_overflow = D.runs_overflow.p; A.stream = D.stream.p;
     A.tp = s->d_tp.p;
-    A.max_local = D.max_local; A.win_dwords = D.win_dwords;
-    const dim3 grid(D.n_tiles), block(sbk::kTileThreads);
+    A.max_local = D.max_local; A.win_dwords = D.win_dwords; A.tile_base = tile_begin;
+    const dim3 grid(tile_end - tile_begin), block(sbk::kTileThreads);
     const bool small = D.max_local <= 2 * sbk::kTileThreads;   // every tile <= 512 particles
     if (D.has_quads) {
         if (small) hipLaunchKernelGGL((sbk::tile_kernel<KIND, true, 2>), grid, block, D.lds_bytes, s->stream, A);
@@ -386,13 +416,13 @@ struct LaunchTimer {            // optional HIP-event pair around every launch o
 // One tick (SPEC.md §2/§3): kernel K_s runs on the tiles of tiling T_(s&1) and fuses
 // cross(T) of substep s-1, the velocity update + integrate, and full(T) of substep s.
 // Launch the tile kernel K_it of a tick of `substeps` substeps (no halo).
-void launch_tick_kernel(sb_solver *s, int it, int substeps, LaunchTimer *lt) {
+void launch_tick_kernel(sb_solver *s, int it, int substeps, LaunchTimer *lt, int tile_begin = 0, int tile_end = -1) {
     const int tl = s->plan->plan.tiling ? (it & 1) : 0;
     DevTiling &D = s->tiling[tl];
     if (lt && D.n_tiles) lt->begin(it == 0 ? 2 + (int)s->gcolours.size() : (it == substeps ? 3 + (int)s->gcolours.size() : tl));
-    if (it == 0) launch_tile<0>(s, D);
-    else if (it < substeps) launch_tile<1>(s, D);
-    else launch_tile<2>(s, D);
+    if (it == 0) launch_tile<0>(s, D, tile_begin, tile_end);
+    else if (it < substeps) launch_tile<1>(s, D, tile_begin, tile_end);
+    else launch_tile<2>(s, D, tile_begin, tile_end);
     if (lt && D.n_tiles) lt->end();
 }
 
@@ -414,6 +444,29 @@ void launch_gcolour(sb_solver *s, int gc, LaunchTimer *lt) {
 // cross(T) of substep s-1, the velocity update + integrate, and full(T) of substep s.
 void enqueue_substeps(sb_solver *s, int substeps, LaunchTimer *lt = nullptr) {
     const bool two = s->plan->plan.tiling;
+    if (s->overlap_halo) {
+        // T0 kernels run their boundary tiles first; the ghost exchange for the following T1 kernel then travels
+        // on comm_stream while the interior tiles run. T0 interior tiles touch neither the packed particles
+        // (they live in boundary tiles) nor the ghost slots the unpack writes.
+        DevTiling &T0 = s->tiling[0];
+        for (int it = 0; it <= substeps; ++it) {
+            if (it & 1) {
+                HIP_CHECK(hipStreamWaitEvent(s->stream, s->ev_halo, 0));
+                launch_tick_kernel(s, it, substeps, lt);
+            } else {
+                launch_tick_kernel(s, it, substeps, lt, 0, T0.n_boundary);
+                if (it < substeps) {
+                    HIP_CHECK(hipEventRecord(s->ev_boundary, s->stream));
+                    HIP_CHECK(hipStreamWaitEvent(s->comm_stream, s->ev_boundary, 0));
+                    halo_exchange(s, 1, s->comm_stream);
+                    HIP_CHECK(hipEventRecord(s->ev_halo, s->comm_stream));
+                }
+                launch_tick_kernel(s, it, substeps, lt, T0.n_boundary, T0.n_tiles);
+            }
+        }
+        HIP_CHECK(hipGetLastError());
+        return;
+    }
     for (int it = 0; it <= substeps; ++it) {
         if (two && (it & 1)) halo_exchange(s, 1);
         launch_tick_kernel(s, it, substeps, lt);
@@ -585,7 +638,13 @@ int sb_comm_init(sb_solver *s, const uint8_t id_bytes[SB_UNIQUE_ID_BYTES]) {
         int rc = set_device(s); if (rc) return rc;
         ncclUniqueId id;
         std::memcpy(&id, id_bytes, sizeof(id));
-        NCCL_CHECK(ncclCommInitRank(&s->comm, s->desc.world, id, s->desc.rank));
+        if (std::getenv("SB_TEST_LOOPBACK")) {
+            // pipeline test on one GPU: a communicator of size 1, every peer replaced by this rank itself
+            s->loopback = true;
+            NCCL_CHECK(ncclCommInitRank(&s->comm, 1, id, 0));
+        } else {
+            NCCL_CHECK(ncclCommInitRank(&s->comm, s->desc.world, id, s->desc.rank));
+        }
         return SB_OK;
     });
 }
@@ -613,6 +672,15 @@ int sb_finalize(sb_solver *s) {
         // opt in to the LDS size the largest tile needs
         for (int tl = 0; tl < 2; ++tl)
             if (s->tiling[tl].lds_bytes > 64 * 1024) throw std::runtime_error("internal: tile LDS budget exceeded");
+        if (s->desc.world > 1 && s->comm && s->plan->plan.tiling && s->gcolours.empty() && s->halos.size() > 1 &&
+            s->halos[1]->active() && std::getenv("SB_HALO_OVERLAP")) {
+            // opt-in: on the one measurement available (RCCL loopback on one GPU, 8-rank share of 256^3) splitting the T0
+            // launch and running the exchange beside the interior tiles was 10 % SLOWER than the serialised schedule
+            HIP_CHECK(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
+            HIP_CHECK(hipEventCreateWithFlags(&s->ev_boundary, hipEventDisableTiming));
+            HIP_CHECK(hipEventCreateWithFlags(&s->ev_halo, hipEventDisableTiming));
+            s->overlap_halo = true;
+        }
         HIP_CHECK(hipDeviceSynchronize());
         // authoring copies are no longer needed (keep rest values out of memory for 50M-constraint meshes)
         std::vector<float>().swap(s->pos); std::vector<float>().swap(s->vel); std::vector<float>().swap(s->rest);
@@ -630,7 +698,8 @@ int sb_step(sb_solver *s, float dt, int32_t substeps) {
     return guarded([&]() -> int {
         int rc = set_device(s); if (rc) return rc;
         upload_tick_params(s, dt, substeps);
-        const bool graph_ok = s->desc.use_graph && s->desc.world == 1;
+        // world > 1: RCCL send/recv inside a captured graph is opt-in (SB_GRAPH_RCCL=1), see DESIGN.md §7
+        const bool graph_ok = s->desc.use_graph && !s->overlap_halo && (s->desc.world == 1 || std::getenv("SB_GRAPH_RCCL"));
         if (!graph_ok) { enqueue_substeps(s, substeps); return SB_OK; }
         auto it = s->graphs.find(substeps);
         if (it == s->graphs.end()) {
