@@ -293,6 +293,7 @@ void build_device(sb_solver *s) {
         D.n_tiles = (int32_t)tiles.size();
         D.max_local = std::max(max_local, 1);
         D.win_dwords = (int32_t)std::min<uint32_t>(max_data, 8192u);     // <= 32 KiB of LDS; >= one round (4 KiB)
+        if (const char *e = std::getenv("SB_WIN_DWORDS")) D.win_dwords = std::max(1024, std::min(D.win_dwords, std::atoi(e)) & ~3);   // tuning experiments
         D.lds_bytes = (size_t)D.max_local * sizeof(float4) + sbk::kMaxRoundsLds * 4 + (size_t)D.win_dwords * 4;
         D.n_slots = 0;
         for (size_t ci = 0; ci < LT.tile_ids.size(); ++ci) {
