@@ -19,22 +19,27 @@ struct TickParams {           // SPEC.md §2 host-side scalars, uploaded once pe
 
 // One LDS tile = one workgroup. 128 B, read with scalar loads.
 // The tile's constraint stream lives at stream[s_begin ...], 16-byte aligned, in dwords:
-//   [round words, padded to 4] [cross rounds' data] [full rounds' data]
-// round word: bits 0-9 count, bits 10-11 type (0 distance, 1 volume, 2 bending, 3 = velocity/integrate marker);
-// a distance round stores count x {i | j<<16, rest length} (padded to 4 dwords), a 4-vertex round stores
-// count x {i0|i1<<16, i2|i3<<16, rest.x, rest.y}; the marker stores nothing.
+//   [round words, padded to 4] [rest-length palette, padded to 4] [cross rounds' data] [full rounds' data]
+// round word: bits 0-9 count, bits 10-12 type (0 distance, 1 volume, 2 bending, 3 = velocity/integrate marker,
+// 4 = distance, dictionary-coded);
+// a distance round stores count x {i | j<<16, rest length} (padded to 4 dwords); when a tile's distance
+// constraints use at most 256 distinct rest lengths (regular meshes) they are dictionary-coded instead:
+// count x {i | j<<12 | palette index<<24} (one dword each) with the values in the tile's palette;
+// a 4-vertex round stores count x {i0|i1<<16, i2|i3<<16, rest.x, rest.y}; the marker stores nothing.
 struct TileDesc {
     int32_t n_local, run_count, n_pre, n_rounds;   // n_rounds = cross rounds + marker + full rounds
     uint32_t s_begin;          // dword offset of the tile's stream
-    uint32_t s_hdr;            // dwords of round words (padded): cross data starts at s_begin + s_hdr
+    uint32_t s_hdr;            // dwords of round words + palette (each padded to 4): cross data starts at s_begin + s_hdr
     uint32_t s_mid;            // dword offset (from s_begin) of the full part's data
     uint32_t s_len;            // total dwords (multiple of 4)
     int32_t run_overflow;      // runs beyond kInlineRuns live at runs_overflow[run_overflow ...]
-    int32_t pad0, pad1, pad2;
+    int32_t n_pal;             // palette entries (0 = no dictionary coding), stored after the round words
+    int32_t pad1, pad2;
     int2 runs[10];             // {first particle (device numbering), first tile-local index}
 };
 constexpr int kInlineRuns = 10;
 constexpr int kMaxRoundsLds = 128;   // round words cached in LDS; longer programs read them from memory
+constexpr int kMaxPalette = 256;     // rest-length dictionary entries per tile
 
 struct TileArgs {
     float4 *pos;              // (x,y,z,w) per local particle
@@ -44,7 +49,8 @@ struct TileArgs {
     const int2 *runs_overflow;
     const uint32_t *stream;
     const TickParams *tp;
-    int32_t max_local;        // LDS carve: [max_local float4][kMaxRoundsLds dwords][win_dwords dwords]
+    int32_t max_local;        // LDS carve: [max_local float4][kMaxRoundsLds dwords][pal_dwords dwords][win_dwords dwords]
+    int32_t pal_dwords;       // 0 or kMaxPalette
     int32_t win_dwords;       // constraint window held in LDS (multiple of 4, >= the largest round)
     int32_t tile_base;        // this launch covers tiles tile_base + blockIdx.x (boundary / interior split)
 };
@@ -165,7 +171,8 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
     extern __shared__ uint4 lds_raw[];
     float4 *lds_pos = reinterpret_cast<float4 *>(lds_raw);
     uint32_t *s_rounds = reinterpret_cast<uint32_t *>(lds_pos + A.max_local);
-    uint32_t *cbuf = s_rounds + kMaxRoundsLds;
+    float *s_pal = reinterpret_cast<float *>(s_rounds + kMaxRoundsLds);
+    uint32_t *cbuf = s_rounds + kMaxRoundsLds + A.pal_dwords;
     // the tile tables are never written by a kernel: read the descriptor through the constant address space so it
     // stays on the scalar-memory path (s_load), one wide read
     typedef const TileDesc __attribute__((address_space(4))) *ConstTileDescPtr;
@@ -231,6 +238,8 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
     }
     const bool rounds_in_lds = n_rounds_all <= kMaxRoundsLds;
     const uint32_t rw = tstream[min(tid, n_rounds_all - 1)];
+    const int n_pal = td.n_pal;
+    const uint32_t palw = tstream[((n_rounds_all + 3) & ~3) + min(tid, max(n_pal, 1) - 1)];   // palette follows the round words
     constexpr int kW = 4;    // uint4 per lane in the first sweep of the window (16 KiB); longer windows loop below
     const uint32_t n4_first = (min(win_lo + win, d_hi) - win_lo) >> 2;
     const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(tstream + win_lo);
@@ -246,11 +255,12 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
     for (int m = 0; m < PPT; ++m) asm volatile("" ::"v"(X[m].x), "v"(pvx[m]));
 #pragma unroll
     for (int q = 0; q < kW; ++q) asm volatile("" ::"v"(wv[q].x));
-    asm volatile("" ::"v"(rw));
+    asm volatile("" ::"v"(rw), "v"(palw));
 #pragma unroll
     for (int m = 0; m < PPT; ++m)
         if (g[m] >= 0) *reinterpret_cast<f32x4 *>(lds_pos + tid + m * kTileThreads) = X[m];
     if (rounds_in_lds && tid < n_rounds_all) s_rounds[tid] = rw;
+    if (tid < n_pal) s_pal[tid] = __uint_as_float(palw);
     {
         u32x4 *dst = reinterpret_cast<u32x4 *>(cbuf);
 #pragma unroll
@@ -271,7 +281,7 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
         uint32_t w;
         if (rounds_in_lds) w = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rounds[r]);
         else w = (uint32_t)__builtin_amdgcn_readfirstlane((int)tstream[r]);
-        const int cnt = w & 1023u, type = (w >> 10) & 3u;
+        const int cnt = w & 1023u, type = (w >> 10) & 7u;
         if (type == 3) {
             // velocity update of the substep that just finished + integrate of the next one (SPEC.md §2)
 #pragma unroll
@@ -310,7 +320,7 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
                     }
                 }
         } else {
-            const uint32_t size = type == 0 ? ((2u * cnt + 3u) & ~3u) : 4u * cnt;
+            const uint32_t size = type == 0 ? ((2u * cnt + 3u) & ~3u) : (type == 4 ? ((cnt + 3u) & ~3u) : 4u * cnt);
             if (off + size > win_lo + win || off < win_lo) {   // refill the window (uniform; rare for small tiles)
                 lds_barrier();
                 win_lo = off;
@@ -328,6 +338,19 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
                     lds_pos[i] = a; lds_pos[k] = b;
 #else
                     if (project_distance(a, b, __uint_as_float(e.y), tp.at_d)) { lds_pos[i] = a; lds_pos[k] = b; }
+#endif
+                }
+            } else if (type == 4) {
+                if (tid < cnt) {
+                    const uint32_t e = base[tid];
+                    const int i = e & 0xfffu, k = (e >> 12) & 0xfffu;
+                    const float L0 = s_pal[e >> 24];
+                    float4 a = lds_pos[i], b = lds_pos[k];
+#if defined(SB_ABLATE) && SB_ABLATE == 2
+                    a.x += L0; b.x -= tp.at_d;
+                    lds_pos[i] = a; lds_pos[k] = b;
+#else
+                    if (project_distance(a, b, L0, tp.at_d)) { lds_pos[i] = a; lds_pos[k] = b; }
 #endif
                 }
             } else if (QUADS) {

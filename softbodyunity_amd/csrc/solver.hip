@@ -71,7 +71,7 @@ struct DevTiling {
     int32_t n_tiles = 0;
     size_t lds_bytes = 0;
     int64_t n_slots = 0;         // constraint slots stored (cross + full)
-    int32_t max_local = 0, win_dwords = 4;
+    int32_t max_local = 0, win_dwords = 4, pal_dwords = 0;
     int32_t n_boundary = 0;      // T0 with world > 1: the first n_boundary tiles hold every particle some peer needs
     bool has_quads = false;
     DevBuf<sbk::TileDesc> tiles;
@@ -239,6 +239,7 @@ void build_device(sb_solver *s) {
         std::vector<uint32_t> stream;
         int32_t max_local = 0;
         uint32_t max_data = 4;
+        bool any_palette = false;
         auto fbits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
         for (size_t ci = 0; ci < LT.tile_ids.size(); ++ci) {
             const sbp::Tile &T = G.tiles[LT.tile_ids[ci]];
@@ -260,8 +261,27 @@ void build_device(sb_solver *s) {
                 throw std::runtime_error("tile constraint stream exceeds 2^32 dwords");
             td.s_begin = (uint32_t)stream.size();
             const size_t s0 = stream.size();
-            for (int32_t r = 0; r < T.n_rounds; ++r) stream.push_back(G.rounds[T.round_begin + r]);
+            // dictionary-code the rest lengths of this tile's distance constraints when few values repeat
+            std::vector<uint32_t> pal;
+            bool compact = !std::getenv("SB_NO_PALETTE") && T.d_end > T.d_begin;
+            if (compact) {
+                std::vector<uint32_t> vals;
+                vals.reserve((size_t)(T.d_end - T.d_begin));
+                for (int64_t k = T.d_begin; k < T.d_end; ++k) vals.push_back(fbits(s->dist_rest[G.t_dist_id[k]]));
+                std::sort(vals.begin(), vals.end());
+                vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
+                if ((int)vals.size() <= sbk::kMaxPalette && T.n_local <= 4096) pal = vals; else compact = false;
+            }
+            for (int32_t r = 0; r < T.n_rounds; ++r) {
+                uint32_t w = G.rounds[T.round_begin + r];
+                if (compact && ((w >> 10) & 7u) == 0) w |= 4u << 10;     // distance -> dictionary-coded distance
+                stream.push_back(w);
+            }
             while ((stream.size() - s0) & 3) stream.push_back(0);
+            td.n_pal = (int32_t)pal.size();
+            for (uint32_t v : pal) stream.push_back(v);
+            while ((stream.size() - s0) & 3) stream.push_back(0);
+            if (!pal.empty()) any_palette = true;
             td.s_hdr = (uint32_t)(stream.size() - s0);
             int64_t dk = T.d_begin, qk = T.q_begin;
             for (int32_t r = 0; r < T.n_rounds; ++r) {
@@ -271,8 +291,14 @@ void build_device(sb_solver *s) {
                 if (type == 3) continue;
                 if (type == 0) {
                     for (int k = 0; k < cnt; ++k, ++dk) {
-                        stream.push_back(G.t_dist[dk]);
-                        stream.push_back(fbits(s->dist_rest[G.t_dist_id[dk]]));
+                        const uint32_t idx = G.t_dist[dk], rb = fbits(s->dist_rest[G.t_dist_id[dk]]);
+                        if (compact) {
+                            const uint32_t pi = (uint32_t)(std::lower_bound(pal.begin(), pal.end(), rb) - pal.begin());
+                            stream.push_back((idx & 0xffffu) | ((idx >> 16) << 12) | (pi << 24));
+                        } else {
+                            stream.push_back(idx);
+                            stream.push_back(rb);
+                        }
                     }
                     while ((stream.size() - s0) & 3) stream.push_back(0);
                 } else {
@@ -294,7 +320,8 @@ void build_device(sb_solver *s) {
         D.max_local = std::max(max_local, 1);
         D.win_dwords = (int32_t)std::min<uint32_t>(max_data, 8192u);     // <= 32 KiB of LDS; >= one round (4 KiB)
         if (const char *e = std::getenv("SB_WIN_DWORDS")) D.win_dwords = std::max(1024, std::min(D.win_dwords, std::atoi(e)) & ~3);   // tuning experiments
-        D.lds_bytes = (size_t)D.max_local * sizeof(float4) + sbk::kMaxRoundsLds * 4 + (size_t)D.win_dwords * 4;
+        D.pal_dwords = any_palette ? sbk::kMaxPalette : 0;
+        D.lds_bytes = (size_t)D.max_local * sizeof(float4) + sbk::kMaxRoundsLds * 4 + (size_t)D.pal_dwords * 4 + (size_t)D.win_dwords * 4;
         D.n_slots = 0;
         for (size_t ci = 0; ci < LT.tile_ids.size(); ++ci) {
             const sbp::Tile &T = G.tiles[LT.tile_ids[ci]];
@@ -388,7 +415,7 @@ void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = 
     A.pos = s->d_pos.p; A.prev = s->d_prev.p; A.vel = s->d_vel.p;
     A.tiles = D.tiles.p; A.runs_overflow = D.runs_overflow.p; A.stream = D.stream.p;
     A.tp = s->d_tp.p;
-    A.max_local = D.max_local; A.win_dwords = D.win_dwords; A.tile_base = tile_begin;
+    A.max_local = D.max_local; A.win_dwords = D.win_dwords; A.tile_base = tile_begin; A.pal_dwords = D.pal_dwords;
     const dim3 grid(tile_end - tile_begin), block(sbk::kTileThreads);
     const bool small = D.max_local <= 2 * sbk::kTileThreads;   // every tile <= 512 particles
     if (D.has_quads) {
