@@ -366,7 +366,11 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
             }
             off += size;
         }
+#if defined(SB_ABLATE) && SB_ABLATE == 3   // timing experiment only (WRONG results): rounds without the workgroup barrier
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#else
         lds_barrier();
+#endif
     }
 #pragma unroll
     for (int m = 0; m < PPT; ++m)
