@@ -239,7 +239,8 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
     const bool rounds_in_lds = n_rounds_all <= kMaxRoundsLds;
     const uint32_t rw = tstream[min(tid, n_rounds_all - 1)];
     const int n_pal = td.n_pal;
-    const uint32_t palw = tstream[((n_rounds_all + 3) & ~3) + min(tid, max(n_pal, 1) - 1)];   // palette follows the round words
+    // palette follows the round words; lanes without an entry re-read round word 0 (always inside the tile's stream)
+    const uint32_t palw = tstream[tid < n_pal ? ((n_rounds_all + 3) & ~3) + tid : 0];
     constexpr int kW = 4;    // uint4 per lane in the first sweep of the window (16 KiB); longer windows loop below
     const uint32_t n4_first = (min(win_lo + win, d_hi) - win_lo) >> 2;
     const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(tstream + win_lo);
@@ -247,7 +248,8 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
 #pragma unroll
     for (int q = 0; q < kW; ++q) {
         const uint32_t i = tid + q * kTileThreads;
-        wv[q] = wsrc[i < n4_first ? i : 0u];
+        // idle lanes read the first 16 bytes of the tile's stream (its round words: always present and aligned)
+        wv[q] = i < n4_first ? wsrc[i] : *reinterpret_cast<const u32x4 *>(tstream);
     }
     // One common use of every loaded value: the scheduler cannot sink a load below it, so all loads are issued
     // first and a single wait follows (left alone it emits load, wait, LDS write, load, wait, ... to save registers).
