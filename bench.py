@@ -66,8 +66,12 @@ def main():
     dist = None
     if world > 1:
         import torch.distributed as dist
+        import datetime
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world, timeout=datetime.timedelta(seconds=900))
+    # a launcher may expose all GPUs to every rank (use LOCAL_RANK) or exactly one per rank (use 0)
+    n_dev = torch.cuda.device_count()
+    device = local_rank if (n_dev == 0 or local_rank < n_dev) else local_rank % n_dev
 
     from softbodyunity_amd import Softbody, comm_unique_id, jelly_cube
 
@@ -89,7 +93,7 @@ def main():
         os.environ["SB_TEST_LOOPBACK"] = "1"
         sb_world = args.loopback_world
         uid = comm_unique_id()
-    sb = Softbody(mesh, substeps=args.substeps, fixed_delta_time=dt, device=local_rank, rank=rank, world=sb_world,
+    sb = Softbody(mesh, substeps=args.substeps, fixed_delta_time=dt, device=device, rank=rank, world=sb_world,
                   tile_particles=args.tile, use_graph=not args.no_graph, unique_id=uid).Start()
     stats = sb.stats()
     setup_s = time.time() - t_setup
