@@ -238,6 +238,10 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
     }
     const bool rounds_in_lds = n_rounds_all <= kMaxRoundsLds;
     const uint32_t rw = tstream[min(tid, n_rounds_all - 1)];
+    // programs of at most 64 rounds: every wave also keeps round word `lane` in a register and reads it back with
+    // v_readlane (no LDS round trip at the head of each round): +3 % at 64^3, +1 % at 256^3
+    const bool rounds_in_lanes = n_rounds_all <= 64;
+    const uint32_t rwl = tstream[min(tid & 63, n_rounds_all - 1)];
     const int n_pal = td.n_pal;
     // palette follows the round words; lanes without an entry re-read round word 0 (always inside the tile's stream)
     const uint32_t palw = tstream[tid < n_pal ? ((n_rounds_all + 3) & ~3) + tid : 0];
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
     for (int m = 0; m < PPT; ++m) asm volatile("" ::"v"(X[m].x), "v"(pvx[m]));
 #pragma unroll
     for (int q = 0; q < kW; ++q) asm volatile("" ::"v"(wv[q].x));
-    asm volatile("" ::"v"(rw), "v"(palw));
+    asm volatile("" ::"v"(rw), "v"(palw), "v"(rwl));
 #pragma unroll
     for (int m = 0; m < PPT; ++m)
         if (g[m] >= 0) *reinterpret_cast<f32x4 *>(lds_pos + tid + m * kTileThreads) = X[m];
@@ -281,7 +285,8 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
     for (int r = r_begin; r < r_end; ++r) {
 #endif
         uint32_t w;
-        if (rounds_in_lds) w = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rounds[r]);
+        if (rounds_in_lanes) w = (uint32_t)__builtin_amdgcn_readlane((int)rwl, __builtin_amdgcn_readfirstlane(r));
+        else if (rounds_in_lds) w = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rounds[r]);
         else w = (uint32_t)__builtin_amdgcn_readfirstlane((int)tstream[r]);
         const int cnt = w & 1023u, type = (w >> 10) & 7u;
         if (type == 3) {
