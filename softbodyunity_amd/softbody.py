@@ -48,6 +48,14 @@ class Softbody:
         h = C.c_void_p()
         check(L.sb_create(C.byref(d), C.byref(h)))
         self._h = h
+        try:
+            self._author(L, h)
+        except Exception:
+            self.OnDestroy()      # do not leak the handle when authoring / finalize fails
+            raise
+        return self
+
+    def _author(self, L, h):
         m = self.mesh
         pos = f32(m.pos, (-1, 3)); vel = f32(m.vel, (-1, 3)); w = f32(m.inv_mass, (-1,))
         self.n = pos.shape[0]
@@ -72,7 +80,6 @@ class Softbody:
             check(L.sb_set_ground_plane(h, *[float(c) for c in self.ground_plane], 1))
         check(L.sb_finalize(h))
         self.vertices = pos.copy()
-        return self
 
     def FixedUpdate(self, readback=True):
         check(native.lib().sb_step(self._h, self.fixed_delta_time, self.substeps))
