@@ -143,14 +143,16 @@ def main():
         names += [f"global colour {c}" for c in range(G)]
         names += ["tile_kernel<0> (first kernel of a tick)", "tile_kernel<2> (last kernel of a tick)"]
         # ALGORITHMIC bytes per launch: a mid-tick tile kernel does one velocity update (36 B)
-        # + one integrate (52 B) per particle and 68 B per constraint slot it stores (cross + full parts)
-        alg_bytes = [88.0 * owned + 68.0 * stats["tile_constraints"][t] for t in (0, 1)]
+        # + one integrate (52 B) per particle and projects every constraint it stores TWICE (before and after
+        # the MARK step: the tail of one substep and the head of the next), 68 B each time
+        alg_bytes = [88.0 * owned + 2 * 68.0 * stats["tile_constraints"][t] for t in (0, 1)]
         mask0 = None
         for c in range(G):
             if mask0 is None:
                 plan = sb.plan(); mask0 = plan.local_order_mask(0).astype(bool); ph0 = [p for p in plan.phases(0) if p["kind"] == 0]
             alg_bytes.append(68.0 * int(mask0[ph0[c]["order_begin"]:ph0[c]["order_end"]].sum()))
-        alg_bytes += [52.0 * owned + 68.0 * stats["tile_constraints"][0], 36.0 * owned + 68.0 * stats["tile_constraints"][0]]
+        last = (args.substeps & 1) if stats["n_tilings"] == 2 else 0
+        alg_bytes += [52.0 * owned + 68.0 * stats["tile_constraints"][0], 36.0 * owned + 68.0 * stats["tile_constraints"][last]]
         k_dom = int(np.argmax(slot_ms))
         launches = max(int(slot_cnt[k_dom]), 1)
         dom_ms = float(slot_ms[k_dom]) / launches
@@ -180,8 +182,8 @@ def main():
                          "algorithmic_bytes_per_launch": alg_bytes[k_dom],
                          "traffic_GBps": (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
                          "frac_traffic": (traffic / (dom_ms * 1e-3) / HBM_PEAK) if traffic else None,
-                         "note": "achieved/frac use ALGORITHMIC bytes (SURVEY 8d: 88 B/particle + 68 B/constraint per mid-tick "
-                                 "launch); the tile kernel keeps positions in LDS across ~3.6 algorithmic passes, so frac > 1 "
+                         "note": "achieved/frac use ALGORITHMIC bytes (SURVEY 8d: 88 B/particle + 68 B per projected constraint per "
+                                 "mid-tick launch); the tile kernel keeps positions in LDS across ~3.6 algorithmic passes, so frac > 1 "
                                  "is on-chip reuse, not a measurement error: traffic (PMC FETCH/WRITE_SIZE) and frac_traffic "
                                  "give the HBM side",
                          "job_algorithmic_GBps": job_alg / 1e9, "job_frac": job_alg / (HBM_PEAK * world),

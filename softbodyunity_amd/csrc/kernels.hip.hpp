@@ -19,19 +19,18 @@ struct TickParams {           // SPEC.md §2 host-side scalars, uploaded once pe
 
 // One LDS tile = one workgroup. 128 B, read with scalar loads.
 // The tile's constraint stream lives at stream[s_begin ...], 16-byte aligned, in dwords:
-//   [round words, padded to 4] [rest-length palette, padded to 4] [cross rounds' data] [full rounds' data]
-// round word: bits 0-9 count, bits 10-12 type (0 distance, 1 volume, 2 bending, 3 = velocity/integrate marker,
-// 4 = distance, dictionary-coded);
+//   [round words, padded to 4] [rest-length palette, padded to 4] [rounds' data]
+// round word: bits 0-9 count, bits 10-12 type (0 distance, 1 volume, 2 bending, 4 = distance, dictionary-coded);
 // a distance round stores count x {i | j<<16, rest length} (padded to 4 dwords); when a tile's distance
 // constraints use at most 256 distinct rest lengths (regular meshes) they are dictionary-coded instead:
 // count x {i | j<<12 | palette index<<24} (one dword each) with the values in the tile's palette;
-// a 4-vertex round stores count x {i0|i1<<16, i2|i3<<16, rest.x, rest.y}; the marker stores nothing.
+// a 4-vertex round stores count x {i0|i1<<16, i2|i3<<16, rest.x, rest.y}.
 struct TileDesc {
-    int32_t n_local, run_count, n_pre, n_rounds;   // n_rounds = cross rounds + marker + full rounds
+    int32_t n_local, run_count, n_rounds, pad0;
     uint32_t s_begin;          // dword offset of the tile's stream
-    uint32_t s_hdr;            // dwords of round words + palette (each padded to 4): cross data starts at s_begin + s_hdr
-    uint32_t s_mid;            // dword offset (from s_begin) of the full part's data
+    uint32_t s_hdr;            // dwords of round words + palette (each padded to 4): round data starts at s_begin + s_hdr
     uint32_t s_len;            // total dwords (multiple of 4)
+    uint32_t pad3;
     int32_t run_overflow;      // runs beyond kInlineRuns live at runs_overflow[run_overflow ...]
     int32_t n_pal;             // palette entries (0 = no dictionary coding), stored after the round words
     int32_t pad1, pad2;
@@ -154,11 +153,11 @@ __device__ __forceinline__ bool project_bending(float4 &pa, float4 &pb, float4 &
     return true;
 }
 
-// One workgroup = one tile. The tile's program is [cross rounds..., MARK, full rounds...] (plan.hpp):
-//   KIND 0 (first kernel of a tick)  : starts at MARK: v from the velocity array, integrate, full rounds
-//   KIND 1 (every other substep)     : cross rounds (finish substep s-1), MARK: v = (x-xprev)/h, integrate
-//                                      (start substep s), full rounds
-//   KIND 2 (after the last substep)  : cross rounds, MARK: write v, stop
+// One workgroup = one tile; a tile owns one constraint list, cut into rounds of independent constraints (plan.hpp):
+//   KIND 0 (first kernel of a tick)  : MARK: v from the velocity array, integrate; the tile's rounds
+//   KIND 1 (every other substep)     : the tile's rounds (finish substep s-1), MARK: v = (x-xprev)/h, integrate
+//                                      (start substep s), the same rounds again
+//   KIND 2 (after the last substep)  : the tile's rounds, MARK: write v, stop
 // Particles AND the tile's constraint stream are staged in LDS with wide coalesced loads issued together,
 // so a tile pays the HBM latency once; rounds then run LDS-to-LDS with one barrier each. Each lane keeps
 // ownership of up to PPT particles for the MARK step. QUADS = the tiling stores 4-vertex rounds.
@@ -202,10 +201,12 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
         g[m] = gi;
     }
     // ---- the stretch of the stream this kernel needs, staged through an LDS window -----------------
-    const int r_begin = KIND == 0 ? td.n_pre : 0;
-    const int r_end = KIND == 2 ? td.n_pre + 1 : n_rounds_all;
-    const uint32_t d_lo = KIND == 0 ? td.s_mid : td.s_hdr;
-    const uint32_t d_hi = KIND == 2 ? td.s_mid : td.s_len;
+    // virtual program: rounds 0..R-1 (finish the previous substep), MARK, rounds 0..R-1 again (start the next)
+    const int R = n_rounds_all;
+    const int v_begin = KIND == 0 ? R : 0;
+    const int v_end = KIND == 2 ? R + 1 : 2 * R + 1;
+    const uint32_t d_lo = td.s_hdr;
+    const uint32_t d_hi = td.s_len;
     const uint32_t win = (uint32_t)A.win_dwords;
     uint32_t win_lo = d_lo;
     auto load_window = [&](uint32_t lo) {
@@ -237,11 +238,11 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
         if (KIND != 0) { pvx[m] = A.prev[3 * (size_t)gc + 0]; pvy[m] = A.prev[3 * (size_t)gc + 1]; pvz[m] = A.prev[3 * (size_t)gc + 2]; }
     }
     const bool rounds_in_lds = n_rounds_all <= kMaxRoundsLds;
-    const uint32_t rw = tstream[min(tid, n_rounds_all - 1)];
+    const uint32_t rw = tstream[max(min(tid, n_rounds_all - 1), 0)];        // (an empty program still has a 16-byte header)
     // programs of at most 64 rounds: every wave also keeps round word `lane` in a register and reads it back with
     // v_readlane (no LDS round trip at the head of each round): +3 % at 64^3, +1 % at 256^3
     const bool rounds_in_lanes = n_rounds_all <= 64;
-    const uint32_t rwl = tstream[min(tid & 63, n_rounds_all - 1)];
+    const uint32_t rwl = tstream[max(min(tid & 63, n_rounds_all - 1), 0)];
     const int n_pal = td.n_pal;
     // palette follows the round words; lanes without an entry re-read round word 0 (always inside the tile's stream)
     const uint32_t palw = tstream[tid < n_pal ? ((n_rounds_all + 3) & ~3) + tid : 0];
@@ -280,14 +281,18 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
 
     uint32_t off = d_lo;    // dword offset (from the tile's stream start) of the current round's data
 #if defined(SB_ABLATE) && SB_ABLATE == 1   // timing experiment only: memory traffic without the rounds
-    for (int r = r_begin; r < r_end; r += 1000) {
+    for (int v = v_begin; v < v_end; v += 100000) {
 #else
-    for (int r = r_begin; r < r_end; ++r) {
+    for (int v = v_begin; v < v_end; ++v) {
 #endif
-        uint32_t w;
-        if (rounds_in_lanes) w = (uint32_t)__builtin_amdgcn_readlane((int)rwl, __builtin_amdgcn_readfirstlane(r));
-        else if (rounds_in_lds) w = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rounds[r]);
-        else w = (uint32_t)__builtin_amdgcn_readfirstlane((int)tstream[r]);
+        const int r = v < R ? v : v - R - 1;
+        if (v == R + 1) off = d_lo;          // the second pass walks the same list again
+        uint32_t w = 3u << 10;               // v == R: the MARK step
+        if (v != R) {
+            if (rounds_in_lanes) w = (uint32_t)__builtin_amdgcn_readlane((int)rwl, __builtin_amdgcn_readfirstlane(r));
+            else if (rounds_in_lds) w = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rounds[r]);
+            else w = (uint32_t)__builtin_amdgcn_readfirstlane((int)tstream[r]);
+        }
         const int cnt = w & 1023u, type = (w >> 10) & 7u;
         if (type == 3) {
             // velocity update of the substep that just finished + integrate of the next one (SPEC.md §2)

@@ -180,6 +180,11 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         nc[a] = (int)std::floor((hi[a] - org[a]) / cs) + 1;
     }
     if ((int64_t)nc[0] * nc[1] * nc[2] > (int64_t)1 << 40) throw std::runtime_error("grid too large");
+    // T1 = T0 shifted by an ODD number of mean spring lengths close to half a cell (kk is even): on a lattice the
+    // springs that cross a T0 boundary and those that cross a T1 boundary then belong to different parity classes,
+    // so each class is a complete matching inside one of the two tilings (see the static split below)
+    const int shift_units = ((kk / 2) & 1) ? kk / 2 : std::max(kk / 2 - 1, 1);
+    const double shift_frac = (double)shift_units / kk;
     std::vector<int64_t> cell(n), scell(n);
     P.owner_of_old.resize(n);
     for (int32_t p = 0; p < n; ++p) {
@@ -187,7 +192,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         for (int a = 0; a < 3; ++a) {
             double r = (in.rest[3 * (int64_t)p + a] - org[a]) / cs;
             c[a] = std::min(std::max((int)std::floor(r), 0), nc[a] - 1);
-            s[a] = std::min(std::max((int)std::floor(r + 0.5), 0), nc[a]);
+            s[a] = std::min(std::max((int)std::floor(r - shift_frac) + 1, 0), nc[a]);
             blk[a] = (int)((int64_t)c[a] * P.dims[a] / nc[a]);
         }
         cell[p] = ((int64_t)c[2] * nc[1] + c[1]) * nc[0] + c[0];
@@ -327,88 +332,139 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         }
     }
 
-    // ---- tile programs ---------------------------------------------------------------------------
-    // seq[tl][part] = (type,id) in execution order, part 0 = cross, 1 = full; tile slices recorded in the tiles
-    std::vector<uint8_t> seq_type[2][2];
-    std::vector<int32_t> seq_id[2][2];
-    std::vector<int64_t> seq_groups[2][2];   // group boundaries (end offsets) inside seq
+    // ---- static split: S0 (run on T0 tiles) / S1 (run on T1 tiles) -------------------------------
+    // own[t][k]: 0 -> S0, 1 -> S1, 2 -> global colours. Constraints inside only one tiling have no choice. The ones
+    // inside both are labelled by alternating propagation: within one type and one direction bucket (distance
+    // constraints: the dominant axis of the rest-pose edge), a free constraint that shares a particle with a
+    // labelled one gets the opposite label, breadth first from the forced ones. Along a lattice row this alternates
+    // S0/S1 spring by spring (the odd grid shift makes the forced springs of the two tilings agree with it), so each
+    // side is a set of complete matchings; on irregular meshes it halves the constraint degree of every particle
+    // per side, i.e. the number of rounds per tile.
+    std::vector<uint8_t> own[3];
     std::vector<Mask128> used((size_t)kMaxTileLocal);
     std::vector<int> col_tmp;
     std::vector<int32_t> lv;
+    for (int t = 0; t < 3; ++t) {
+        own[t].assign(C.count(t), 2);
+        if (!tiling) continue;
+        const int nv = kVerts[t];
+        const int64_t M = C.count(t);
+        if (M == 0) continue;
+        const int n_buckets = t == 0 ? 3 : 1;
+        std::vector<uint8_t> bucket(M, 0);
+        std::vector<int8_t> label(M, -2);        // -2: not tiled (global), -1: free, 0/1: assigned
+        for (int64_t k = 0; k < M; ++k) {
+            const uint8_t c = cls[t][k];
+            if (c == 0) continue;
+            label[k] = c == 3 ? -1 : (c == 1 ? 0 : 1);
+            if (t == 0) {
+                const int32_t *v = C.idx(t, k);
+                double best = -1; int ba = 0;
+                for (int a = 0; a < 3; ++a) {
+                    double d = std::fabs((double)in.rest[3 * (int64_t)v[0] + a] - in.rest[3 * (int64_t)v[1] + a]);
+                    if (d > best * (1 + 1e-9)) { best = d; ba = a; }
+                }
+                bucket[k] = (uint8_t)ba;
+            }
+        }
+        std::vector<int64_t> inc_off((size_t)n + 1);
+        std::vector<int32_t> inc, queue;
+        for (int b = 0; b < n_buckets; ++b) {
+            std::fill(inc_off.begin(), inc_off.end(), 0);
+            for (int64_t k = 0; k < M; ++k) if (label[k] != -2 && bucket[k] == b) for (int a = 0; a < nv; ++a) ++inc_off[C.idx(t, k)[a] + 1];
+            for (int32_t p = 0; p < n; ++p) inc_off[p + 1] += inc_off[p];
+            inc.resize(inc_off[n]);
+            {
+                std::vector<int64_t> cur(inc_off.begin(), inc_off.end() - 1);
+                for (int64_t k = 0; k < M; ++k) if (label[k] != -2 && bucket[k] == b) for (int a = 0; a < nv; ++a) inc[cur[C.idx(t, k)[a]]++] = (int32_t)k;
+            }
+            queue.clear();
+            for (int64_t k = 0; k < M; ++k) if (label[k] >= 0 && bucket[k] == b) queue.push_back((int32_t)k);
+            size_t head = 0;
+            int64_t next_seed = 0;
+            for (;;) {
+                while (head < queue.size()) {
+                    const int32_t c = queue[head++];
+                    const int32_t *v = C.idx(t, c);
+                    for (int a = 0; a < nv; ++a)
+                        for (int64_t q = inc_off[v[a]]; q < inc_off[v[a] + 1]; ++q) {
+                            const int32_t c2 = inc[q];
+                            if (label[c2] == -1) { label[c2] = (int8_t)(1 - label[c]); queue.push_back(c2); }
+                        }
+                }
+                // components without a forced member: seed the lowest unlabelled constraint with S0
+                while (next_seed < M && !(label[next_seed] == -1 && bucket[next_seed] == b)) ++next_seed;
+                if (next_seed == M) break;
+                label[next_seed] = 0;
+                queue.push_back((int32_t)next_seed);
+            }
+        }
+        for (int64_t k = 0; k < M; ++k) if (label[k] >= 0) own[t][k] = (uint8_t)label[k];
+    }
+
+    // ---- tile programs ---------------------------------------------------------------------------
+    // seq[tl] = (type,id) of S_tl in execution order; tile slices recorded in the tiles
+    std::vector<uint8_t> seq_type[2];
+    std::vector<int32_t> seq_id[2];
+    std::vector<int64_t> seq_groups[2];   // group boundaries (end offsets) inside seq
     for (int tl = 0; tl < 2; ++tl) {
         if (n_tiles[tl] == 0) continue;
         Tiling &TT = P.T[tl];
         const std::vector<int32_t> &tof = *tile_of[tl];
-        const uint8_t in_bit = tl == 0 ? 1 : 2, other_bit = tl == 0 ? 2 : 1;
-        // bucket by tile: part 0 (cross) = inside this tiling but not the other; part 1 (full) = inside this tiling
-        std::vector<int64_t> off[2][3];
-        std::vector<int32_t> lst[2][3];
-        for (int part = 0; part < 2; ++part)
-            for (int t = 0; t < 3; ++t) {
-                auto want = [&](int64_t k) {
-                    uint8_t c = cls[t][k];
-                    return part == 1 ? (c & in_bit) != 0 : ((c & in_bit) != 0 && (c & other_bit) == 0);
-                };
-                auto &o = off[part][t];
-                o.assign((size_t)n_tiles[tl] + 1, 0);
-                for (int64_t k = 0; k < C.count(t); ++k) if (want(k)) ++o[tof[C.idx(t, k)[0]] + 1];
-                for (int32_t c = 0; c < n_tiles[tl]; ++c) o[c + 1] += o[c];
-                lst[part][t].resize(o[n_tiles[tl]]);
-                std::vector<int64_t> cur(o.begin(), o.end() - 1);
-                for (int64_t k = 0; k < C.count(t); ++k) if (want(k)) lst[part][t][cur[tof[C.idx(t, k)[0]]]++] = (int32_t)k;
-            }
+        std::vector<int64_t> off[3];
+        std::vector<int32_t> lst[3];
+        for (int t = 0; t < 3; ++t) {
+            auto &o = off[t];
+            o.assign((size_t)n_tiles[tl] + 1, 0);
+            for (int64_t k = 0; k < C.count(t); ++k) if (own[t][k] == tl) ++o[tof[C.idx(t, k)[0]] + 1];
+            for (int32_t c = 0; c < n_tiles[tl]; ++c) o[c + 1] += o[c];
+            lst[t].resize(o[n_tiles[tl]]);
+            std::vector<int64_t> cur(o.begin(), o.end() - 1);
+            for (int64_t k = 0; k < C.count(t); ++k) if (own[t][k] == tl) lst[t][cur[tof[C.idx(t, k)[0]]]++] = (int32_t)k;
+        }
         for (int32_t c = 0; c < n_tiles[tl]; ++c) {
             Tile &tile = TT.tiles[c];
             tile.round_begin = (int32_t)TT.rounds.size();
             tile.d_begin = (int64_t)TT.t_dist.size(); tile.q_begin = (int64_t)TT.t_quad_id.size();
-            for (int part = 0; part < 2; ++part) {
-                if (part == 1) {
-                    tile.n_pre = (int32_t)TT.rounds.size() - tile.round_begin;
-                    TT.rounds.push_back(kRoundMark);
-                    tile.d_mid = (int64_t)TT.t_dist.size(); tile.q_mid = (int64_t)TT.t_quad_id.size();
+            tile.seq_begin = (int64_t)seq_id[tl].size();
+            for (int t = 0; t < 3; ++t) {
+                const int32_t *it = lst[t].data() + off[t][c];
+                const int64_t cnt = off[t][c + 1] - off[t][c];
+                if (cnt == 0) continue;
+                const int nv = kVerts[t];
+                lv.resize((size_t)cnt * nv);
+                for (int64_t k = 0; k < cnt; ++k) {
+                    const int32_t *v = C.idx(t, it[k]);
+                    for (int a = 0; a < nv; ++a) lv[k * nv + a] = lidx[tl][P.new_of_old[v[a]]];
                 }
-                int64_t &ob = part == 0 ? tile.cross_order_begin : tile.full_order_begin;
-                int64_t &oe = part == 0 ? tile.cross_order_end : tile.full_order_end;
-                ob = (int64_t)seq_id[tl][part].size();
-                for (int t = 0; t < 3; ++t) {
-                    const int32_t *it = lst[part][t].data() + off[part][t][c];
-                    const int64_t cnt = off[part][t][c + 1] - off[part][t][c];
-                    if (cnt == 0) continue;
-                    const int nv = kVerts[t];
-                    lv.resize((size_t)cnt * nv);
-                    for (int64_t k = 0; k < cnt; ++k) {
-                        const int32_t *v = C.idx(t, it[k]);
-                        for (int a = 0; a < nv; ++a) lv[k * nv + a] = lidx[tl][P.new_of_old[v[a]]];
-                    }
-                    int ncol = greedy_colour(cnt, nv, [&](int64_t k) { return lv.data() + (size_t)k * nv; }, used, col_tmp);
-                    if (ncol < 0) throw std::runtime_error("a tile needs more than 128 colours (particle valence too high)");
-                    std::vector<std::vector<int32_t>> by(ncol);
-                    for (int64_t k = 0; k < cnt; ++k) by[col_tmp[k]].push_back((int32_t)k);
-                    for (auto &colv : by) {
-                        for (size_t s0 = 0; s0 < colv.size(); s0 += kRoundThreads) {
-                            size_t s1 = std::min(colv.size(), s0 + kRoundThreads);
-                            TT.rounds.push_back((uint32_t)(s1 - s0) | ((uint32_t)t << 10));
-                            for (size_t q = s0; q < s1; ++q) {
-                                const int32_t k = colv[q];
-                                const int32_t *l = lv.data() + (size_t)k * nv;
-                                if (t == 0) {
-                                    TT.t_dist.push_back((uint32_t)l[0] | ((uint32_t)l[1] << 16));
-                                    TT.t_dist_id.push_back(it[k]);
-                                } else {
-                                    TT.t_quad.push_back((uint32_t)l[0] | ((uint32_t)l[1] << 16));
-                                    TT.t_quad.push_back((uint32_t)l[2] | ((uint32_t)l[3] << 16));
-                                    TT.t_quad_id.push_back(it[k]);
-                                    TT.t_quad_type.push_back((uint8_t)t);
-                                }
-                                seq_type[tl][part].push_back((uint8_t)t);
-                                seq_id[tl][part].push_back(it[k]);
+                int ncol = greedy_colour(cnt, nv, [&](int64_t k) { return lv.data() + (size_t)k * nv; }, used, col_tmp);
+                if (ncol < 0) throw std::runtime_error("a tile needs more than 128 colours (particle valence too high)");
+                std::vector<std::vector<int32_t>> by(ncol);
+                for (int64_t k = 0; k < cnt; ++k) by[col_tmp[k]].push_back((int32_t)k);
+                for (auto &colv : by) {
+                    for (size_t s0 = 0; s0 < colv.size(); s0 += kRoundThreads) {
+                        size_t s1 = std::min(colv.size(), s0 + kRoundThreads);
+                        TT.rounds.push_back((uint32_t)(s1 - s0) | ((uint32_t)t << 10));
+                        for (size_t q = s0; q < s1; ++q) {
+                            const int32_t k = colv[q];
+                            const int32_t *l = lv.data() + (size_t)k * nv;
+                            if (t == 0) {
+                                TT.t_dist.push_back((uint32_t)l[0] | ((uint32_t)l[1] << 16));
+                                TT.t_dist_id.push_back(it[k]);
+                            } else {
+                                TT.t_quad.push_back((uint32_t)l[0] | ((uint32_t)l[1] << 16));
+                                TT.t_quad.push_back((uint32_t)l[2] | ((uint32_t)l[3] << 16));
+                                TT.t_quad_id.push_back(it[k]);
+                                TT.t_quad_type.push_back((uint8_t)t);
                             }
-                            seq_groups[tl][part].push_back((int64_t)seq_id[tl][part].size());
+                            seq_type[tl].push_back((uint8_t)t);
+                            seq_id[tl].push_back(it[k]);
                         }
+                        seq_groups[tl].push_back((int64_t)seq_id[tl].size());
                     }
                 }
-                oe = (int64_t)seq_id[tl][part].size();
             }
+            tile.seq_end = (int64_t)seq_id[tl].size();
             tile.n_rounds = (int32_t)TT.rounds.size() - tile.round_begin;
             tile.d_end = (int64_t)TT.t_dist.size(); tile.q_end = (int64_t)TT.t_quad_id.size();
         }
@@ -421,7 +477,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         std::vector<int> colr;
         for (int t = 0; t < 3; ++t) {
             left.clear();
-            for (int64_t k = 0; k < C.count(t); ++k) if (cls[t][k] == 0) left.push_back((int32_t)k);
+            for (int64_t k = 0; k < C.count(t); ++k) if (own[t][k] == 2) left.push_back((int32_t)k);
             if (left.empty()) continue;
             if (gused.empty()) gused.assign(n, Mask128());
             const int nv = kVerts[t];
@@ -442,31 +498,27 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
     P.cons_in_tiles = P.m[0] + P.m[1] + P.m[2] - P.cons_in_global;
 
     // ---- published orders per parity --------------------------------------------------------------
+    // parity p: S_p on the tiles of T_p, the global colours, S_(1-p) on the tiles of T_(1-p)
     for (int p = 0; p < 2; ++p) {
         auto &ot = P.order_type[p]; auto &oi = P.order_id[p];
         auto &tasks = P.task_off[p]; auto &groups = P.group_off[p];
         tasks.push_back(0); groups.push_back(0);
-        const int tf = tiling ? p : 0;           // tiling whose tiles run their full part
-        const int tc = tiling ? 1 - p : -1;      // tiling whose tiles run their cross part
-        auto append_tiles = [&](int tl, int part, int kind) {
+        auto append_tiles = [&](int tl, int kind) {
             Phase ph; ph.kind = kind; ph.type = -1; ph.tiling = tl; ph.gcolour = -1; ph.halo_slot = -1;
             ph.order_begin = (int64_t)oi.size(); ph.task_begin = (int64_t)tasks.size() - 1;
             const int64_t base = (int64_t)oi.size();
-            ot.insert(ot.end(), seq_type[tl][part].begin(), seq_type[tl][part].end());
-            oi.insert(oi.end(), seq_id[tl][part].begin(), seq_id[tl][part].end());
-            for (int64_t g : seq_groups[tl][part]) groups.push_back(base + g);
+            ot.insert(ot.end(), seq_type[tl].begin(), seq_type[tl].end());
+            oi.insert(oi.end(), seq_id[tl].begin(), seq_id[tl].end());
+            for (int64_t g : seq_groups[tl]) groups.push_back(base + g);
             for (Tile &tile : P.T[tl].tiles) {
-                int64_t &b = part == 0 ? tile.cross_order_begin : tile.full_order_begin;
-                int64_t &e = part == 0 ? tile.cross_order_end : tile.full_order_end;
-                if (e > b) tasks.push_back(base + e);
-                // rebase tile slices to the published order (done once: slices of parity `p` order)
-                b += base; e += base;
+                tile.order_begin[p] = base + tile.seq_begin; tile.order_end[p] = base + tile.seq_end;
+                if (tile.seq_end > tile.seq_begin) tasks.push_back(base + tile.seq_end);
             }
             ph.order_end = (int64_t)oi.size(); ph.task_end = (int64_t)tasks.size() - 1;
             if (ph.order_end > ph.order_begin) P.phases[p].push_back(ph);
         };
-        // full part of tiling tf lives in order[tf]; cross part of tiling tc lives in order[1-tc] = order[p]
-        if (!P.T[tf].tiles.empty() && (tiling || p == 0)) append_tiles(tf, 1, 1);
+        const int first = tiling ? p : 0;
+        if (!P.T[first].tiles.empty()) append_tiles(first, 1);
         for (size_t gc = 0; gc < P.gcolours.size(); ++gc) {
             const GColour &g = P.gcolours[gc];
             Phase ph; ph.kind = 0; ph.type = g.type; ph.tiling = -1; ph.gcolour = (int)gc;
@@ -481,7 +533,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
             ph.order_end = (int64_t)oi.size(); ph.task_end = (int64_t)tasks.size() - 1;
             P.phases[p].push_back(ph);
         }
-        if (tc >= 0 && !P.T[tc].tiles.empty()) append_tiles(tc, 0, 2);
+        if (tiling && !P.T[1 - p].tiles.empty()) append_tiles(1 - p, 2);
         if ((int64_t)oi.size() != P.m[0] + P.m[1] + P.m[2]) throw std::runtime_error("planner lost constraints");
     }
     // halo slot 1: T1 tiles with more than one owner need ghosts (positions and previous positions)
@@ -490,7 +542,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         for (const Tile &t : P.T[1].tiles) multi |= t.owner < 0;
         if (multi)
             for (int p = 0; p < 2; ++p)
-                for (Phase &ph : P.phases[p]) if (ph.kind != 0 && ph.tiling == 1 && ph.kind == 2) ph.halo_slot = 1;
+                for (Phase &ph : P.phases[p]) if (ph.kind != 0 && ph.tiling == 1) ph.halo_slot = 1;
     }
 }
 
@@ -539,9 +591,8 @@ void extract_local(const Plan &P, const Input &in, int rank, LocalPlan &L) {
             }
             if (!mine) continue;
             L.T[tl].tile_ids.push_back(c);
-            // full part is in order[tl], cross part in order[1-tl]
-            for (int64_t k = tile.full_order_begin; k < tile.full_order_end; ++k) L.order_mask[tl][k] = 1;
-            for (int64_t k = tile.cross_order_begin; k < tile.cross_order_end; ++k) L.order_mask[1 - tl][k] = 1;
+            for (int p = 0; p < 2; ++p)
+                for (int64_t k = tile.order_begin[p]; k < tile.order_end[p]; ++k) L.order_mask[p][k] = 1;
         }
     }
     // global colours: executed by every rank that owns one of the constraint's particles

@@ -1,21 +1,21 @@
 // plan.hpp — host-side planner: tiles, colours, partition, halo schedule (pure C++, no HIP).
 //
 // No reference counterpart exists (/root/reference/README.md:1 is the whole reference tree); the
-// planner implements SPEC.md §3 and DESIGN.md §3 ("two-tiling alternating schedule"):
+// planner implements SPEC.md §3 and DESIGN.md §3 ("two tilings, static split"):
 //
 //   tiling T0 : cells of a uniform grid over the rest pose            (a partition of the particles)
-//   tiling T1 : cells of the same grid shifted by half a cell         (another partition)
-//   in0/in1   : a constraint is "inside" a tiling when all its particles share one of its tiles
+//   tiling T1 : cells of the same grid shifted by about half a cell   (another partition)
+//   S0 / S1   : a static split of the constraints: S0 is projected on the tiles of T0, S1 on the tiles of T1
+//               (a constraint can only go where all its particles share a tile; constraints inside both
+//               tilings are assigned so that colour classes stay whole and the two sides balance)
 //   G         : constraints inside neither tiling, greedy edge-coloured, one global kernel per colour
 //
 //   substep of parity p (0,1,0,1,... restarting at 0 every tick) projects, in this order,
-//     full(T_p)     = every constraint inside T_p,               tile by tile, colour by colour
-//     G             = the global colours
-//     cross(T_1-p)  = constraints inside T_1-p but not inside T_p, tile by tile, colour by colour
+//     S_p on T_p's tiles, then G, then S_(1-p) on T_(1-p)'s tiles       (tile by tile, round by round)
 //
-// cross(T_q) of one substep and full(T_q) of the next run on the same tiles, so the GPU fuses them
-// (with the per-particle velocity update + integrate between them) into ONE kernel per substep that
-// reads and writes every particle once. The flat sequential order equivalent to that execution is
+// S_q of one substep and S_q of the next are the same constraint list on the same tiles, so the GPU runs
+// them in ONE kernel with the per-particle velocity update + integrate between them: every particle and
+// every constraint word is read once per kernel. The flat sequential order equivalent to that execution is
 // published per parity for the oracle.
 #pragma once
 #include <cstdint>
@@ -36,7 +36,6 @@ struct Run {            // a contiguous range of particles
 };
 
 constexpr int kRoundThreads = 256;          // constraints per round (one per lane of a 256-thread workgroup)
-constexpr uint32_t kRoundMark = 3u << 10;   // round word: bits 0-9 count, bits 10-11 type (3 = velocity/integrate marker)
 constexpr int kMaxTileLocal = 1024;         // particles staged per tile (4 per lane)
 constexpr int kMaxTileRuns = 64;
 
@@ -44,14 +43,12 @@ struct Tile {
     int32_t owner;          // owning rank if all its particles have one owner, else -1
     int32_t run_begin, run_count;
     int32_t n_local;        // particles staged in LDS
-    int32_t round_begin;    // into Tiling::rounds: [cross rounds..., MARK, full rounds...]
-    int32_t n_pre;          // number of cross rounds (marker is at round_begin + n_pre)
-    int32_t n_rounds;       // including the marker
-    int64_t d_begin, q_begin;   // start of the cross part in the tiling's constraint arrays
-    int64_t d_mid, q_mid;       // start of the full part
+    int32_t round_begin;    // into Tiling::rounds: the rounds of the tile's constraint list
+    int32_t n_rounds;
+    int64_t d_begin, q_begin;   // the tile's constraints in the tiling's arrays
     int64_t d_end, q_end;
-    // slices of the published orders: cross part lives in order[1-t], full part in order[t]
-    int64_t cross_order_begin, cross_order_end, full_order_begin, full_order_end;
+    int64_t seq_begin, seq_end; // slice of the tiling's sequence
+    int64_t order_begin[2], order_end[2];   // slices of the two published orders
 };
 
 struct Tiling {

@@ -256,7 +256,7 @@ void build_device(sb_solver *s) {
             }
             if (lstart != T.n_local) throw std::runtime_error("internal: tile run lengths do not add up");
             max_local = std::max(max_local, T.n_local);
-            td.n_pre = T.n_pre; td.n_rounds = T.n_rounds;
+            td.n_rounds = T.n_rounds;
             if (stream.size() > 0xfffffff0ull - 4ull * (size_t)(T.d_end - T.d_begin + T.q_end - T.q_begin))
                 throw std::runtime_error("tile constraint stream exceeds 2^32 dwords");
             td.s_begin = (uint32_t)stream.size();
@@ -278,6 +278,7 @@ void build_device(sb_solver *s) {
                 stream.push_back(w);
             }
             while ((stream.size() - s0) & 3) stream.push_back(0);
+            if (stream.size() == s0) stream.insert(stream.end(), 4, 0u);   // empty program: keep 16 readable bytes
             td.n_pal = (int32_t)pal.size();
             for (uint32_t v : pal) stream.push_back(v);
             while ((stream.size() - s0) & 3) stream.push_back(0);
@@ -287,8 +288,6 @@ void build_device(sb_solver *s) {
             for (int32_t r = 0; r < T.n_rounds; ++r) {
                 const uint32_t w = G.rounds[T.round_begin + r];
                 const int cnt = w & 1023u, type = (w >> 10) & 3u;
-                if (r == T.n_pre) td.s_mid = (uint32_t)(stream.size() - s0);
-                if (type == 3) continue;
                 if (type == 0) {
                     for (int k = 0; k < cnt; ++k, ++dk) {
                         const uint32_t idx = G.t_dist[dk], rb = fbits(s->dist_rest[G.t_dist_id[dk]]);

@@ -47,14 +47,19 @@ def test_cube_64_structure():
     mesh = jelly_cube(64)
     plan = build_plan(mesh)
     p0, p1 = plan.phases(0), plan.phases(1)
-    # parity 0: full(T0) then cross(T1); parity 1: full(T1) then cross(T0); nothing left for global colours
+    # parity 0: S0 on T0's tiles then S1 on T1's tiles; parity 1: the other way round; nothing left for global colours
     assert [(p["kind"], p["tiling"]) for p in p0] == [(1, 0), (2, 1)]
     assert [(p["kind"], p["tiling"]) for p in p1] == [(1, 1), (2, 0)]
     assert p0[0]["task_end"] - p0[0]["task_begin"] == 512        # 8^3 aligned cells of 8^3 particles
-    assert p0[0]["order_end"] == 512 * 1344                      # all in-cell springs
     assert p1[0]["task_end"] - p1[0]["task_begin"] == 729        # 9^3 shifted cells
-    assert p1[1]["order_end"] - p1[1]["order_begin"] == 512 * 192  # springs over the mid-planes of aligned cells
+    n0 = p0[0]["order_end"] - p0[0]["order_begin"]
+    assert n0 == 512 * 768                                       # alternate springs of every row: three perfect matchings per tile
+    assert p1[1]["order_end"] - p1[1]["order_begin"] == n0       # the same set S0 in both parities
     assert p0[1]["order_end"] == 3 * 64 * 64 * 63 == p1[1]["order_end"]
+    t0, i0 = plan.order(0); t1, i1 = plan.order(1)
+    assert np.array_equal(np.sort(i0[:n0]), np.sort(i1[-n0:]))
+    g = np.diff(plan.groups(0))
+    assert (g[:512 * 3] == 256).all()                            # every T0 round is a full 256-lane matching
 
 
 def test_full_stencil_cube_uses_global_colours_and_stays_valid():
