@@ -129,7 +129,12 @@ struct sb_solver {
     std::vector<std::unique_ptr<DevHalo>> halos;   // indexed by halo slot
     sbk::TickParams tp_host{};
     bool tp_valid = false;
-    std::map<int, hipGraphExec_t> graphs;
+    std::map<int, hipGraphExec_t> graphs;      // key = substeps * 2 + (1 if the tick starts with the fused kernel)
+    // Lazy tick boundary: the last kernel of a tick (rounds + collide + velocity write) is deferred; if the next tick
+    // has the same parameters it is FUSED with that tick's first kernel into one ordinary mid-tick kernel, otherwise
+    // (or whenever state is read or written) it is flushed first. Results are identical either way.
+    bool deferred = false;
+    int deferred_substeps = 0;
     std::vector<float4> h_stage;
     // asynchronous render readback (sb_readback_begin / sb_readback_end): two snapshot slots
     hipStream_t copy_stream = nullptr;
@@ -390,7 +395,8 @@ void halo_exchange(sb_solver *s, int slot, hipStream_t st = nullptr) {
     }
     NCCL_CHECK(ncclGroupStart());
     for (size_t k = 0; k < D.peers.size(); ++k) {
-        const int cs = D.send_off[k + 1] - D.send_off[k], cr = D.recv_off[k + 1] - D.recv_off[k];
+        int cs = D.send_off[k + 1] - D.send_off[k], cr = D.recv_off[k + 1] - D.recv_off[k];
+        if (s->loopback) cs = cr = std::min(cs, cr);   // a self-exchange must post equal sizes (real peers always do)
         const size_t m = with_prev ? 2 : 1;   // float4 per particle; one message per peer and direction
         if (cs) NCCL_CHECK(ncclSend(s->d_sendbuf.p + m * D.send_off[k], m * (size_t)cs * 4, ncclFloat, s->loopback ? 0 : D.peers[k], s->comm, st));
         if (cr) NCCL_CHECK(ncclRecv(s->d_recvbuf.p + m * D.recv_off[k], m * (size_t)cr * 4, ncclFloat, s->loopback ? 0 : D.peers[k], s->comm, st));
@@ -440,8 +446,6 @@ struct LaunchTimer {            // optional HIP-event pair around every launch o
     ~LaunchTimer() { for (auto e : ev) (void)hipEventDestroy(e); }
 };
 
-// One tick (SPEC.md §2/§3): kernel K_s runs on the tiles of tiling T_(s&1) and fuses
-// cross(T) of substep s-1, the velocity update + integrate, and full(T) of substep s.
 // Launch the tile kernel K_it of a tick of `substeps` substeps (no halo).
 void launch_tick_kernel(sb_solver *s, int it, int substeps, LaunchTimer *lt, int tile_begin = 0, int tile_end = -1) {
     const int tl = s->plan->plan.tiling ? (it & 1) : 0;
@@ -467,9 +471,11 @@ void launch_gcolour(sb_solver *s, int gc, LaunchTimer *lt) {
     if (lt) lt->end();
 }
 
-// One tick (SPEC.md §2/§3): kernel K_s runs on the tiles of tiling T_(s&1) and fuses
-// cross(T) of substep s-1, the velocity update + integrate, and full(T) of substep s.
-void enqueue_substeps(sb_solver *s, int substeps, LaunchTimer *lt = nullptr) {
+// One tick (SPEC.md §2/§3): kernel K_s runs on the tiles of tiling T_(s&1): the tile's rounds (end of substep
+// s-1), collide + velocity update + integrate, the same rounds again (start of substep s).
+// fused_first: the tick starts with an ordinary mid-tick kernel on T0 that also finishes the PREVIOUS tick (its
+// deferred last kernel); defer_last: leave K_substeps to the next tick / to flush_deferred().
+void enqueue_substeps(sb_solver *s, int substeps, LaunchTimer *lt = nullptr, bool fused_first = false, bool defer_last = false) {
     const bool two = s->plan->plan.tiling;
     if (s->overlap_halo) {
         // T0 kernels run their boundary tiles first; the ghost exchange for the following T1 kernel then travels
@@ -495,14 +501,26 @@ void enqueue_substeps(sb_solver *s, int substeps, LaunchTimer *lt = nullptr) {
         return;
     }
     for (int it = 0; it <= substeps; ++it) {
+        if (it == substeps && defer_last) break;
         if (two && (it & 1)) halo_exchange(s, 1);
-        launch_tick_kernel(s, it, substeps, lt);
+        if (it == 0 && fused_first) launch_tick_kernel(s, 2, 4, lt);   // an even, interior step index: KIND 1 on T0
+        else launch_tick_kernel(s, it, substeps, lt);
         if (it == substeps) break;
         for (size_t gc = 0; gc < s->gcolours.size(); ++gc) {
             halo_exchange(s, 2 + (int)gc);
             launch_gcolour(s, (int)gc, lt);
         }
     }
+    HIP_CHECK(hipGetLastError());
+}
+
+// Launch the deferred last kernel of the previous tick (uses the tick parameters still on the device).
+void flush_deferred(sb_solver *s) {
+    if (!s->deferred) return;
+    const int S = s->deferred_substeps;
+    s->deferred = false;
+    if (s->plan->plan.tiling && (S & 1)) halo_exchange(s, 1);
+    launch_tick_kernel(s, S, S, nullptr);
     HIP_CHECK(hipGetLastError());
 }
 
@@ -724,29 +742,41 @@ int sb_step(sb_solver *s, float dt, int32_t substeps) {
     if (!(dt > 0.0f) || substeps <= 0) return fail(SB_ERR_INVALID_ARG, "sb_step: dt and substeps must be positive");
     return guarded([&]() -> int {
         int rc = set_device(s); if (rc) return rc;
+        // lazy tick boundary: fuse with the previous tick's deferred last kernel when nothing changed
+        const sbk::TickParams tp_new = tick_params(s, dt, substeps);
+        const bool can_defer = !s->overlap_halo && !std::getenv("SB_NO_LAZY_TICK") && (!s->plan->plan.tiling || (substeps & 1) == 0);
+        const bool fuse = s->deferred && can_defer && s->deferred_substeps == substeps && s->tp_valid &&
+                          std::memcmp(&tp_new, &s->tp_host, sizeof(tp_new)) == 0;
+        if (!fuse) flush_deferred(s);
         upload_tick_params(s, dt, substeps);
         // world > 1: RCCL send/recv inside a captured graph is opt-in (SB_GRAPH_RCCL=1), see DESIGN.md §7
         const bool graph_ok = s->desc.use_graph && !s->overlap_halo && (s->desc.world == 1 || std::getenv("SB_GRAPH_RCCL"));
-        if (!graph_ok) { enqueue_substeps(s, substeps); return SB_OK; }
-        auto it = s->graphs.find(substeps);
-        if (it == s->graphs.end()) {
-            hipGraph_t g = nullptr;
-            HIP_CHECK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
-            try {
-                enqueue_substeps(s, substeps);
-            } catch (...) {
-                (void)hipStreamEndCapture(s->stream, &g);
-                if (g) (void)hipGraphDestroy(g);
-                throw;
+        if (!graph_ok) {
+            enqueue_substeps(s, substeps, nullptr, fuse, can_defer);
+        } else {
+            const int key = substeps * 4 + (fuse ? 1 : 0) + (can_defer ? 2 : 0);
+            auto it = s->graphs.find(key);
+            if (it == s->graphs.end()) {
+                hipGraph_t g = nullptr;
+                HIP_CHECK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
+                try {
+                    enqueue_substeps(s, substeps, nullptr, fuse, can_defer);
+                } catch (...) {
+                    (void)hipStreamEndCapture(s->stream, &g);
+                    if (g) (void)hipGraphDestroy(g);
+                    throw;
+                }
+                HIP_CHECK(hipStreamEndCapture(s->stream, &g));
+                hipGraphExec_t ge = nullptr;
+                hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
+                (void)hipGraphDestroy(g);
+                if (e != hipSuccess) throw HipError(SB_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
+                it = s->graphs.emplace(key, ge).first;
             }
-            HIP_CHECK(hipStreamEndCapture(s->stream, &g));
-            hipGraphExec_t ge = nullptr;
-            hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
-            (void)hipGraphDestroy(g);
-            if (e != hipSuccess) throw HipError(SB_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-            it = s->graphs.emplace(substeps, ge).first;
+            HIP_CHECK(hipGraphLaunch(it->second, s->stream));
         }
-        HIP_CHECK(hipGraphLaunch(it->second, s->stream));
+        s->deferred = can_defer;
+        s->deferred_substeps = substeps;
         return SB_OK;
     });
 }
@@ -758,6 +788,7 @@ int sb_step_profiled(sb_solver *s, float dt, int32_t substeps, float *slot_ms, i
     if (n_slots != (int32_t)s->gcolours.size() + 4) return fail(SB_ERR_INVALID_ARG, "sb_step_profiled: n_slots must be 4 + n_global_colours");
     return guarded([&]() -> int {
         int rc = set_device(s); if (rc) return rc;
+        flush_deferred(s);
         upload_tick_params(s, dt, substeps);
         LaunchTimer lt; lt.stream = s->stream;
         enqueue_substeps(s, substeps, &lt);
@@ -781,6 +812,7 @@ int sb_debug_launch(sb_solver *s, float dt, int32_t substeps, int32_t it, int32_
         return fail(SB_ERR_INVALID_ARG, "sb_debug_launch: bad argument");
     return guarded([&]() -> int {
         int rc = set_device(s); if (rc) return rc;
+        flush_deferred(s);
         upload_tick_params(s, dt, substeps);
         if (gcolour < 0) launch_tick_kernel(s, it, substeps, nullptr);
         else launch_gcolour(s, gcolour, nullptr);
@@ -796,6 +828,7 @@ int sb_debug_halo_pack(sb_solver *s, int32_t slot, float *host_out, int64_t capa
     if (slot < 0 || slot >= (int32_t)s->halos.size()) return fail(SB_ERR_INVALID_ARG, "sb_debug_halo_pack: bad slot");
     return guarded([&]() -> int {
         int rc = set_device(s); if (rc) return rc;
+        flush_deferred(s);
         DevHalo &D = *s->halos[slot];
         const int ns = D.send_off.back();
         const int64_t need = (int64_t)ns * 4 * (slot == 1 ? 2 : 1);
@@ -842,6 +875,7 @@ int sb_synchronize(sb_solver *s) {
     if (!s) return fail(SB_ERR_INVALID_ARG, "sb_synchronize: null handle");
     return guarded([&]() -> int {
         int rc = set_device(s); if (rc) return rc;
+        flush_deferred(s);
         HIP_CHECK(hipStreamSynchronize(s->stream));
         return SB_OK;
     });
@@ -854,6 +888,7 @@ static int get_state(sb_solver *s, float *out, int32_t n, bool velocity) {
     return guarded([&]() -> int {
         int rc = set_device(s); if (rc) return rc;
         const sbp::LocalPlan &L = s->plan->local;
+        flush_deferred(s);
         HIP_CHECK(hipStreamSynchronize(s->stream));
         if (velocity) {
             std::vector<float> h((size_t)s->n_owned * 3);
@@ -885,6 +920,7 @@ int sb_set_state(sb_solver *s, const float *pos, const float *vel, int32_t n) {
     return guarded([&]() -> int {
         int rc = set_device(s); if (rc) return rc;
         const sbp::LocalPlan &L = s->plan->local;
+        flush_deferred(s);
         HIP_CHECK(hipStreamSynchronize(s->stream));
         std::vector<float4> hp((size_t)s->n_local);
         HIP_CHECK(hipMemcpy(hp.data(), s->d_pos.p, hp.size() * sizeof(float4), hipMemcpyDeviceToHost));
@@ -920,6 +956,7 @@ int sb_readback_begin(sb_solver *s) {
                 HIP_CHECK(hipEventCreateWithFlags(&s->ev_copied[k], hipEventDisableTiming));
             }
         }
+        flush_deferred(s);
         const int k = (s->snap_head + s->snap_pending) & 1;
         // snapshot on the compute stream (ordered after every tick enqueued so far, before the next one) ...
         if (s->n_owned)

@@ -228,3 +228,36 @@ def test_async_readback_matches_blocking_readback():
             sb.readback_end()
     finally:
         sb.OnDestroy()
+
+
+def test_lazy_tick_boundary_is_invisible(oracle_mod, monkeypatch):
+    # the deferred last kernel of a tick is fused into the next tick or flushed on any read / parameter change:
+    # every interleaving must give the bits of the eager schedule (SB_NO_LAZY_TICK) and of the oracle
+    mesh = jelly_cube(20)
+    plan_steps = [(0.02, 10, False), (0.02, 10, False), (0.02, 10, True), (0.02, 10, False), (0.01, 10, False),
+                  (0.01, 10, False), (0.01, 6, False), (0.01, 7, True), (0.01, 6, False), (0.01, 6, False)]
+
+    def run(lazy):
+        if lazy:
+            monkeypatch.delenv("SB_NO_LAZY_TICK", raising=False)
+        else:
+            monkeypatch.setenv("SB_NO_LAZY_TICK", "1")
+        sb = Softbody(mesh, ground_plane=(0, 1, 0, -2.0)).Start()
+        try:
+            snaps = []
+            for dt, S, read in plan_steps:
+                sb.step(dt, S)
+                if read:
+                    snaps.append(sb.get_positions().copy())
+            return sb.get_positions().copy(), sb.get_velocities().copy(), snaps, sb.plan()
+        finally:
+            pass
+    xa, va, sa, plan = run(True)
+    xb, vb, sb_, _ = run(False)
+    assert np.array_equal(xa.view(np.uint32), xb.view(np.uint32)) and np.array_equal(va.view(np.uint32), vb.view(np.uint32))
+    for p, q in zip(sa, sb_):
+        assert np.array_equal(p.view(np.uint32), q.view(np.uint32))
+    o = make_oracle(oracle_mod, mesh, plan, ground_plane=(0, 1, 0, -2.0))
+    for dt, S, _ in plan_steps:
+        o.step(dt, S)
+    assert np.array_equal(xa.view(np.uint32), o.x.view(np.uint32)) and np.array_equal(va.view(np.uint32), o.v.view(np.uint32))
