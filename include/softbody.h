@@ -88,6 +88,10 @@ int sb_comm_unique_id(uint8_t out_id[SB_UNIQUE_ID_BYTES]);
 int sb_comm_init(sb_solver *s, const uint8_t id[SB_UNIQUE_ID_BYTES]);
 
 /* ---- the hot path (FixedUpdate) -------------------------------------------------------------- */
+/* One tick of `substeps` substeps (SPEC.md §2). Asynchronous: work is enqueued on the solver's stream. The last
+ * kernel of a tick may be held back and fused with the next tick when dt/substeps/plane are unchanged; every call
+ * that reads or writes state (sb_get_*, sb_set_state, sb_readback_begin, sb_synchronize, ...) completes it first, so
+ * the laziness is not observable. */
 int sb_step(sb_solver *s, float dt, int32_t substeps);
 
 /* ---- readback / state round trip ------------------------------------------------------------- */

@@ -249,15 +249,18 @@ def test_lazy_tick_boundary_is_invisible(oracle_mod, monkeypatch):
                 sb.step(dt, S)
                 if read:
                     snaps.append(sb.get_positions().copy())
-            return sb.get_positions().copy(), sb.get_velocities().copy(), snaps, sb.plan()
+            orders = [sb.plan().order(par) for par in (0, 1)]
+            return sb.get_positions().copy(), sb.get_velocities().copy(), snaps, orders
         finally:
-            pass
-    xa, va, sa, plan = run(True)
+            sb.OnDestroy()
+    xa, va, sa, orders = run(True)
     xb, vb, sb_, _ = run(False)
     assert np.array_equal(xa.view(np.uint32), xb.view(np.uint32)) and np.array_equal(va.view(np.uint32), vb.view(np.uint32))
     for p, q in zip(sa, sb_):
         assert np.array_equal(p.view(np.uint32), q.view(np.uint32))
-    o = make_oracle(oracle_mod, mesh, plan, ground_plane=(0, 1, 0, -2.0))
+    o = make_oracle(oracle_mod, mesh, None, ground_plane=(0, 1, 0, -2.0))
+    for par in (0, 1):
+        o.set_order(orders[par][0], orders[par][1], parity=par)
     for dt, S, _ in plan_steps:
         o.step(dt, S)
     assert np.array_equal(xa.view(np.uint32), o.x.view(np.uint32)) and np.array_equal(va.view(np.uint32), o.v.view(np.uint32))
