@@ -40,8 +40,26 @@ constexpr int kInlineRuns = 10;
 constexpr int kMaxRoundsLds = 128;   // round words cached in LDS; longer programs read them from memory
 constexpr int kMaxPalette = 256;     // rest-length dictionary entries per tile
 
+// Positions in HBM: packed xyz (12 B) + the static inverse mass in a side array (never rewritten).
+struct PosView {
+    float *xyz;        // 3 floats per local particle
+    const float *w;    // inverse mass per local particle
+};
+__device__ __forceinline__ float4 pv_load(const PosView &P, int g) {
+    const size_t o = 3 * (size_t)g;
+    return make_float4(P.xyz[o], P.xyz[o + 1], P.xyz[o + 2], P.w[g]);
+}
+__device__ __forceinline__ void pv_store(const PosView &P, int g, const float4 &v) {
+    const size_t o = 3 * (size_t)g;
+    P.xyz[o] = v.x; P.xyz[o + 1] = v.y; P.xyz[o + 2] = v.z;
+}
+
+constexpr int kMaxMassPalette = 64;   // distinct inverse masses that fit the one-byte-per-particle coding (one per lane)
+
 struct TileArgs {
-    float4 *pos;              // (x,y,z,w) per local particle
+    PosView pos;              // packed xyz + inverse mass per local particle
+    const uint8_t *w8;        // WPAL kernels: index of the particle's inverse mass in wpal (1 B instead of 4 B per read)
+    const float *wpal;        // kMaxMassPalette entries
     float *prev;              // packed xyz
     float *vel;               // packed xyz (read by KIND 0, written by KIND 2)
     const TileDesc *tiles;
@@ -165,7 +183,8 @@ __device__ __forceinline__ bool project_bending(float4 &pa, float4 &pb, float4 &
 // __syncthreads() would also drain vmcnt, i.e. wait for the xprev stores of the MARK step.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-template <int KIND, bool QUADS, int PPT>
+// WPAL = inverse masses are read as one-byte palette indices (the palette entry comes from another lane by ds_bpermute).
+template <int KIND, bool QUADS, int PPT, bool WPAL>
 __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileArgs A) {
     extern __shared__ uint4 lds_raw[];
     float4 *lds_pos = reinterpret_cast<float4 *>(lds_raw);
@@ -230,10 +249,13 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
     // which would serialise the tile's loads into several HBM round trips.
     f32x4 X[PPT];
     float pvx[PPT], pvy[PPT], pvz[PPT];
+    uint32_t wi[PPT];
+    const int mypal = WPAL ? __float_as_int(A.wpal[tid & (kMaxMassPalette - 1)]) : 0;   // lane l holds palette entry l
 #pragma unroll
     for (int m = 0; m < PPT; ++m) {
         const int gc = max(g[m], 0);
-        X[m] = *reinterpret_cast<const f32x4 *>(A.pos + gc);
+        X[m].x = A.pos.xyz[3 * (size_t)gc + 0]; X[m].y = A.pos.xyz[3 * (size_t)gc + 1]; X[m].z = A.pos.xyz[3 * (size_t)gc + 2];
+        if (WPAL) { wi[m] = A.w8[gc]; X[m].w = 0.0f; } else { wi[m] = 0; X[m].w = A.pos.w[gc]; }
         pvx[m] = pvy[m] = pvz[m] = 0.0f;
         if (KIND != 0) { pvx[m] = A.prev[3 * (size_t)gc + 0]; pvy[m] = A.prev[3 * (size_t)gc + 1]; pvz[m] = A.prev[3 * (size_t)gc + 2]; }
     }
@@ -259,7 +281,12 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
     // One common use of every loaded value: the scheduler cannot sink a load below it, so all loads are issued
     // first and a single wait follows (left alone it emits load, wait, LDS write, load, wait, ... to save registers).
 #pragma unroll
-    for (int m = 0; m < PPT; ++m) asm volatile("" ::"v"(X[m].x), "v"(pvx[m]));
+    for (int m = 0; m < PPT; ++m) asm volatile("" ::"v"(X[m].x), "v"(pvx[m]), "v"(wi[m]), "v"(X[m].w));
+    asm volatile("" ::"v"(mypal));
+    if (WPAL) {
+#pragma unroll
+        for (int m = 0; m < PPT; ++m) X[m].w = __int_as_float(__builtin_amdgcn_ds_bpermute((int)(wi[m] << 2), mypal));
+    }
 #pragma unroll
     for (int q = 0; q < kW; ++q) asm volatile("" ::"v"(wv[q].x));
     asm volatile("" ::"v"(rw), "v"(palw), "v"(rwl));
@@ -386,36 +413,36 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
     }
 #pragma unroll
     for (int m = 0; m < PPT; ++m)
-        if (g[m] >= 0) A.pos[g[m]] = lds_pos[tid + m * kTileThreads];
+        if (g[m] >= 0) pv_store(A.pos, g[m], lds_pos[tid + m * kTileThreads]);
 }
 
 // Global-colour kernels: one constraint per lane, gather/scatter straight on HBM.
-__global__ __launch_bounds__(256) void global_distance_kernel(float4 *pos, const int2 *ij, const float *rest, int count,
+__global__ __launch_bounds__(256) void global_distance_kernel(PosView pos, const int2 *ij, const float *rest, int count,
                                                               const TickParams *tpp) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= count) return;
     const float at = tpp->at_d;
     const int2 e = ij[k];
-    float4 a = pos[e.x], b = pos[e.y];
-    if (project_distance(a, b, rest[k], at)) { pos[e.x] = a; pos[e.y] = b; }
+    float4 a = pv_load(pos, e.x), b = pv_load(pos, e.y);
+    if (project_distance(a, b, rest[k], at)) { pv_store(pos, e.x, a); pv_store(pos, e.y, b); }
 }
 
-__global__ __launch_bounds__(256) void global_quad_kernel(float4 *pos, const int4 *idx, const float2 *rest, int count,
+__global__ __launch_bounds__(256) void global_quad_kernel(PosView pos, const int4 *idx, const float2 *rest, int count,
                                                           int type, const TickParams *tpp) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= count) return;
     const int4 e = idx[k];
-    float4 p0 = pos[e.x], p1 = pos[e.y], p2 = pos[e.z], p3 = pos[e.w];
+    float4 p0 = pv_load(pos, e.x), p1 = pv_load(pos, e.y), p2 = pv_load(pos, e.z), p3 = pv_load(pos, e.w);
     const float2 r = rest[k];
     bool ok = type == 1 ? project_volume(p0, p1, p2, p3, r.x, tpp->at_v) : project_bending(p0, p1, p2, p3, r, tpp->at_b);
-    if (ok) { pos[e.x] = p0; pos[e.y] = p1; pos[e.z] = p2; pos[e.w] = p3; }
+    if (ok) { pv_store(pos, e.x, p0); pv_store(pos, e.y, p1); pv_store(pos, e.z, p2); pv_store(pos, e.w, p3); }
 }
 
 // Render readback: owned positions (device order, float4) -> caller order, packed xyz.
-__global__ __launch_bounds__(256) void snapshot_kernel(const float4 *pos, const int32_t *local_to_old, float *out_xyz, int n_owned) {
+__global__ __launch_bounds__(256) void snapshot_kernel(PosView pos, const int32_t *local_to_old, float *out_xyz, int n_owned) {
     const int l = blockIdx.x * 256 + threadIdx.x;
     if (l >= n_owned) return;
-    const float4 p = pos[l];
+    const float4 p = pv_load(pos, l);
     const size_t o = 3 * (size_t)local_to_old[l];
     out_xyz[o] = p.x; out_xyz[o + 1] = p.y; out_xyz[o + 2] = p.z;
 }
@@ -423,23 +450,23 @@ __global__ __launch_bounds__(256) void snapshot_kernel(const float4 *pos, const 
 // Halo pack / unpack: ghost positions travel as float4; with WITH_PREV every particle travels as a
 // {position, previous position} pair of float4 (the T1 kernels run velocity + integrate on ghosts too).
 template <bool WITH_PREV>
-__global__ __launch_bounds__(256) void halo_pack_kernel(const float4 *pos, const float *prev, const int32_t *idx,
+__global__ __launch_bounds__(256) void halo_pack_kernel(PosView pos, const float *prev, const int32_t *idx,
                                                         float4 *buf, int count) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= count) return;
     const int g = idx[k];
-    if (!WITH_PREV) { buf[k] = pos[g]; return; }
-    buf[2 * (size_t)k] = pos[g];   // {position, previous position} pairs: one contiguous message per peer
+    if (!WITH_PREV) { buf[k] = pv_load(pos, g); return; }
+    buf[2 * (size_t)k] = pv_load(pos, g);   // {position, previous position} pairs: one contiguous message per peer
     buf[2 * (size_t)k + 1] = make_float4(prev[3 * (size_t)g], prev[3 * (size_t)g + 1], prev[3 * (size_t)g + 2], 0.0f);
 }
 template <bool WITH_PREV>
-__global__ __launch_bounds__(256) void halo_unpack_kernel(float4 *pos, float *prev, const int32_t *idx, const float4 *buf,
+__global__ __launch_bounds__(256) void halo_unpack_kernel(PosView pos, float *prev, const int32_t *idx, const float4 *buf,
                                                           int count) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= count) return;
     const int g = idx[k];
-    if (!WITH_PREV) { pos[g] = buf[k]; return; }
-    pos[g] = buf[2 * (size_t)k];
+    if (!WITH_PREV) { pv_store(pos, g, buf[k]); return; }       // the inverse mass of a ghost is static: uploaded once
+    pv_store(pos, g, buf[2 * (size_t)k]);
     {
         const float4 p = buf[2 * (size_t)k + 1];
         prev[3 * (size_t)g] = p.x; prev[3 * (size_t)g + 1] = p.y; prev[3 * (size_t)g + 2] = p.z;

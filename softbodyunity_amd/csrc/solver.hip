@@ -120,7 +120,12 @@ struct sb_solver {
     // device state
     int64_t dev_bytes = 0;
     int64_t n_owned = 0, n_local = 0;
-    DevBuf<float4> d_pos;
+    DevBuf<float> d_pos3;            // packed xyz per local particle
+    DevBuf<float> d_wf;              // inverse mass per local particle (static)
+    DevBuf<uint8_t> d_w8;            // palette index of the inverse mass (when <= 64 distinct values)
+    DevBuf<float> d_wpal;
+    bool w_palette = false;
+    sbk::PosView pos_view() const { return sbk::PosView{d_pos3.p, d_wf.p}; }
     DevBuf<float> d_prev, d_vel;
     DevBuf<sbk::TickParams> d_tp;
     DevBuf<float4> d_sendbuf, d_recvbuf;
@@ -135,7 +140,7 @@ struct sb_solver {
     // (or whenever state is read or written) it is flushed first. Results are identical either way.
     bool deferred = false;
     int deferred_substeps = 0;
-    std::vector<float4> h_stage;
+    std::vector<float> h_stage;
     // asynchronous render readback (sb_readback_begin / sb_readback_end): two snapshot slots
     hipStream_t copy_stream = nullptr;
     DevBuf<int32_t> d_local_to_old;
@@ -201,14 +206,31 @@ void build_device(sb_solver *s) {
     s->n_owned = L.n_owned;
     s->n_local = (int64_t)L.local_to_old.size();
     // particle state
-    std::vector<float4> hp((size_t)s->n_local);
+    std::vector<float> hp((size_t)s->n_local * 3), hw((size_t)s->n_local);
     std::vector<float> hv((size_t)s->n_local * 3, 0.0f);
     for (int64_t l = 0; l < s->n_local; ++l) {
         int32_t o = L.local_to_old[l];
-        hp[l] = make_float4(s->pos[3 * (size_t)o], s->pos[3 * (size_t)o + 1], s->pos[3 * (size_t)o + 2], s->invm[o]);
-        for (int c = 0; c < 3; ++c) hv[3 * (size_t)l + c] = s->vel[3 * (size_t)o + c];
+        for (int c = 0; c < 3; ++c) { hp[3 * (size_t)l + c] = s->pos[3 * (size_t)o + c]; hv[3 * (size_t)l + c] = s->vel[3 * (size_t)o + c]; }
+        hw[l] = s->invm[o];
     }
-    s->d_pos.upload(hp, s->dev_bytes);
+    s->d_pos3.upload(hp, s->dev_bytes);
+    s->d_wf.upload(hw, s->dev_bytes);
+    {   // one byte per particle instead of four when the mesh uses few distinct masses (the usual case)
+        std::vector<uint32_t> vals(hw.size());
+        for (size_t l = 0; l < hw.size(); ++l) std::memcpy(&vals[l], &hw[l], 4);
+        std::vector<uint32_t> uniq = vals;
+        std::sort(uniq.begin(), uniq.end());
+        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        std::vector<float> pal(sbk::kMaxMassPalette, 0.0f);
+        if ((int)uniq.size() <= sbk::kMaxMassPalette && !std::getenv("SB_NO_MASS_PALETTE")) {
+            std::vector<uint8_t> w8(hw.size());
+            for (size_t l = 0; l < hw.size(); ++l) w8[l] = (uint8_t)(std::lower_bound(uniq.begin(), uniq.end(), vals[l]) - uniq.begin());
+            for (size_t k = 0; k < uniq.size(); ++k) std::memcpy(&pal[k], &uniq[k], 4);
+            s->d_w8.upload(w8, s->dev_bytes);
+            s->w_palette = true;
+        }
+        s->d_wpal.upload(pal, s->dev_bytes);
+    }
     s->d_vel.upload(hv, s->dev_bytes);
     s->d_prev.alloc((size_t)s->n_local * 3, s->dev_bytes);
     HIP_CHECK(hipMemset(s->d_prev.p, 0, (size_t)s->n_local * 3 * sizeof(float)));
@@ -387,10 +409,10 @@ void halo_exchange(sb_solver *s, int slot, hipStream_t st = nullptr) {
     const int ns = D.send_off.back(), nr = D.recv_off.back();
     if (ns) {
         if (with_prev)
-            hipLaunchKernelGGL(sbk::halo_pack_kernel<true>, dim3((ns + 255) / 256), dim3(256), 0, st, s->d_pos.p,
+            hipLaunchKernelGGL(sbk::halo_pack_kernel<true>, dim3((ns + 255) / 256), dim3(256), 0, st, s->pos_view(),
                                s->d_prev.p, D.send_idx.p, s->d_sendbuf.p, ns);
         else
-            hipLaunchKernelGGL(sbk::halo_pack_kernel<false>, dim3((ns + 255) / 256), dim3(256), 0, st, s->d_pos.p,
+            hipLaunchKernelGGL(sbk::halo_pack_kernel<false>, dim3((ns + 255) / 256), dim3(256), 0, st, s->pos_view(),
                                s->d_prev.p, D.send_idx.p, s->d_sendbuf.p, ns);
     }
     NCCL_CHECK(ncclGroupStart());
@@ -404,10 +426,10 @@ void halo_exchange(sb_solver *s, int slot, hipStream_t st = nullptr) {
     NCCL_CHECK(ncclGroupEnd());
     if (nr) {
         if (with_prev)
-            hipLaunchKernelGGL(sbk::halo_unpack_kernel<true>, dim3((nr + 255) / 256), dim3(256), 0, st, s->d_pos.p,
+            hipLaunchKernelGGL(sbk::halo_unpack_kernel<true>, dim3((nr + 255) / 256), dim3(256), 0, st, s->pos_view(),
                                s->d_prev.p, D.recv_idx.p, s->d_recvbuf.p, nr);
         else
-            hipLaunchKernelGGL(sbk::halo_unpack_kernel<false>, dim3((nr + 255) / 256), dim3(256), 0, st, s->d_pos.p,
+            hipLaunchKernelGGL(sbk::halo_unpack_kernel<false>, dim3((nr + 255) / 256), dim3(256), 0, st, s->pos_view(),
                                s->d_prev.p, D.recv_idx.p, s->d_recvbuf.p, nr);
     }
 }
@@ -417,19 +439,21 @@ void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = 
     if (tile_end < 0) tile_end = D.n_tiles;
     if (tile_end <= tile_begin) return;
     sbk::TileArgs A{};
-    A.pos = s->d_pos.p; A.prev = s->d_prev.p; A.vel = s->d_vel.p;
+    A.pos = s->pos_view(); A.w8 = s->d_w8.p; A.wpal = s->d_wpal.p; A.prev = s->d_prev.p; A.vel = s->d_vel.p;
     A.tiles = D.tiles.p; A.runs_overflow = D.runs_overflow.p; A.stream = D.stream.p;
     A.tp = s->d_tp.p;
     A.max_local = D.max_local; A.win_dwords = D.win_dwords; A.tile_base = tile_begin; A.pal_dwords = D.pal_dwords;
     const dim3 grid(tile_end - tile_begin), block(sbk::kTileThreads);
     const bool small = D.max_local <= 2 * sbk::kTileThreads;   // every tile <= 512 particles
-    if (D.has_quads) {
-        if (small) hipLaunchKernelGGL((sbk::tile_kernel<KIND, true, 2>), grid, block, D.lds_bytes, s->stream, A);
-        else hipLaunchKernelGGL((sbk::tile_kernel<KIND, true, 4>), grid, block, D.lds_bytes, s->stream, A);
+#define SB_LAUNCH_TILE(Q, P, W) hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, P, W>), grid, block, D.lds_bytes, s->stream, A)
+    if (s->w_palette) {
+        if (D.has_quads) { if (small) SB_LAUNCH_TILE(true, 2, true); else SB_LAUNCH_TILE(true, 4, true); }
+        else { if (small) SB_LAUNCH_TILE(false, 2, true); else SB_LAUNCH_TILE(false, 4, true); }
     } else {
-        if (small) hipLaunchKernelGGL((sbk::tile_kernel<KIND, false, 2>), grid, block, D.lds_bytes, s->stream, A);
-        else hipLaunchKernelGGL((sbk::tile_kernel<KIND, false, 4>), grid, block, D.lds_bytes, s->stream, A);
+        if (D.has_quads) { if (small) SB_LAUNCH_TILE(true, 2, false); else SB_LAUNCH_TILE(true, 4, false); }
+        else { if (small) SB_LAUNCH_TILE(false, 2, false); else SB_LAUNCH_TILE(false, 4, false); }
     }
+#undef SB_LAUNCH_TILE
 }
 
 struct LaunchTimer {            // optional HIP-event pair around every launch of one tick (sb_step_profiled)
@@ -463,10 +487,10 @@ void launch_gcolour(sb_solver *s, int gc, LaunchTimer *lt) {
     if (lt) lt->begin(2 + gc);
     dim3 grid((G.count + 255) / 256);
     if (G.type == 0)
-        hipLaunchKernelGGL(sbk::global_distance_kernel, grid, dim3(256), 0, s->stream, s->d_pos.p, G.ij.p, G.rest.p, G.count,
+        hipLaunchKernelGGL(sbk::global_distance_kernel, grid, dim3(256), 0, s->stream, s->pos_view(), G.ij.p, G.rest.p, G.count,
                            s->d_tp.p);
     else
-        hipLaunchKernelGGL(sbk::global_quad_kernel, grid, dim3(256), 0, s->stream, s->d_pos.p, G.quad.p, G.rest2.p, G.count,
+        hipLaunchKernelGGL(sbk::global_quad_kernel, grid, dim3(256), 0, s->stream, s->pos_view(), G.quad.p, G.rest2.p, G.count,
                            G.type, s->d_tp.p);
     if (lt) lt->end();
 }
@@ -836,10 +860,10 @@ int sb_debug_halo_pack(sb_solver *s, int32_t slot, float *host_out, int64_t capa
         if (need == 0) return SB_OK;
         if (!host_out || capacity_floats < need) return fail(SB_ERR_INVALID_ARG, "sb_debug_halo_pack: buffer too small");
         if (slot == 1)
-            hipLaunchKernelGGL(sbk::halo_pack_kernel<true>, dim3((ns + 255) / 256), dim3(256), 0, s->stream, s->d_pos.p, s->d_prev.p,
+            hipLaunchKernelGGL(sbk::halo_pack_kernel<true>, dim3((ns + 255) / 256), dim3(256), 0, s->stream, s->pos_view(), s->d_prev.p,
                                D.send_idx.p, s->d_sendbuf.p, ns);
         else
-            hipLaunchKernelGGL(sbk::halo_pack_kernel<false>, dim3((ns + 255) / 256), dim3(256), 0, s->stream, s->d_pos.p, s->d_prev.p,
+            hipLaunchKernelGGL(sbk::halo_pack_kernel<false>, dim3((ns + 255) / 256), dim3(256), 0, s->stream, s->pos_view(), s->d_prev.p,
                                D.send_idx.p, s->d_sendbuf.p, ns);
         HIP_CHECK(hipMemcpyAsync(host_out, s->d_sendbuf.p, (size_t)need * sizeof(float), hipMemcpyDeviceToHost, s->stream));
         HIP_CHECK(hipStreamSynchronize(s->stream));
@@ -861,10 +885,10 @@ int sb_debug_halo_unpack(sb_solver *s, int32_t slot, const float *host_in, int64
         if (!host_in) return fail(SB_ERR_INVALID_ARG, "sb_debug_halo_unpack: null buffer");
         HIP_CHECK(hipMemcpyAsync(s->d_recvbuf.p, host_in, (size_t)need * sizeof(float), hipMemcpyHostToDevice, s->stream));
         if (slot == 1)
-            hipLaunchKernelGGL(sbk::halo_unpack_kernel<true>, dim3((nr + 255) / 256), dim3(256), 0, s->stream, s->d_pos.p, s->d_prev.p,
+            hipLaunchKernelGGL(sbk::halo_unpack_kernel<true>, dim3((nr + 255) / 256), dim3(256), 0, s->stream, s->pos_view(), s->d_prev.p,
                                D.recv_idx.p, s->d_recvbuf.p, nr);
         else
-            hipLaunchKernelGGL(sbk::halo_unpack_kernel<false>, dim3((nr + 255) / 256), dim3(256), 0, s->stream, s->d_pos.p, s->d_prev.p,
+            hipLaunchKernelGGL(sbk::halo_unpack_kernel<false>, dim3((nr + 255) / 256), dim3(256), 0, s->stream, s->pos_view(), s->d_prev.p,
                                D.recv_idx.p, s->d_recvbuf.p, nr);
         HIP_CHECK(hipStreamSynchronize(s->stream));
         return SB_OK;
@@ -898,12 +922,11 @@ static int get_state(sb_solver *s, float *out, int32_t n, bool velocity) {
                 out[3 * (size_t)o] = h[3 * l]; out[3 * (size_t)o + 1] = h[3 * l + 1]; out[3 * (size_t)o + 2] = h[3 * l + 2];
             }
         } else {
-            s->h_stage.resize((size_t)s->n_owned);
-            if (s->n_owned) HIP_CHECK(hipMemcpy(s->h_stage.data(), s->d_pos.p, (size_t)s->n_owned * sizeof(float4), hipMemcpyDeviceToHost));
+            s->h_stage.resize((size_t)s->n_owned * 3);
+            if (s->n_owned) HIP_CHECK(hipMemcpy(s->h_stage.data(), s->d_pos3.p, (size_t)s->n_owned * 3 * sizeof(float), hipMemcpyDeviceToHost));
             for (int64_t l = 0; l < s->n_owned; ++l) {
                 int32_t o = L.local_to_old[l];
-                const float4 v = s->h_stage[l];
-                out[3 * (size_t)o] = v.x; out[3 * (size_t)o + 1] = v.y; out[3 * (size_t)o + 2] = v.z;
+                for (int c = 0; c < 3; ++c) out[3 * (size_t)o + c] = s->h_stage[3 * (size_t)l + c];
             }
         }
         return SB_OK;
@@ -922,15 +945,12 @@ int sb_set_state(sb_solver *s, const float *pos, const float *vel, int32_t n) {
         const sbp::LocalPlan &L = s->plan->local;
         flush_deferred(s);
         HIP_CHECK(hipStreamSynchronize(s->stream));
-        std::vector<float4> hp((size_t)s->n_local);
-        HIP_CHECK(hipMemcpy(hp.data(), s->d_pos.p, hp.size() * sizeof(float4), hipMemcpyDeviceToHost));
-        std::vector<float> hv((size_t)s->n_local * 3);
+        std::vector<float> hp((size_t)s->n_local * 3), hv((size_t)s->n_local * 3);
         for (int64_t l = 0; l < s->n_local; ++l) {
             int32_t o = L.local_to_old[l];
-            hp[l].x = pos[3 * (size_t)o]; hp[l].y = pos[3 * (size_t)o + 1]; hp[l].z = pos[3 * (size_t)o + 2];
-            for (int c = 0; c < 3; ++c) hv[3 * (size_t)l + c] = vel[3 * (size_t)o + c];
+            for (int c = 0; c < 3; ++c) { hp[3 * (size_t)l + c] = pos[3 * (size_t)o + c]; hv[3 * (size_t)l + c] = vel[3 * (size_t)o + c]; }
         }
-        HIP_CHECK(hipMemcpy(s->d_pos.p, hp.data(), hp.size() * sizeof(float4), hipMemcpyHostToDevice));
+        HIP_CHECK(hipMemcpy(s->d_pos3.p, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(s->d_vel.p, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice));
         return SB_OK;
     });
@@ -961,7 +981,7 @@ int sb_readback_begin(sb_solver *s) {
         // snapshot on the compute stream (ordered after every tick enqueued so far, before the next one) ...
         if (s->n_owned)
             hipLaunchKernelGGL(sbk::snapshot_kernel, dim3((unsigned)((s->n_owned + 255) / 256)), dim3(256), 0, s->stream,
-                               s->d_pos.p, s->d_local_to_old.p, s->d_snap[k].p, (int)s->n_owned);
+                               s->pos_view(), s->d_local_to_old.p, s->d_snap[k].p, (int)s->n_owned);
         HIP_CHECK(hipEventRecord(s->ev_snap[k], s->stream));
         // ... D2H on the copy stream, overlapping whatever the compute stream does next
         HIP_CHECK(hipStreamWaitEvent(s->copy_stream, s->ev_snap[k], 0));
