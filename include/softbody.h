@@ -124,8 +124,8 @@ int sb_step_profiled(sb_solver *s, float dt, int32_t substeps, float *slot_ms_ou
  * GPU, where RCCL cannot form a communicator): run ONE launch of a tick — tile kernel K_it (gcolour = -1)
  * or global colour `gcolour` of the substep that K_it started — without any ghost exchange, and move one
  * halo slot's send / receive buffer through host memory. Buffer layout = what goes over the wire: peers in
- * increasing rank order, each peer's particles back to back as float4 positions (slot 1: as {position,
- * previous position} pairs of float4). */
+ * increasing rank order, each peer's particles back to back, 3 floats (position) per particle, slot 1: 6 floats
+ * (position, previous position). */
 int sb_debug_launch(sb_solver *s, float dt, int32_t substeps, int32_t it, int32_t gcolour);
 int sb_debug_halo_pack(sb_solver *s, int32_t slot, float *host_out, int64_t capacity_floats, int64_t *count_floats_out);
 int sb_debug_halo_unpack(sb_solver *s, int32_t slot, const float *host_in, int64_t count_floats);

@@ -447,30 +447,27 @@ __global__ __launch_bounds__(256) void snapshot_kernel(PosView pos, const int32_
     out_xyz[o] = p.x; out_xyz[o + 1] = p.y; out_xyz[o + 2] = p.z;
 }
 
-// Halo pack / unpack: ghost positions travel as float4; with WITH_PREV every particle travels as a
-// {position, previous position} pair of float4 (the T1 kernels run velocity + integrate on ghosts too).
+// Halo pack / unpack: a ghost travels as 3 floats (position) or, WITH_PREV, 6 floats (position, previous position:
+// the T1 kernels run velocity + integrate on ghosts too). The inverse mass of a ghost is static: uploaded once.
 template <bool WITH_PREV>
-__global__ __launch_bounds__(256) void halo_pack_kernel(PosView pos, const float *prev, const int32_t *idx,
-                                                        float4 *buf, int count) {
+__global__ __launch_bounds__(256) void halo_pack_kernel(PosView pos, const float *prev, const int32_t *idx, float *buf, int count) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= count) return;
-    const int g = idx[k];
-    if (!WITH_PREV) { buf[k] = pv_load(pos, g); return; }
-    buf[2 * (size_t)k] = pv_load(pos, g);   // {position, previous position} pairs: one contiguous message per peer
-    buf[2 * (size_t)k + 1] = make_float4(prev[3 * (size_t)g], prev[3 * (size_t)g + 1], prev[3 * (size_t)g + 2], 0.0f);
+    const size_t o = 3 * (size_t)idx[k];
+    constexpr int F = WITH_PREV ? 6 : 3;
+    float *b = buf + (size_t)F * k;
+    b[0] = pos.xyz[o]; b[1] = pos.xyz[o + 1]; b[2] = pos.xyz[o + 2];
+    if (WITH_PREV) { b[3] = prev[o]; b[4] = prev[o + 1]; b[5] = prev[o + 2]; }
 }
 template <bool WITH_PREV>
-__global__ __launch_bounds__(256) void halo_unpack_kernel(PosView pos, float *prev, const int32_t *idx, const float4 *buf,
-                                                          int count) {
+__global__ __launch_bounds__(256) void halo_unpack_kernel(PosView pos, float *prev, const int32_t *idx, const float *buf, int count) {
     const int k = blockIdx.x * 256 + threadIdx.x;
     if (k >= count) return;
-    const int g = idx[k];
-    if (!WITH_PREV) { pv_store(pos, g, buf[k]); return; }       // the inverse mass of a ghost is static: uploaded once
-    pv_store(pos, g, buf[2 * (size_t)k]);
-    {
-        const float4 p = buf[2 * (size_t)k + 1];
-        prev[3 * (size_t)g] = p.x; prev[3 * (size_t)g + 1] = p.y; prev[3 * (size_t)g + 2] = p.z;
-    }
+    const size_t o = 3 * (size_t)idx[k];
+    constexpr int F = WITH_PREV ? 6 : 3;
+    const float *b = buf + (size_t)F * k;
+    pos.xyz[o] = b[0]; pos.xyz[o + 1] = b[1]; pos.xyz[o + 2] = b[2];
+    if (WITH_PREV) { prev[o] = b[3]; prev[o + 1] = b[4]; prev[o + 2] = b[5]; }
 }
 
 }  // namespace sbk

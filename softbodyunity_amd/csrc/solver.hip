@@ -128,7 +128,7 @@ struct sb_solver {
     sbk::PosView pos_view() const { return sbk::PosView{d_pos3.p, d_wf.p}; }
     DevBuf<float> d_prev, d_vel;
     DevBuf<sbk::TickParams> d_tp;
-    DevBuf<float4> d_sendbuf, d_recvbuf;
+    DevBuf<float> d_sendbuf, d_recvbuf;   // 3 (slot 1: 6) floats per ghost, peers back to back
     DevTiling tiling[2];
     std::vector<std::unique_ptr<DevGColour>> gcolours;
     std::vector<std::unique_ptr<DevHalo>> halos;   // indexed by halo slot
@@ -389,16 +389,16 @@ void build_device(sb_solver *s) {
             D->send_off.push_back((int32_t)sidx.size()); D->recv_off.push_back((int32_t)ridx.size());
         }
         D->send_idx.upload(sidx, s->dev_bytes); D->recv_idx.upload(ridx, s->dev_bytes);
-        const size_t mult = slot == 1 ? 2 : 1;   // slot 1 also carries previous positions
-        max_send = std::max(max_send, sidx.size() * mult); max_recv = std::max(max_recv, ridx.size() * mult);
+        const size_t fl = slot == 1 ? 6 : 3;   // floats per ghost (slot 1 also carries previous positions)
+        max_send = std::max(max_send, sidx.size() * fl); max_recv = std::max(max_recv, ridx.size() * fl);
         s->halos.push_back(std::move(D));
     }
     s->d_sendbuf.alloc(max_send, s->dev_bytes);
     s->d_recvbuf.alloc(max_recv, s->dev_bytes);
 }
 
-// Ghost refresh for one halo slot. Buffers hold every peer's particles back to back (slot 1: {position, previous
-// position} pairs), so each peer gets exactly one message per direction.
+// Ghost refresh for one halo slot. Buffers hold every peer's particles back to back (3 floats each, slot 1: 6 with the
+// previous position), so each peer gets exactly one message per direction.
 void halo_exchange(sb_solver *s, int slot, hipStream_t st = nullptr) {
     if (!st) st = s->stream;
     if (slot < 0 || slot >= (int)s->halos.size()) return;
@@ -419,9 +419,9 @@ void halo_exchange(sb_solver *s, int slot, hipStream_t st = nullptr) {
     for (size_t k = 0; k < D.peers.size(); ++k) {
         int cs = D.send_off[k + 1] - D.send_off[k], cr = D.recv_off[k + 1] - D.recv_off[k];
         if (s->loopback) cs = cr = std::min(cs, cr);   // a self-exchange must post equal sizes (real peers always do)
-        const size_t m = with_prev ? 2 : 1;   // float4 per particle; one message per peer and direction
-        if (cs) NCCL_CHECK(ncclSend(s->d_sendbuf.p + m * D.send_off[k], m * (size_t)cs * 4, ncclFloat, s->loopback ? 0 : D.peers[k], s->comm, st));
-        if (cr) NCCL_CHECK(ncclRecv(s->d_recvbuf.p + m * D.recv_off[k], m * (size_t)cr * 4, ncclFloat, s->loopback ? 0 : D.peers[k], s->comm, st));
+        const size_t fl = with_prev ? 6 : 3;   // floats per ghost; one message per peer and direction
+        if (cs) NCCL_CHECK(ncclSend(s->d_sendbuf.p + fl * D.send_off[k], fl * (size_t)cs, ncclFloat, s->loopback ? 0 : D.peers[k], s->comm, st));
+        if (cr) NCCL_CHECK(ncclRecv(s->d_recvbuf.p + fl * D.recv_off[k], fl * (size_t)cr, ncclFloat, s->loopback ? 0 : D.peers[k], s->comm, st));
     }
     NCCL_CHECK(ncclGroupEnd());
     if (nr) {
@@ -855,7 +855,7 @@ int sb_debug_halo_pack(sb_solver *s, int32_t slot, float *host_out, int64_t capa
         flush_deferred(s);
         DevHalo &D = *s->halos[slot];
         const int ns = D.send_off.back();
-        const int64_t need = (int64_t)ns * 4 * (slot == 1 ? 2 : 1);
+        const int64_t need = (int64_t)ns * (slot == 1 ? 6 : 3);
         *count_floats = need;
         if (need == 0) return SB_OK;
         if (!host_out || capacity_floats < need) return fail(SB_ERR_INVALID_ARG, "sb_debug_halo_pack: buffer too small");
@@ -879,7 +879,7 @@ int sb_debug_halo_unpack(sb_solver *s, int32_t slot, const float *host_in, int64
         int rc = set_device(s); if (rc) return rc;
         DevHalo &D = *s->halos[slot];
         const int nr = D.recv_off.back();
-        const int64_t need = (int64_t)nr * 4 * (slot == 1 ? 2 : 1);
+        const int64_t need = (int64_t)nr * (slot == 1 ? 6 : 3);
         if (count_floats != need) return fail(SB_ERR_INVALID_ARG, "sb_debug_halo_unpack: wrong element count");
         if (need == 0) return SB_OK;
         if (!host_in) return fail(SB_ERR_INVALID_ARG, "sb_debug_halo_unpack: null buffer");

@@ -83,29 +83,29 @@ def _hosted_worker(rank, world, port, tile, mesh_kind, out_dir):
     tiling = sb.stats()["n_tilings"] == 2
 
     def exchange(slot):
-        blocks = 2 if slot == 1 else 1
+        fl = 6 if slot == 1 else 3       # floats per ghost on the wire
         peers = sorted(halos[slot].keys())
         ns = sum(len(halos[slot][p][0]) for p in peers); nr = sum(len(halos[slot][p][1]) for p in peers)
-        sendbuf = np.zeros(max(ns * 4 * blocks, 1), np.float32)
+        sendbuf = np.zeros(max(ns * fl, 1), np.float32)
         cnt = C.c_int64()
         native.check(L.sb_debug_halo_pack(sb._h, slot, native.ptr(sendbuf), sendbuf.size, C.byref(cnt)))
-        assert cnt.value == ns * 4 * blocks
-        recvbuf = np.zeros(max(nr * 4 * blocks, 1), np.float32)
+        assert cnt.value == ns * fl
+        recvbuf = np.zeros(max(nr * fl, 1), np.float32)
         ops, so, ro = [], 0, 0
         keep = []
-        for p in peers:      # wire layout: one contiguous segment per peer, `blocks` float4 per particle
+        for p in peers:      # wire layout: one contiguous segment per peer
             cs, cr = len(halos[slot][p][0]), len(halos[slot][p][1])
             if cs:
-                t = torch.from_numpy(sendbuf[so * 4 * blocks:(so + cs) * 4 * blocks].copy()); keep.append(t)
+                t = torch.from_numpy(sendbuf[so * fl:(so + cs) * fl].copy()); keep.append(t)
                 ops.append(dist.P2POp(dist.isend, t, p))
             if cr:
-                t = torch.from_numpy(recvbuf[ro * 4 * blocks:(ro + cr) * 4 * blocks])
+                t = torch.from_numpy(recvbuf[ro * fl:(ro + cr) * fl])
                 ops.append(dist.P2POp(dist.irecv, t, p))
             so += cs; ro += cr
         if ops:
             for w in dist.batch_isend_irecv(ops):
                 w.wait()
-        native.check(L.sb_debug_halo_unpack(sb._h, slot, native.ptr(recvbuf), nr * 4 * blocks))
+        native.check(L.sb_debug_halo_unpack(sb._h, slot, native.ptr(recvbuf), nr * fl))
 
     for _ in range(2):
         for it in range(S + 1):
