@@ -138,8 +138,8 @@ def main():
     if rank == 0:
         G = stats["n_global_colours"]
         owned = stats["n_particles_owned"]
-        names = ["tile_kernel<1> on T0 (cross + velocity/integrate + full)",
-                 "tile_kernel<1> on T1 (cross + velocity/integrate + full)"]
+        names = ["tile_kernel<1> on T0 (rounds + collide/velocity/integrate + rounds)",
+                 "tile_kernel<1> on T1 (rounds + collide/velocity/integrate + rounds)"]
         names += [f"global colour {c}" for c in range(G)]
         names += ["tile_kernel<0> (first kernel of a tick)", "tile_kernel<2> (last kernel of a tick)"]
         # ALGORITHMIC bytes per launch: a mid-tick tile kernel does one velocity update (36 B)

@@ -115,7 +115,7 @@ int sb_profile_begin(sb_solver *s);
 int sb_profile_end(sb_solver *s, float *elapsed_ms_out);
 int sb_synchronize(sb_solver *s);
 /* One tick launched eagerly with a HIP-event pair around every kernel launch on the solver's stream.
- * Slots: 0 / 1 = mid-tick tile kernels on tiling T0 / T1 (cross + velocity/integrate + full),
+ * Slots: 0 / 1 = mid-tick tile kernels on tiling T0 / T1 (rounds + velocity/integrate + rounds),
  * 2+c = global colour c, 2+G = the first kernel of the tick, 3+G = the last (G = n_global_colours).
  * n_slots must be 4 + n_global_colours (sb_get_stats). Same results as sb_step. */
 int sb_step_profiled(sb_solver *s, float dt, int32_t substeps, float *slot_ms_out, int32_t *slot_launches_out,
@@ -152,7 +152,7 @@ typedef struct {
     int32_t tile_particles;
 } sb_plan_opts;
 typedef struct {
-    int32_t kind;               /* 0 = global colour, 1 = full part of a tiling's tiles, 2 = cross part */
+    int32_t kind;               /* 0 = global colour, 1 = a tiling's tiles, first phase of the substep, 2 = the other tiling's tiles, last phase */
     int32_t type;               /* kind 0: constraint type 0/1/2; else -1 */
     int32_t tiling;             /* kind 1/2: 0 or 1; kind 0: -1 */
     int32_t halo_slot;          /* -1 none; 1 = before the T1 tile kernel; 2+c = before global colour c */

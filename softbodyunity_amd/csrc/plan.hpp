@@ -71,7 +71,7 @@ struct GColour {            // one global colour: constraints of one type that s
 };
 
 struct Phase {              // one entry of a parity's phase list (inspection / oracle task parallelism)
-    int kind;               // 0 global colour, 1 full(T_p), 2 cross(T_1-p)
+    int kind;               // 0 global colour, 1 = S_p on T_p's tiles (first in the substep), 2 = S_(1-p) on T_(1-p)'s tiles (last)
     int type;               // kind 0: constraint type, else -1
     int tiling;             // kind 1/2: which tiling's tiles; kind 0: -1
     int gcolour;            // kind 0: index into Plan::gcolours

@@ -30,7 +30,7 @@ class RankSim:
     """One rank of the partitioned oracle: full-size arrays, only local entries meaningful.
 
     Mirrors the GPU kernel sequence of one tick: kernel K_s runs on tiling T_(s&1) and does
-    cross(T) of substep s-1, the velocity update + integrate, full(T) of substep s; the global colours of
+    S_T (the tiling's constraint list) for substep s-1, the velocity update + integrate, S_T again for substep s; the global colours of
     substep s follow. Ghosts are refreshed before every T1 kernel (slot 1: x and xprev) and before every
     cut global colour (slot 2+c: x)."""
 
@@ -93,12 +93,12 @@ def run_tick(ranks, s, substeps, tiling_on, exchange):
             exchange(1, True)
         for R in ranks:
             if it > 0:
-                R.project(s, (it - 1) & 1, kinds=(2,), tiling=tl)   # cross(T_tl) finishes substep it-1
+                R.project(s, (it - 1) & 1, kinds=(2,), tiling=tl)   # S_tl finishes substep it-1
                 R.o.collide()
                 R.o.velocity(s)
             if it < substeps:
                 R.o.integrate(s)
-                R.project(s, it & 1, kinds=(1,), tiling=tl)         # full(T_tl) starts substep it
+                R.project(s, it & 1, kinds=(1,), tiling=tl)         # S_tl starts substep it
         if it == substeps:
             break
         n_g = len(ranks[0].gcolour_phases(it & 1))
