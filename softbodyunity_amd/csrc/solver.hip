@@ -7,6 +7,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -70,13 +71,13 @@ struct DevHalo {                 // one halo slot: who we talk to and which part
 struct DevTiling {
     int32_t n_tiles = 0;
     size_t lds_bytes = 0;
-    int64_t n_slots = 0;         // constraint slots stored (cross + full)
+    int64_t n_slots = 0;         // constraints stored in the tile streams
     int32_t max_local = 0, win_dwords = 4, pal_dwords = 0;
     int32_t n_boundary = 0;      // T0 with world > 1: the first n_boundary tiles hold every particle some peer needs
     bool has_quads = false;
     DevBuf<sbk::TileDesc> tiles;
     DevBuf<int2> runs_overflow;
-    DevBuf<uint32_t> stream;     // per tile: [round words][cross data][full data], see kernels.hip.hpp
+    DevBuf<uint32_t> stream;     // per tile: [round words][rest-length dictionary][round data], see kernels.hip.hpp
 };
 
 struct DevGColour {
@@ -134,12 +135,14 @@ struct sb_solver {
     std::vector<std::unique_ptr<DevHalo>> halos;   // indexed by halo slot
     sbk::TickParams tp_host{};
     bool tp_valid = false;
-    std::map<int, hipGraphExec_t> graphs;      // key = substeps * 2 + (1 if the tick starts with the fused kernel)
+    std::map<int, hipGraphExec_t> graphs;      // key = substeps * 4 + (1: tick starts with the fused kernel) + (2: last kernel deferred)
     // Lazy tick boundary: the last kernel of a tick (rounds + collide + velocity write) is deferred; if the next tick
     // has the same parameters it is FUSED with that tick's first kernel into one ordinary mid-tick kernel, otherwise
     // (or whenever state is read or written) it is flushed first. Results are identical either way.
     bool deferred = false;
     int deferred_substeps = 0;
+    bool lazy_tick = true;           // SB_NO_LAZY_TICK unset (read once in sb_create)
+    bool graph_rccl = false;         // SB_GRAPH_RCCL set: capture the RCCL calls of a multi-rank tick in the hipGraph
     std::vector<float> h_stage;
     // asynchronous render readback (sb_readback_begin / sb_readback_end): two snapshot slots
     hipStream_t copy_stream = nullptr;
@@ -615,6 +618,8 @@ int sb_create(const sb_desc *desc, sb_solver **out) {
         HIP_CHECK(hipSetDevice(d.device));
         auto s = std::make_unique<sb_solver>();
         s->desc = d;
+        s->lazy_tick = !std::getenv("SB_NO_LAZY_TICK");
+        s->graph_rccl = std::getenv("SB_GRAPH_RCCL") != nullptr;
         HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreate(&s->ev0));
         HIP_CHECK(hipEventCreate(&s->ev1));
@@ -768,13 +773,13 @@ int sb_step(sb_solver *s, float dt, int32_t substeps) {
         int rc = set_device(s); if (rc) return rc;
         // lazy tick boundary: fuse with the previous tick's deferred last kernel when nothing changed
         const sbk::TickParams tp_new = tick_params(s, dt, substeps);
-        const bool can_defer = !s->overlap_halo && !std::getenv("SB_NO_LAZY_TICK") && (!s->plan->plan.tiling || (substeps & 1) == 0);
+        const bool can_defer = !s->overlap_halo && s->lazy_tick && (!s->plan->plan.tiling || (substeps & 1) == 0);
         const bool fuse = s->deferred && can_defer && s->deferred_substeps == substeps && s->tp_valid &&
                           std::memcmp(&tp_new, &s->tp_host, sizeof(tp_new)) == 0;
         if (!fuse) flush_deferred(s);
         upload_tick_params(s, dt, substeps);
         // world > 1: RCCL send/recv inside a captured graph is opt-in (SB_GRAPH_RCCL=1), see DESIGN.md §7
-        const bool graph_ok = s->desc.use_graph && !s->overlap_halo && (s->desc.world == 1 || std::getenv("SB_GRAPH_RCCL"));
+        const bool graph_ok = s->desc.use_graph && !s->overlap_halo && (s->desc.world == 1 || s->graph_rccl);
         if (!graph_ok) {
             enqueue_substeps(s, substeps, nullptr, fuse, can_defer);
         } else {
