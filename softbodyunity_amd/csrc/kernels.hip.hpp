@@ -194,7 +194,17 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
     // the tile tables are never written by a kernel: read the descriptor through the constant address space so it
     // stays on the scalar-memory path (s_load), one wide read
     typedef const TileDesc __attribute__((address_space(4))) *ConstTileDescPtr;
-    const TileDesc __attribute__((address_space(4))) &td = *((ConstTileDescPtr)(uintptr_t)A.tiles + (A.tile_base + blockIdx.x));
+    // Workgroups are dealt round-robin over the 8 XCDs (observed, MI355X_MICROARCH.md §Workgroup dispatch; speed only):
+    // give each XCD a contiguous range of tiles, so that neighbouring tiles -- whose runs meet inside a 128-byte line
+    // wherever a T1 tile's pieces of one T0 tile lie side by side -- read and write those lines through the same L2.
+#ifndef SB_NO_XCD_REMAP
+    const int nwg = (int)gridDim.x, wg = (int)blockIdx.x;
+    const int xq = nwg >> 3, xr = nwg & 7, xcd = wg & 7;
+    const int tile_index = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wg >> 3);
+#else
+    const int tile_index = (int)blockIdx.x;
+#endif
+    const TileDesc __attribute__((address_space(4))) &td = *((ConstTileDescPtr)(uintptr_t)A.tiles + (A.tile_base + tile_index));
     const int n_rounds_all = td.n_rounds;
     const int tid = threadIdx.x;
     const int n_local = td.n_local;

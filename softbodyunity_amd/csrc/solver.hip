@@ -142,6 +142,7 @@ struct sb_solver {
     bool deferred = false;
     int deferred_substeps = 0;
     bool lazy_tick = true;           // SB_NO_LAZY_TICK unset (read once in sb_create)
+    bool pack_tiles = true;          // SB_NO_PACK unset: under-full tiles share a workgroup (build_device)
     bool graph_rccl = false;         // SB_GRAPH_RCCL set: capture the RCCL calls of a multi-rank tick in the hipGraph
     std::vector<float> h_stage;
     // asynchronous render readback (sb_readback_begin / sb_readback_end): two snapshot slots
@@ -264,6 +265,61 @@ void build_device(sb_solver *s) {
             }
             LT = R;
         }
+        // Packing: a tile is only a set of particles whose own constraints are projected in LDS, so several under-full
+        // plan tiles (the rim of the shifted grid, surface cells of an irregular mesh) can share one workgroup: their
+        // particles are staged side by side and round r of the pack is the union of the members' next rounds of one
+        // type. Members share no particle and keep their own round order, so the result is bit-identical to running
+        // them one after the other (the published order); only the number of workgroups changes.
+        const size_t n_plan_tiles = LT.tile_ids.size();
+        int32_t plan_max_local = 0;
+        for (size_t ci = 0; ci < n_plan_tiles; ++ci) plan_max_local = std::max(plan_max_local, G.tiles[LT.tile_ids[ci]].n_local);
+        const int capacity = plan_max_local <= 2 * sbk::kTileThreads ? 2 * sbk::kTileThreads : sbk::kMaxPPT * sbk::kTileThreads;
+        std::vector<std::vector<int32_t>> packs;      // members (indices into LT.tile_ids), in execution order
+        {
+            std::vector<int32_t> pack_of(n_plan_tiles, -1), cand;
+            auto cls = [&](int32_t ci) { return ci < D.n_boundary ? 0 : 1; };
+            auto size_of = [&](int32_t ci) { return G.tiles[LT.tile_ids[ci]].n_local; };
+            auto runs_of = [&](int32_t ci) { return LT.run_begin[ci + 1] - LT.run_begin[ci]; };
+            if (s->pack_tiles)
+                for (size_t ci = 0; ci < n_plan_tiles; ++ci)
+                    if (size_of((int32_t)ci) < capacity && runs_of((int32_t)ci) <= sbk::kInlineRuns) cand.push_back((int32_t)ci);
+            std::sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) {
+                if (cls(a) != cls(b)) return cls(a) < cls(b);
+                if (size_of(a) != size_of(b)) return size_of(a) > size_of(b);
+                return a < b;
+            });
+            struct Bin { int32_t fill, runs, members; };
+            std::vector<Bin> bins;
+            std::vector<std::vector<int32_t>> open((size_t)capacity + 1);   // open[r]: bins of the current class with r free slots
+            int cur_cls = -1;
+            for (int32_t ci : cand) {     // best fit, largest first
+                if (cls(ci) != cur_cls) { for (auto &o : open) o.clear(); cur_cls = cls(ci); }
+                int32_t chosen = -1;
+                for (int r = size_of(ci); r <= capacity && chosen < 0; ++r)
+                    for (size_t k = open[r].size(); k-- > 0;) {
+                        const Bin &B = bins[open[r][k]];
+                        if (B.runs + runs_of(ci) <= sbk::kInlineRuns && B.members < 16) {
+                            chosen = open[r][k];
+                            open[r].erase(open[r].begin() + (std::ptrdiff_t)k);
+                            break;
+                        }
+                    }
+                if (chosen < 0) { chosen = (int32_t)bins.size(); bins.push_back({0, 0, 0}); }
+                Bin &B = bins[chosen];
+                B.fill += size_of(ci); B.runs += runs_of(ci); ++B.members;
+                open[capacity - B.fill].push_back(chosen);
+                pack_of[ci] = chosen;
+            }
+            std::vector<int32_t> slot_of_bin(bins.size(), -1);
+            int32_t n_boundary_packs = 0;
+            for (size_t ci = 0; ci < n_plan_tiles; ++ci) {
+                if (pack_of[ci] < 0) { packs.push_back({(int32_t)ci}); }
+                else if (slot_of_bin[pack_of[ci]] < 0) { slot_of_bin[pack_of[ci]] = (int32_t)packs.size(); packs.push_back({(int32_t)ci}); }
+                else { packs[slot_of_bin[pack_of[ci]]].push_back((int32_t)ci); continue; }
+                if ((int32_t)ci < D.n_boundary) ++n_boundary_packs;
+            }
+            D.n_boundary = n_boundary_packs;
+        }
         std::vector<sbk::TileDesc> tiles;
         std::vector<int2> overflow;
         std::vector<uint32_t> stream;
@@ -271,40 +327,89 @@ void build_device(sb_solver *s) {
         uint32_t max_data = 4;
         bool any_palette = false;
         auto fbits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
-        for (size_t ci = 0; ci < LT.tile_ids.size(); ++ci) {
-            const sbp::Tile &T = G.tiles[LT.tile_ids[ci]];
+        struct Part { int32_t member, cnt; int64_t first; };             // a member's round inside a pack round
+        struct PackRound { int type; int32_t cnt; std::vector<Part> parts; };
+        std::vector<PackRound> prog;
+        for (const std::vector<int32_t> &members : packs) {
             sbk::TileDesc td{};
-            td.n_local = T.n_local;
-            td.run_count = LT.run_begin[ci + 1] - LT.run_begin[ci];
             td.run_overflow = (int32_t)overflow.size();
-            int32_t lstart = 0;
-            for (int32_t r = 0; r < td.run_count; ++r) {
-                const sbp::Run &rn = LT.runs[LT.run_begin[ci] + r];
-                if (r < sbk::kInlineRuns) td.runs[r] = make_int2(rn.start, lstart);
-                else overflow.push_back(make_int2(rn.start, lstart));
-                lstart += rn.len;
+            std::vector<int32_t> base(members.size());
+            int32_t lstart = 0, n_runs = 0;
+            int64_t n_dist = 0, n_cons = 0;
+            for (size_t m = 0; m < members.size(); ++m) {
+                const int32_t ci = members[m];
+                const sbp::Tile &T = G.tiles[LT.tile_ids[ci]];
+                base[m] = lstart;
+                for (int32_t r = LT.run_begin[ci]; r < LT.run_begin[ci + 1]; ++r, ++n_runs) {
+                    const sbp::Run &rn = LT.runs[r];
+                    if (n_runs < sbk::kInlineRuns) td.runs[n_runs] = make_int2(rn.start, lstart);
+                    else overflow.push_back(make_int2(rn.start, lstart));
+                    lstart += rn.len;
+                }
+                if (lstart - base[m] != T.n_local) throw std::runtime_error("internal: tile run lengths do not add up");
+                n_dist += T.d_end - T.d_begin;
+                n_cons += (T.d_end - T.d_begin) + (T.q_end - T.q_begin);
             }
-            if (lstart != T.n_local) throw std::runtime_error("internal: tile run lengths do not add up");
-            max_local = std::max(max_local, T.n_local);
-            td.n_rounds = T.n_rounds;
-            if (stream.size() > 0xfffffff0ull - 4ull * (size_t)(T.d_end - T.d_begin + T.q_end - T.q_begin))
+            td.n_local = lstart;
+            td.run_count = n_runs;
+            if (lstart > sbk::kMaxPPT * sbk::kTileThreads) throw std::runtime_error("internal: packed tile too large");
+            max_local = std::max(max_local, lstart);
+            // the pack's program: zip the members' round lists (same type, at most 256 constraints per round)
+            prog.clear();
+            {
+                std::vector<int32_t> next(members.size(), 0);
+                std::vector<int64_t> dk(members.size()), qk(members.size());
+                for (size_t m = 0; m < members.size(); ++m) {
+                    const sbp::Tile &T = G.tiles[LT.tile_ids[members[m]]];
+                    dk[m] = T.d_begin; qk[m] = T.q_begin;
+                }
+                for (;;) {
+                    int type = 4;     // every member lists its distance rounds first, then volume, then bending: lowest type first
+                    for (size_t m = 0; m < members.size(); ++m) {
+                        const sbp::Tile &T = G.tiles[LT.tile_ids[members[m]]];
+                        if (next[m] < T.n_rounds) type = std::min(type, (int)((G.rounds[T.round_begin + next[m]] >> 10) & 3u));
+                    }
+                    if (type == 4) break;
+                    PackRound R{type, 0, {}};
+                    for (size_t m = 0; m < members.size(); ++m) {
+                        const sbp::Tile &T = G.tiles[LT.tile_ids[members[m]]];
+                        if (next[m] >= T.n_rounds) continue;
+                        const uint32_t w = G.rounds[T.round_begin + next[m]];
+                        const int32_t cnt = (int32_t)(w & 1023u);
+                        if ((int)((w >> 10) & 3u) != type || R.cnt + cnt > sbp::kRoundThreads) continue;
+                        int64_t &k = type == 0 ? dk[m] : qk[m];
+                        R.parts.push_back({(int32_t)m, cnt, k});
+                        k += cnt; R.cnt += cnt; ++next[m];
+                    }
+                    prog.push_back(std::move(R));
+                }
+                for (size_t m = 0; m < members.size(); ++m) {
+                    const sbp::Tile &T = G.tiles[LT.tile_ids[members[m]]];
+                    if (dk[m] != T.d_end || qk[m] != T.q_end) throw std::runtime_error("internal: tile stream does not match its rounds");
+                }
+            }
+            td.n_rounds = (int32_t)prog.size();
+            if (stream.size() > 0xfffffff0ull - 4ull * (size_t)n_cons - 4ull * prog.size() - 1024ull)
                 throw std::runtime_error("tile constraint stream exceeds 2^32 dwords");
             td.s_begin = (uint32_t)stream.size();
             const size_t s0 = stream.size();
             // dictionary-code the rest lengths of this tile's distance constraints when few values repeat
             std::vector<uint32_t> pal;
-            bool compact = !std::getenv("SB_NO_PALETTE") && T.d_end > T.d_begin;
+            bool compact = !std::getenv("SB_NO_PALETTE") && n_dist > 0;
             if (compact) {
                 std::vector<uint32_t> vals;
-                vals.reserve((size_t)(T.d_end - T.d_begin));
-                for (int64_t k = T.d_begin; k < T.d_end; ++k) vals.push_back(fbits(s->dist_rest[G.t_dist_id[k]]));
+                vals.reserve((size_t)n_dist);
+                for (int32_t ci : members) {
+                    const sbp::Tile &T = G.tiles[LT.tile_ids[ci]];
+                    for (int64_t k = T.d_begin; k < T.d_end; ++k) vals.push_back(fbits(s->dist_rest[G.t_dist_id[k]]));
+                }
                 std::sort(vals.begin(), vals.end());
                 vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
-                if ((int)vals.size() <= sbk::kMaxPalette && T.n_local <= 4096) pal = vals; else compact = false;
+                if ((int)vals.size() <= sbk::kMaxPalette && td.n_local <= 4096) pal = vals; else compact = false;
             }
-            for (int32_t r = 0; r < T.n_rounds; ++r) {
-                uint32_t w = G.rounds[T.round_begin + r];
-                if (compact && ((w >> 10) & 7u) == 0) w |= 4u << 10;     // distance -> dictionary-coded distance
+            for (const PackRound &R : prog) {
+                uint32_t w = (uint32_t)R.cnt | ((uint32_t)R.type << 10);
+                if (compact && R.type == 0) w |= 4u << 10;     // distance -> dictionary-coded distance
                 stream.push_back(w);
             }
             while ((stream.size() - s0) & 3) stream.push_back(0);
@@ -314,33 +419,32 @@ void build_device(sb_solver *s) {
             while ((stream.size() - s0) & 3) stream.push_back(0);
             if (!pal.empty()) any_palette = true;
             td.s_hdr = (uint32_t)(stream.size() - s0);
-            int64_t dk = T.d_begin, qk = T.q_begin;
-            for (int32_t r = 0; r < T.n_rounds; ++r) {
-                const uint32_t w = G.rounds[T.round_begin + r];
-                const int cnt = w & 1023u, type = (w >> 10) & 3u;
-                if (type == 0) {
-                    for (int k = 0; k < cnt; ++k, ++dk) {
-                        const uint32_t idx = G.t_dist[dk], rb = fbits(s->dist_rest[G.t_dist_id[dk]]);
-                        if (compact) {
-                            const uint32_t pi = (uint32_t)(std::lower_bound(pal.begin(), pal.end(), rb) - pal.begin());
-                            stream.push_back((idx & 0xffffu) | ((idx >> 16) << 12) | (pi << 24));
-                        } else {
-                            stream.push_back(idx);
-                            stream.push_back(rb);
+            for (const PackRound &R : prog) {
+                for (const Part &pt : R.parts) {
+                    const uint32_t b = (uint32_t)base[pt.member], b2 = b | (b << 16);   // added to both 16-bit local indices
+                    if (R.type == 0) {
+                        for (int64_t k = pt.first; k < pt.first + pt.cnt; ++k) {
+                            const uint32_t idx = G.t_dist[k] + b2, rb = fbits(s->dist_rest[G.t_dist_id[k]]);
+                            if (compact) {
+                                const uint32_t pi = (uint32_t)(std::lower_bound(pal.begin(), pal.end(), rb) - pal.begin());
+                                stream.push_back((idx & 0xffffu) | ((idx >> 16) << 12) | (pi << 24));
+                            } else {
+                                stream.push_back(idx);
+                                stream.push_back(rb);
+                            }
+                        }
+                    } else {
+                        D.has_quads = true;
+                        for (int64_t k = pt.first; k < pt.first + pt.cnt; ++k) {
+                            stream.push_back(G.t_quad[2 * k] + b2); stream.push_back(G.t_quad[2 * k + 1] + b2);
+                            const int32_t id = G.t_quad_id[k];
+                            if (G.t_quad_type[k] == 1) { volatile float r6 = 6.0f * s->vol_rest[id]; stream.push_back(fbits(r6)); stream.push_back(0); }
+                            else { stream.push_back(fbits(s->bend_rest[2 * (size_t)id])); stream.push_back(fbits(s->bend_rest[2 * (size_t)id + 1])); }
                         }
                     }
-                    while ((stream.size() - s0) & 3) stream.push_back(0);
-                } else {
-                    D.has_quads = true;
-                    for (int k = 0; k < cnt; ++k, ++qk) {
-                        stream.push_back(G.t_quad[2 * qk]); stream.push_back(G.t_quad[2 * qk + 1]);
-                        const int32_t id = G.t_quad_id[qk];
-                        if (G.t_quad_type[qk] == 1) { volatile float r6 = 6.0f * s->vol_rest[id]; stream.push_back(fbits(r6)); stream.push_back(0); }
-                        else { stream.push_back(fbits(s->bend_rest[2 * (size_t)id])); stream.push_back(fbits(s->bend_rest[2 * (size_t)id + 1])); }
-                    }
                 }
+                if (R.type == 0) while ((stream.size() - s0) & 3) stream.push_back(0);
             }
-            if (dk != T.d_end || qk != T.q_end) throw std::runtime_error("internal: tile stream does not match its rounds");
             td.s_len = (uint32_t)(stream.size() - s0);
             max_data = std::max(max_data, td.s_len - td.s_hdr);
             tiles.push_back(td);
@@ -620,6 +724,7 @@ int sb_create(const sb_desc *desc, sb_solver **out) {
         s->desc = d;
         s->lazy_tick = !std::getenv("SB_NO_LAZY_TICK");
         s->graph_rccl = std::getenv("SB_GRAPH_RCCL") != nullptr;
+        s->pack_tiles = !std::getenv("SB_NO_PACK");
         HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreate(&s->ev0));
         HIP_CHECK(hipEventCreate(&s->ev1));

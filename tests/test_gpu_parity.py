@@ -64,7 +64,9 @@ def test_cfg2_cube64_20substeps(oracle_mod, tile, graph):
     assert rel <= TOL, (rel, mabs)
     assert bit, f"max abs diff {mabs}"
     if tile > 0:
-        assert st["n_tilings"] == 2 and st["n_global_colours"] == 0 and st["n_tiles"] == [512, 729]
+        # 8^3 aligned cells; 9^3 shifted cells of which the 386 partial rim cells share ~170 workgroups (tile packing)
+        assert st["n_tilings"] == 2 and st["n_global_colours"] == 0
+        assert st["n_tiles"][0] == 512 and 512 <= st["n_tiles"][1] <= 520
 
 
 def test_pinned_top_layer_and_damping_and_compliance(oracle_mod):
@@ -264,3 +266,25 @@ def test_lazy_tick_boundary_is_invisible(oracle_mod, monkeypatch):
     for dt, S, _ in plan_steps:
         o.step(dt, S)
     assert np.array_equal(xa.view(np.uint32), o.x.view(np.uint32)) and np.array_equal(va.view(np.uint32), o.v.view(np.uint32))
+
+
+def test_tile_packing_is_invisible(oracle_mod, bunny20k, monkeypatch):
+    # under-full tiles share a workgroup (solver.hip build_device); the members keep their own round order, so the
+    # bits must not depend on the packing -- irregular mesh with all three constraint types, and the lattice rim
+    def run(mesh, pack, **kw):
+        if pack:
+            monkeypatch.delenv("SB_NO_PACK", raising=False)
+        else:
+            monkeypatch.setenv("SB_NO_PACK", "1")
+        sb = Softbody(mesh, **kw).Start()
+        try:
+            for _ in range(2):
+                sb.step(0.02, 6)
+            return sb.get_positions().copy(), sb.get_velocities().copy(), sb.stats()["n_tiles"]
+        finally:
+            sb.OnDestroy()
+    for mesh, kw in ((bunny20k, dict(tile_particles=256, distance_compliance=1e-7, volume_compliance=1e-7, bending_compliance=1e-5)), (jelly_cube(24), dict())):
+        xa, va, ta = run(mesh, True, **kw)
+        xb, vb, tb = run(mesh, False, **kw)
+        assert sum(ta) < sum(tb), (ta, tb)
+        assert np.array_equal(xa.view(np.uint32), xb.view(np.uint32)) and np.array_equal(va.view(np.uint32), vb.view(np.uint32))
