@@ -66,14 +66,23 @@ struct TileArgs {
     const int2 *runs_overflow;
     const uint32_t *stream;
     const TickParams *tp;
-    int32_t max_local;        // LDS carve: [max_local float4][kMaxRoundsLds dwords][pal_dwords dwords][win_dwords dwords]
-    int32_t pal_dwords;       // 0 or kMaxPalette
+    int32_t max_local;        // LDS carve: [max_local float4][rounds_dwords][pal_dwords][win_dwords]
+    int32_t rounds_dwords;    // round words cached in LDS (multiple of 4, <= kMaxRoundsLds); longer programs read memory
+    int32_t pal_dwords;       // largest rest-length dictionary of the tiling, padded to 4 (0 = none)
     int32_t win_dwords;       // constraint window held in LDS (multiple of 4, >= the largest round)
     int32_t tile_base;        // this launch covers tiles tile_base + blockIdx.x (boundary / interior split)
 };
 
-constexpr int kTileThreads = 256;
-constexpr int kMaxPPT = 4;     // particles per lane (tile <= 1024 particles)
+// Lanes per tile (template parameter THREADS of tile_kernel). A round holds up to kRoundSlots independent constraints,
+// so a lane projects kRoundSlots / THREADS of them per round. Fewer waves per tile = more tiles resident per CU (the
+// wave slots, not LDS, cap a 256-lane workgroup at 8 tiles per CU; 128 lanes reach the 12-14 that LDS allows): +4.4 %
+// at 256^3. A launch whose tiles all fit on the chip at once is latency-bound instead and wants the wide workgroup
+// (64^3: 256 lanes are 22 % faster), so the host picks per launch (solver.hip launch_tile).
+constexpr int kNarrowTileThreads = 128;                     // small tiles, launches that oversubscribe the chip
+constexpr int kWideTileThreads = 256;                       // small tiles in latency-bound launches, and all large tiles
+constexpr int kRoundSlots = 256;                            // plan.hpp kRoundThreads
+constexpr int kSmallTile = 512, kLargeTile = 1024;          // the two particle capacities the kernels are built for
+typedef float f32x3 __attribute__((ext_vector_type(3)));
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));     // native vectors: one 16-byte load/store, no struct copies
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
@@ -111,6 +120,26 @@ __device__ __forceinline__ bool project_distance(float4 &a, float4 &b, float L0,
     a.x = a.x + ax; a.y = a.y + ay; a.z = a.z + az;
     b.x = b.x - bx; b.y = b.y - by; b.z = b.z - bz;
     return true;
+}
+
+// Same arithmetic without the early return (results of skipped constraints are simply not stored): lets the
+// compiler interleave the independent projections a lane performs in one round.
+__device__ __forceinline__ bool project_distance_nobranch(float4 &a, float4 &b, float L0, float at) {
+    float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
+    float xx = dx * dx, yy = dy * dy, zz = dz * dz;
+    float L2 = (xx + yy) + zz;
+    float L = sqrtf(L2);
+    float ws = (a.w + b.w) + at;
+    const bool ok = (L > 0.0f) && (ws > 0.0f);
+    float C = L - L0;
+    float wl = ws * L;
+    float s = (-C) / wl;
+    float si = a.w * s, sj = b.w * s;
+    float ax = si * dx, ay = si * dy, az = si * dz;
+    float bx = sj * dx, by = sj * dy, bz = sj * dz;
+    a.x = a.x + ax; a.y = a.y + ay; a.z = a.z + az;
+    b.x = b.x - bx; b.y = b.y - by; b.z = b.z - bz;
+    return ok;
 }
 
 // SPEC.md §5.
@@ -183,14 +212,18 @@ __device__ __forceinline__ bool project_bending(float4 &pa, float4 &pb, float4 &
 // __syncthreads() would also drain vmcnt, i.e. wait for the xprev stores of the MARK step.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
+// Register budget (HIP: second launch-bound = waves per SIMD). LDS allows ~14 tiles per CU, so aim for that many waves.
+template <bool QUADS, int THREADS> constexpr int kWavesPerSimd = QUADS ? (THREADS == 64 ? 3 : 4) : (THREADS == 256 ? 8 : (THREADS == 128 ? 6 : 4));
 // WPAL = inverse masses are read as one-byte palette indices (the palette entry comes from another lane by ds_bpermute).
-template <int KIND, bool QUADS, int PPT, bool WPAL>
-__global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileArgs A) {
+template <int KIND, bool QUADS, int THREADS, int PPT, bool WPAL>
+__global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile_kernel(TileArgs A) {
+    constexpr int kTileThreads = THREADS;
+    constexpr int kCPL = kRoundSlots / THREADS;       // constraints per lane per round
     extern __shared__ uint4 lds_raw[];
     float4 *lds_pos = reinterpret_cast<float4 *>(lds_raw);
     uint32_t *s_rounds = reinterpret_cast<uint32_t *>(lds_pos + A.max_local);
-    float *s_pal = reinterpret_cast<float *>(s_rounds + kMaxRoundsLds);
-    uint32_t *cbuf = s_rounds + kMaxRoundsLds + A.pal_dwords;
+    float *s_pal = reinterpret_cast<float *>(s_rounds + A.rounds_dwords);
+    uint32_t *cbuf = s_rounds + A.rounds_dwords + A.pal_dwords;
     // the tile tables are never written by a kernel: read the descriptor through the constant address space so it
     // stays on the scalar-memory path (s_load), one wide read
     typedef const TileDesc __attribute__((address_space(4))) *ConstTileDescPtr;
@@ -269,7 +302,7 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
         pvx[m] = pvy[m] = pvz[m] = 0.0f;
         if (KIND != 0) { pvx[m] = A.prev[3 * (size_t)gc + 0]; pvy[m] = A.prev[3 * (size_t)gc + 1]; pvz[m] = A.prev[3 * (size_t)gc + 2]; }
     }
-    const bool rounds_in_lds = n_rounds_all <= kMaxRoundsLds;
+    const bool rounds_in_lds = n_rounds_all <= A.rounds_dwords;
     const uint32_t rw = tstream[max(min(tid, n_rounds_all - 1), 0)];        // (an empty program still has a 16-byte header)
     // programs of at most 64 rounds: every wave also keeps round word `lane` in a register and reads it back with
     // v_readlane (no LDS round trip at the head of each round): +3 % at 64^3, +1 % at 256^3
@@ -278,7 +311,7 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
     const int n_pal = td.n_pal;
     // palette follows the round words; lanes without an entry re-read round word 0 (always inside the tile's stream)
     const uint32_t palw = tstream[tid < n_pal ? ((n_rounds_all + 3) & ~3) + tid : 0];
-    constexpr int kW = 4;    // uint4 per lane in the first sweep of the window (16 KiB); longer windows loop below
+    constexpr int kW = kCPL > 1 ? 8 : 4;   // uint4 per lane in the first sweep of the window; longer windows loop below
     const uint32_t n4_first = (min(win_lo + win, d_hi) - win_lo) >> 2;
     const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(tstream + win_lo);
     u32x4 wv[kW];
@@ -305,6 +338,10 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
         if (g[m] >= 0) *reinterpret_cast<f32x4 *>(lds_pos + tid + m * kTileThreads) = X[m];
     if (rounds_in_lds && tid < n_rounds_all) s_rounds[tid] = rw;
     if (tid < n_pal) s_pal[tid] = __uint_as_float(palw);
+    if (kTileThreads < kMaxRoundsLds && rounds_in_lds)
+        for (int q = tid + kTileThreads; q < n_rounds_all; q += kTileThreads) s_rounds[q] = tstream[q];
+    if (kTileThreads < kMaxPalette)
+        for (int q = tid + kTileThreads; q < n_pal; q += kTileThreads) s_pal[q] = __uint_as_float(tstream[((n_rounds_all + 3) & ~3) + q]);
     {
         u32x4 *dst = reinterpret_cast<u32x4 *>(cbuf);
 #pragma unroll
@@ -377,7 +414,7 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
                 __syncthreads();
             }
             const uint32_t *base = cbuf + (off - win_lo);
-            if (type == 0) {
+            if (kCPL == 1 && type == 0) {
                 if (tid < cnt) {
                     const uint2 e = *reinterpret_cast<const uint2 *>(base + 2 * tid);
                     const int i = e.x & 0xffffu, k = e.x >> 16;
@@ -389,7 +426,7 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
                     if (project_distance(a, b, __uint_as_float(e.y), tp.at_d)) { lds_pos[i] = a; lds_pos[k] = b; }
 #endif
                 }
-            } else if (type == 4) {
+            } else if (kCPL == 1 && type == 4) {
                 if (tid < cnt) {
                     const uint32_t e = base[tid];
                     const int i = e & 0xfffu, k = (e >> 12) & 0xfffu;
@@ -402,9 +439,53 @@ __global__ __launch_bounds__(kTileThreads, QUADS ? 4 : 8) void tile_kernel(TileA
                     if (project_distance(a, b, L0, tp.at_d)) { lds_pos[i] = a; lds_pos[k] = b; }
 #endif
                 }
+            } else if (type == 0 || type == 4) {
+                // kCPL independent constraints per lane: fetch all slots, gather all operands, project, scatter. Lanes
+                // past the end of the round re-read its first slot (always present) and drop the result.
+                int ci[kCPL], ck[kCPL];
+                float cL0[kCPL];
+                bool con[kCPL];
+                f32x4 ca[kCPL], cb[kCPL];
+                if (type == 0) {
+#pragma unroll
+                    for (int u = 0; u < kCPL; ++u) {
+                        const int c = tid + u * kTileThreads;
+                        con[u] = c < cnt;
+                        const uint2 e = *reinterpret_cast<const uint2 *>(base + 2 * (con[u] ? c : 0));
+                        ci[u] = e.x & 0xffffu; ck[u] = e.x >> 16; cL0[u] = __uint_as_float(e.y);
+                    }
+                } else {
+                    uint32_t ce[kCPL];
+#pragma unroll
+                    for (int u = 0; u < kCPL; ++u) {
+                        const int c = tid + u * kTileThreads;
+                        con[u] = c < cnt;
+                        ce[u] = base[con[u] ? c : 0];
+                    }
+#pragma unroll
+                    for (int u = 0; u < kCPL; ++u) { ci[u] = ce[u] & 0xfffu; ck[u] = (ce[u] >> 12) & 0xfffu; cL0[u] = s_pal[ce[u] >> 24]; }
+                }
+#pragma unroll
+                for (int u = 0; u < kCPL; ++u) {
+                    ca[u] = *reinterpret_cast<const f32x4 *>(lds_pos + ci[u]);
+                    cb[u] = *reinterpret_cast<const f32x4 *>(lds_pos + ck[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < kCPL; ++u) {
+                    float4 a = make_float4(ca[u].x, ca[u].y, ca[u].z, ca[u].w), b = make_float4(cb[u].x, cb[u].y, cb[u].z, cb[u].w);
+                    con[u] = project_distance_nobranch(a, b, cL0[u], tp.at_d) && con[u];
+                    ca[u].x = a.x; ca[u].y = a.y; ca[u].z = a.z; cb[u].x = b.x; cb[u].y = b.y; cb[u].z = b.z;
+                }
+#pragma unroll
+                for (int u = 0; u < kCPL; ++u)
+                    if (con[u]) {
+                        *reinterpret_cast<f32x3 *>(lds_pos + ci[u]) = (f32x3){ca[u].x, ca[u].y, ca[u].z};
+                        *reinterpret_cast<f32x3 *>(lds_pos + ck[u]) = (f32x3){cb[u].x, cb[u].y, cb[u].z};
+                    }
             } else if (QUADS) {
-                if (tid < cnt) {
-                    const uint4 e = *reinterpret_cast<const uint4 *>(base + 4 * tid);
+#pragma unroll 1
+                for (int c = tid; c < cnt; c += kTileThreads) {
+                    const uint4 e = *reinterpret_cast<const uint4 *>(base + 4 * c);
                     const int i0 = e.x & 0xffffu, i1 = e.x >> 16, i2 = e.y & 0xffffu, i3 = e.y >> 16;
                     const float2 rest = make_float2(__uint_as_float(e.z), __uint_as_float(e.w));
                     float4 p0 = lds_pos[i0], p1 = lds_pos[i1], p2 = lds_pos[i2], p3 = lds_pos[i3];

@@ -72,7 +72,7 @@ struct DevTiling {
     int32_t n_tiles = 0;
     size_t lds_bytes = 0;
     int64_t n_slots = 0;         // constraints stored in the tile streams
-    int32_t max_local = 0, win_dwords = 4, pal_dwords = 0;
+    int32_t max_local = 0, win_dwords = 4, pal_dwords = 0, rounds_dwords = 0;
     int32_t n_boundary = 0;      // T0 with world > 1: the first n_boundary tiles hold every particle some peer needs
     bool has_quads = false;
     DevBuf<sbk::TileDesc> tiles;
@@ -142,6 +142,8 @@ struct sb_solver {
     bool deferred = false;
     int deferred_substeps = 0;
     bool lazy_tick = true;           // SB_NO_LAZY_TICK unset (read once in sb_create)
+    int tile_lanes = 0;              // SB_TILE_LANES=128|256 forces the workgroup width of small tiles (0 = by launch size)
+    int narrow_min_tiles = 10240;    // SB_NARROW_MIN_TILES; measured crossover: 160^3 (8000 tiles) ties, 192^3 (13824) +4 % narrow
     bool pack_tiles = true;          // SB_NO_PACK unset: under-full tiles share a workgroup (build_device)
     bool graph_rccl = false;         // SB_GRAPH_RCCL set: capture the RCCL calls of a multi-rank tick in the hipGraph
     std::vector<float> h_stage;
@@ -273,7 +275,7 @@ void build_device(sb_solver *s) {
         const size_t n_plan_tiles = LT.tile_ids.size();
         int32_t plan_max_local = 0;
         for (size_t ci = 0; ci < n_plan_tiles; ++ci) plan_max_local = std::max(plan_max_local, G.tiles[LT.tile_ids[ci]].n_local);
-        const int capacity = plan_max_local <= 2 * sbk::kTileThreads ? 2 * sbk::kTileThreads : sbk::kMaxPPT * sbk::kTileThreads;
+        const int capacity = plan_max_local <= sbk::kSmallTile ? sbk::kSmallTile : sbk::kLargeTile;
         std::vector<std::vector<int32_t>> packs;      // members (indices into LT.tile_ids), in execution order
         {
             std::vector<int32_t> pack_of(n_plan_tiles, -1), cand;
@@ -325,7 +327,7 @@ void build_device(sb_solver *s) {
         std::vector<uint32_t> stream;
         int32_t max_local = 0;
         uint32_t max_data = 4;
-        bool any_palette = false;
+        int32_t max_pal = 0, max_rounds = 0;
         auto fbits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
         struct Part { int32_t member, cnt; int64_t first; };             // a member's round inside a pack round
         struct PackRound { int type; int32_t cnt; std::vector<Part> parts; };
@@ -352,7 +354,7 @@ void build_device(sb_solver *s) {
             }
             td.n_local = lstart;
             td.run_count = n_runs;
-            if (lstart > sbk::kMaxPPT * sbk::kTileThreads) throw std::runtime_error("internal: packed tile too large");
+            if (lstart > sbk::kLargeTile) throw std::runtime_error("internal: packed tile too large");
             max_local = std::max(max_local, lstart);
             // the pack's program: zip the members' round lists (same type, at most 256 constraints per round)
             prog.clear();
@@ -417,7 +419,8 @@ void build_device(sb_solver *s) {
             td.n_pal = (int32_t)pal.size();
             for (uint32_t v : pal) stream.push_back(v);
             while ((stream.size() - s0) & 3) stream.push_back(0);
-            if (!pal.empty()) any_palette = true;
+            max_pal = std::max(max_pal, (int32_t)pal.size());
+            max_rounds = std::max(max_rounds, td.n_rounds);
             td.s_hdr = (uint32_t)(stream.size() - s0);
             for (const PackRound &R : prog) {
                 for (const Part &pt : R.parts) {
@@ -453,8 +456,9 @@ void build_device(sb_solver *s) {
         D.max_local = std::max(max_local, 1);
         D.win_dwords = (int32_t)std::min<uint32_t>(max_data, 8192u);     // <= 32 KiB of LDS; >= one round (4 KiB)
         if (const char *e = std::getenv("SB_WIN_DWORDS")) D.win_dwords = std::max(1024, std::min(D.win_dwords, std::atoi(e)) & ~3);   // tuning experiments
-        D.pal_dwords = any_palette ? sbk::kMaxPalette : 0;
-        D.lds_bytes = (size_t)D.max_local * sizeof(float4) + sbk::kMaxRoundsLds * 4 + (size_t)D.pal_dwords * 4 + (size_t)D.win_dwords * 4;
+        D.pal_dwords = (max_pal + 3) & ~3;
+        D.rounds_dwords = std::min(sbk::kMaxRoundsLds, (max_rounds + 3) & ~3);
+        D.lds_bytes = (size_t)D.max_local * sizeof(float4) + (size_t)D.rounds_dwords * 4 + (size_t)D.pal_dwords * 4 + (size_t)D.win_dwords * 4;
         D.n_slots = 0;
         for (size_t ci = 0; ci < LT.tile_ids.size(); ++ci) {
             const sbp::Tile &T = G.tiles[LT.tile_ids[ci]];
@@ -549,17 +553,22 @@ void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = 
     A.pos = s->pos_view(); A.w8 = s->d_w8.p; A.wpal = s->d_wpal.p; A.prev = s->d_prev.p; A.vel = s->d_vel.p;
     A.tiles = D.tiles.p; A.runs_overflow = D.runs_overflow.p; A.stream = D.stream.p;
     A.tp = s->d_tp.p;
-    A.max_local = D.max_local; A.win_dwords = D.win_dwords; A.tile_base = tile_begin; A.pal_dwords = D.pal_dwords;
-    const dim3 grid(tile_end - tile_begin), block(sbk::kTileThreads);
-    const bool small = D.max_local <= 2 * sbk::kTileThreads;   // every tile <= 512 particles
-#define SB_LAUNCH_TILE(Q, P, W) hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, P, W>), grid, block, D.lds_bytes, s->stream, A)
-    if (s->w_palette) {
-        if (D.has_quads) { if (small) SB_LAUNCH_TILE(true, 2, true); else SB_LAUNCH_TILE(true, 4, true); }
-        else { if (small) SB_LAUNCH_TILE(false, 2, true); else SB_LAUNCH_TILE(false, 4, true); }
-    } else {
-        if (D.has_quads) { if (small) SB_LAUNCH_TILE(true, 2, false); else SB_LAUNCH_TILE(true, 4, false); }
-        else { if (small) SB_LAUNCH_TILE(false, 2, false); else SB_LAUNCH_TILE(false, 4, false); }
-    }
+    A.max_local = D.max_local; A.win_dwords = D.win_dwords; A.tile_base = tile_begin; A.pal_dwords = D.pal_dwords; A.rounds_dwords = D.rounds_dwords;
+    const bool small = D.max_local <= sbk::kSmallTile;   // every tile <= 512 particles
+    // narrow (2-wave) workgroups once the launch oversubscribes the chip; wide ones while every tile is resident at once
+    const bool narrow = small && (s->tile_lanes ? s->tile_lanes == sbk::kNarrowTileThreads : tile_end - tile_begin >= s->narrow_min_tiles);
+    const dim3 grid(tile_end - tile_begin), block(narrow ? sbk::kNarrowTileThreads : sbk::kWideTileThreads);
+#define SB_LAUNCH_TILE(Q, W)                                                                                                  \
+    do {                                                                                                                      \
+        if (narrow) hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kNarrowTileThreads, sbk::kSmallTile / sbk::kNarrowTileThreads, W>), \
+                                       grid, block, D.lds_bytes, s->stream, A);                                              \
+        else if (small) hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kWideTileThreads, sbk::kSmallTile / sbk::kWideTileThreads, W>), \
+                                           grid, block, D.lds_bytes, s->stream, A);                                          \
+        else hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kWideTileThreads, sbk::kLargeTile / sbk::kWideTileThreads, W>), \
+                                grid, block, D.lds_bytes, s->stream, A);                                                     \
+    } while (0)
+    if (s->w_palette) { if (D.has_quads) SB_LAUNCH_TILE(true, true); else SB_LAUNCH_TILE(false, true); }
+    else { if (D.has_quads) SB_LAUNCH_TILE(true, false); else SB_LAUNCH_TILE(false, false); }
 #undef SB_LAUNCH_TILE
 }
 
@@ -725,6 +734,8 @@ int sb_create(const sb_desc *desc, sb_solver **out) {
         s->lazy_tick = !std::getenv("SB_NO_LAZY_TICK");
         s->graph_rccl = std::getenv("SB_GRAPH_RCCL") != nullptr;
         s->pack_tiles = !std::getenv("SB_NO_PACK");
+        if (const char *e = std::getenv("SB_TILE_LANES")) s->tile_lanes = std::atoi(e) == 128 ? 128 : (std::atoi(e) == 256 ? 256 : 0);
+        if (const char *e = std::getenv("SB_NARROW_MIN_TILES")) s->narrow_min_tiles = std::max(1, std::atoi(e));
         HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreate(&s->ev0));
         HIP_CHECK(hipEventCreate(&s->ev1));
