@@ -288,3 +288,14 @@ def test_tile_packing_is_invisible(oracle_mod, bunny20k, monkeypatch):
         xb, vb, tb = run(mesh, False, **kw)
         assert sum(ta) < sum(tb), (ta, tb)
         assert np.array_equal(xa.view(np.uint32), xb.view(np.uint32)) and np.array_equal(va.view(np.uint32), vb.view(np.uint32))
+
+
+@pytest.mark.parametrize("lanes", ["128", "256"])
+def test_both_workgroup_widths_match_the_oracle(oracle_mod, bunny20k, monkeypatch, lanes):
+    # small tiles run as 256-lane workgroups (one constraint per lane and round) or, in launches of >= 10240 tiles,
+    # as 128-lane workgroups (two per lane): force each width on meshes the oracle finishes in seconds
+    monkeypatch.setenv("SB_TILE_LANES", lanes)
+    rel, mabs, bit, x, v, o, st = _run_pair(oracle_mod, jelly_cube(40), ticks=2, substeps=20, ground_plane=None)
+    assert bit and np.array_equal(v.view(np.uint32), o.v.view(np.uint32)), (rel, mabs)
+    rel, mabs, bit, x, v, o, st = _run_pair(oracle_mod, bunny20k, ticks=2, substeps=6, compliance=(1e-7, 1e-7, 1e-5), tile_particles=256)
+    assert bit and np.array_equal(v.view(np.uint32), o.v.view(np.uint32)), (rel, mabs)
