@@ -94,9 +94,9 @@ namespace SoftbodyMI355X
             float dx = (float)(x[i].x - x[j].x), dy = (float)(x[i].y - x[j].y), dz = (float)(x[i].z - x[j].z);
             float xx = (float)(dx * dx), yy = (float)(dy * dy), zz = (float)(dz * dz);
             float L2 = (float)((float)(xx + yy) + zz);
-            float L = (float)Math.Sqrt(L2);        // sqrt of a float in double, rounded to float == correctly rounded sqrtf
             float ws = (float)((float)(wi + wj) + at);
-            if (!(L > 0f) || !(ws > 0f)) return;
+            if (!(L2 >= 1.262177448e-29f) || !(ws > 0f)) return;   // 2^-96 (SPEC.md §4): coincident endpoints give no direction
+            float L = (float)Math.Sqrt(L2);        // sqrt of a float in double, rounded to float == correctly rounded sqrtf
             float C = (float)(L - L0);
             float wl = (float)(ws * L);
             float s = (float)((-C) / wl);

@@ -93,9 +93,9 @@ void orc_project_distance(float *x, const float *w, int i, int j, float L0, floa
     float dx = xi[0] - xj[0], dy = xi[1] - xj[1], dz = xi[2] - xj[2];
     float xx = dx * dx, yy = dy * dy, zz = dz * dz;
     float L2 = (xx + yy) + zz;
-    float L = sqrtf(L2);
     float ws = (wi + wj) + at;
-    if (!(L > 0.0f) || !(ws > 0.0f)) return;
+    if (!(L2 >= 0x1p-96f) || !(ws > 0.0f)) return;   /* SPEC.md §4: coincident endpoints give no direction */
+    float L = sqrtf(L2);
     float C = L - L0;
     float wl = ws * L;
     float s = (-C) / wl;

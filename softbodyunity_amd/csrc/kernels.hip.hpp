@@ -103,14 +103,29 @@ __device__ __forceinline__ V3 addscaled3(V3 x, float s, V3 g) {
 }
 __device__ __forceinline__ V3 xyz(float4 p) { return {p.x, p.y, p.z}; }
 
+// Correctly rounded sqrt for x >= 2^-96 (also right for +inf; NaN stays NaN): v_sqrt_f32 is good to 1 ulp, the two
+// residuals pick the neighbour when it is closer. This is the compiler's own sqrtf expansion without its rescaling
+// of tiny arguments and its special-case select (7 VALU instructions fewer per constraint); SPEC.md §4 skips the
+// constraints whose argument would need them.
+__device__ __forceinline__ float sqrt_rn_normal(float x) {
+#ifdef SB_LIBM_SQRT   // A/B timing builds only
+    return sqrtf(x);
+#endif
+    float s = __builtin_amdgcn_sqrtf(x);
+    float sd = __int_as_float(__float_as_int(s) - 1), su = __int_as_float(__float_as_int(s) + 1);
+    float rd = __builtin_fmaf(-sd, s, x), ru = __builtin_fmaf(-su, s, x);
+    s = rd <= 0.0f ? sd : s;
+    return ru > 0.0f ? su : s;
+}
+
 // SPEC.md §4. Returns false when the constraint is skipped.
 __device__ __forceinline__ bool project_distance(float4 &a, float4 &b, float L0, float at) {
     float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
     float xx = dx * dx, yy = dy * dy, zz = dz * dz;
     float L2 = (xx + yy) + zz;
-    float L = sqrtf(L2);
     float ws = (a.w + b.w) + at;
-    if (!(L > 0.0f) || !(ws > 0.0f)) return false;
+    if (!(L2 >= 0x1p-96f) || !(ws > 0.0f)) return false;
+    float L = sqrt_rn_normal(L2);
     float C = L - L0;
     float wl = ws * L;
     float s = (-C) / wl;
@@ -128,9 +143,9 @@ __device__ __forceinline__ bool project_distance_nobranch(float4 &a, float4 &b, 
     float dx = a.x - b.x, dy = a.y - b.y, dz = a.z - b.z;
     float xx = dx * dx, yy = dy * dy, zz = dz * dz;
     float L2 = (xx + yy) + zz;
-    float L = sqrtf(L2);
     float ws = (a.w + b.w) + at;
-    const bool ok = (L > 0.0f) && (ws > 0.0f);
+    const bool ok = (L2 >= 0x1p-96f) && (ws > 0.0f);
+    float L = sqrt_rn_normal(L2);
     float C = L - L0;
     float wl = ws * L;
     float s = (-C) / wl;

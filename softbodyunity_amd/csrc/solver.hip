@@ -144,6 +144,7 @@ struct sb_solver {
     bool lazy_tick = true;           // SB_NO_LAZY_TICK unset (read once in sb_create)
     int tile_lanes = 0;              // SB_TILE_LANES=128|256 forces the workgroup width of small tiles (0 = by launch size)
     int narrow_min_tiles = 10240;    // SB_NARROW_MIN_TILES; measured crossover: 160^3 (8000 tiles) ties, 192^3 (13824) +4 % narrow
+    size_t lds_pad = 0;              // SB_LDS_PAD bytes of unused LDS per workgroup (occupancy experiments)
     bool pack_tiles = true;          // SB_NO_PACK unset: under-full tiles share a workgroup (build_device)
     bool graph_rccl = false;         // SB_GRAPH_RCCL set: capture the RCCL calls of a multi-rank tick in the hipGraph
     std::vector<float> h_stage;
@@ -561,11 +562,11 @@ void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = 
 #define SB_LAUNCH_TILE(Q, W)                                                                                                  \
     do {                                                                                                                      \
         if (narrow) hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kNarrowTileThreads, sbk::kSmallTile / sbk::kNarrowTileThreads, W>), \
-                                       grid, block, D.lds_bytes, s->stream, A);                                              \
+                                       grid, block, D.lds_bytes + s->lds_pad, s->stream, A);                                              \
         else if (small) hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kWideTileThreads, sbk::kSmallTile / sbk::kWideTileThreads, W>), \
-                                           grid, block, D.lds_bytes, s->stream, A);                                          \
+                                           grid, block, D.lds_bytes + s->lds_pad, s->stream, A);                                          \
         else hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kWideTileThreads, sbk::kLargeTile / sbk::kWideTileThreads, W>), \
-                                grid, block, D.lds_bytes, s->stream, A);                                                     \
+                                grid, block, D.lds_bytes + s->lds_pad, s->stream, A);                                                     \
     } while (0)
     if (s->w_palette) { if (D.has_quads) SB_LAUNCH_TILE(true, true); else SB_LAUNCH_TILE(false, true); }
     else { if (D.has_quads) SB_LAUNCH_TILE(true, false); else SB_LAUNCH_TILE(false, false); }
@@ -734,6 +735,7 @@ int sb_create(const sb_desc *desc, sb_solver **out) {
         s->lazy_tick = !std::getenv("SB_NO_LAZY_TICK");
         s->graph_rccl = std::getenv("SB_GRAPH_RCCL") != nullptr;
         s->pack_tiles = !std::getenv("SB_NO_PACK");
+        if (const char *e = std::getenv("SB_LDS_PAD")) s->lds_pad = (size_t)std::max(0, std::atoi(e));
         if (const char *e = std::getenv("SB_TILE_LANES")) s->tile_lanes = std::atoi(e) == 128 ? 128 : (std::atoi(e) == 256 ? 256 : 0);
         if (const char *e = std::getenv("SB_NARROW_MIN_TILES")) s->narrow_min_tiles = std::max(1, std::atoi(e));
         HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));

@@ -113,3 +113,33 @@ def test_bad_calls_are_rejected():
     bad = jelly_cube(4); bad.inv_mass[3] = -1.0
     with pytest.raises(native.SoftbodyError):
         Softbody(bad).Start()
+
+
+@pytest.mark.parametrize("tile", [512, -1])
+def test_spring_lengths_across_the_float_range(oracle_mod, tile):
+    # the kernels use their own correctly rounded sqrt for squared lengths >= 2^-96 and SPEC §4 skips shorter springs:
+    # independent two-particle springs whose lengths sweep 2^-60 .. 2^+55, a cluster right at the 2^-48 threshold
+    rng = np.random.default_rng(5)
+    n_pairs = 6000
+    expo = np.concatenate([rng.uniform(-60, 55, n_pairs - 1000), rng.uniform(-48.6, -47.4, 1000)])
+    length = np.exp2(expo)
+    direction = rng.normal(size=(n_pairs, 3)); direction /= np.linalg.norm(direction, axis=1)[:, None]
+    a = np.zeros((n_pairs, 3)); a[:, 0] = np.arange(n_pairs) * 0.0   # all pairs start at the origin side by side in index space
+    b = a + direction * length[:, None]
+    pos = np.empty((2 * n_pairs, 3), f32); pos[0::2] = a; pos[1::2] = b
+    ij = np.stack([np.arange(n_pairs) * 2, np.arange(n_pairs) * 2 + 1], 1)
+    rest = (length * rng.uniform(0.5, 1.5, n_pairs)).astype(f32)
+    w = rng.choice(np.array([0.0, 0.5, 1.0, 3.0], f32), 2 * n_pairs)
+    m = _mesh(pos, ij=ij, rest=rest, w=w)
+    sb = Softbody(m, substeps=2, gravity=(0, 0, 0), tile_particles=tile).Start()
+    try:
+        o = make_oracle(oracle_mod, m, sb.plan(), gravity=(0, 0, 0))
+        x0 = sb.get_positions().copy()
+        sb.step(); o.step(0.02, 2)
+        x, v = sb.get_positions(), sb.get_velocities()
+    finally:
+        sb.OnDestroy()
+    assert np.array_equal(x.view(np.uint32), o.x.view(np.uint32)) and np.array_equal(v.view(np.uint32), o.v.view(np.uint32))
+    moved = (x != x0).any(1).reshape(-1, 2).any(1)
+    L2 = ((pos[0::2].astype(np.float64) - pos[1::2]) ** 2).sum(1)
+    assert not moved[L2 < 2.0 ** -97].any() and moved[(L2 > 2.0 ** -95) & (w.reshape(-1, 2).sum(1) > 0)].mean() > 0.9

@@ -20,12 +20,24 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def pmc_mean(d, counter):
+    """Mean counter value per (kernel, workgroups per launch): T0 and T1 launches of tile_kernel differ in grid size."""
     acc = collections.defaultdict(list)
     for f in os.listdir(d):
         if f.endswith("counter_collection.csv"):
             for r in csv.DictReader(open(os.path.join(d, f))):
                 if r["Counter_Name"] == counter:
-                    acc[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+                    acc[(r["Kernel_Name"], int(r["Grid_Size"]) // max(int(r["Workgroup_Size"]), 1))].append(float(r["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+def trace_mean(d):
+    """Mean duration (ns) per (kernel, workgroups per launch) from the kernel trace."""
+    acc = collections.defaultdict(list)
+    for f in os.listdir(d):
+        if f.endswith("kernel_trace.csv"):
+            for r in csv.DictReader(open(os.path.join(d, f))):
+                wg = int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)
+                acc[(r["Kernel_Name"], wg)].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
     return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
 
 
@@ -36,7 +48,6 @@ def main():
     ap.add_argument("--fetch")
     ap.add_argument("--write")
     ap.add_argument("--key", required=True, help="e.g. n256_tile512_gpus1")
-    ap.add_argument("--slots", default="tile_kernel<1,=0;tile_kernel<1,=1", help="kernel substring = bench slot index")
     args = ap.parse_args()
     out_dir = os.path.join(ROOT, "profiles")
     os.makedirs(out_dir, exist_ok=True)
@@ -50,23 +61,29 @@ def main():
         md.append(f"| `{r['Name'][:70]}` | {r['Calls']} | {float(r['AverageNs']) / 1e3:.2f} | "
                   f"{float(r['TotalDurationNs']) / 1e6:.3f} | {float(r['Percentage']):.2f} |")
     traffic = {}
+    tm = trace_mean(args.kt)
+    if tm:
+        md += ["", "## per launch shape (kernel trace; T0 and T1 launches of one kernel differ in workgroup count)", "",
+               "| kernel | workgroups | launches | avg µs |", "|---|---|---|---|"]
+        for k in sorted(tm):
+            if "tile_kernel" in k[0] or "global_" in k[0] or "halo_" in k[0]:
+                md.append(f"| `{k[0][:60]}` | {k[1]} | {tm[k][1]} | {tm[k][0] / 1e3:.2f} |")
     if args.fetch and args.write:
         fe = pmc_mean(args.fetch, "FETCH_SIZE"); wr = pmc_mean(args.write, "WRITE_SIZE")
-        avg_ns = {r["Name"]: float(r["AverageNs"]) for r in rows}
         md += ["", "## HBM traffic per launch (separate --pmc FETCH_SIZE / --pmc WRITE_SIZE passes)", "",
-               "| kernel | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | bytes = 2·F·1024 + W·1024 | avg µs (kernel trace) | TB/s |",
-               "|---|---|---|---|---|---|"]
+               "| kernel | workgroups | FETCH_SIZE KiB (raw) | WRITE_SIZE KiB | bytes = 2·F·1024 + W·1024 | avg µs (kernel trace) | TB/s |",
+               "|---|---|---|---|---|---|---|"]
+        mid = sorted(k for k in fe if "tile_kernel<1" in k[0] and k in wr)      # mid-tick kernel: fewer workgroups = T0
         for k in sorted(fe):
             if k not in wr:
                 continue
             b = 2 * fe[k][0] * 1024 + wr[k][0] * 1024
-            us = avg_ns.get(k, 0) / 1e3
+            us = tm.get(k, (0, 0))[0] / 1e3
             tbs = b / (us * 1e-6) / 1e12 if us else float("nan")
-            md.append(f"| `{k[:60]}` | {fe[k][0]:.1f} | {wr[k][0]:.1f} | {b / 1e6:.1f} MB | {us:.2f} | {tbs:.2f} |")
-            for spec in args.slots.split(";"):
-                sub, slot = spec.split("=")
-                if sub in k:
-                    traffic[slot] = b
+            md.append(f"| `{k[0][:60]}` | {k[1]} | {fe[k][0]:.1f} | {wr[k][0]:.1f} | {b / 1e6:.1f} MB | {us:.2f} | {tbs:.2f} |")
+            if k in mid:
+                if k == mid[0]: traffic["0"] = b
+                if k == mid[-1]: traffic["1"] = b
         tj_path = os.path.join(out_dir, "hbm_traffic.json")
         tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
         tj[args.key] = traffic
