@@ -274,9 +274,7 @@ void build_device(sb_solver *s) {
         // type. Members share no particle and keep their own round order, so the result is bit-identical to running
         // them one after the other (the published order); only the number of workgroups changes.
         const size_t n_plan_tiles = LT.tile_ids.size();
-        int32_t plan_max_local = 0;
-        for (size_t ci = 0; ci < n_plan_tiles; ++ci) plan_max_local = std::max(plan_max_local, G.tiles[LT.tile_ids[ci]].n_local);
-        const int capacity = plan_max_local <= sbk::kSmallTile ? sbk::kSmallTile : sbk::kLargeTile;
+        const int capacity = sbk::kSmallTile;         // packs stay small tiles; plan tiles above that size are left alone
         std::vector<std::vector<int32_t>> packs;      // members (indices into LT.tile_ids), in execution order
         {
             std::vector<int32_t> pack_of(n_plan_tiles, -1), cand;
