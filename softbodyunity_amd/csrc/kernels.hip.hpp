@@ -34,7 +34,7 @@ struct TileDesc {
     int32_t run_overflow;      // runs beyond kInlineRuns live at runs_overflow[run_overflow ...]
     int32_t n_pal;             // palette entries (0 = no dictionary coding), stored after the round words
     int32_t pad1, pad2;
-    int2 runs[10];             // {first particle (device numbering), first tile-local index}
+    int2 runs[10];             // {first particle (device numbering), first tile-local index}; unused entries: {0, INT_MAX}
 };
 constexpr int kInlineRuns = 10;
 constexpr int kMaxRoundsLds = 128;   // round words cached in LDS; longer programs read them from memory
@@ -260,22 +260,29 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
     const TickParams tp = *A.tp;
     const uint32_t *tstream = A.stream + td.s_begin;
 
-    // ---- particle ownership: lane tid owns tile-local particles tid + 256*m -----------------------
+    // ---- particle ownership: lane tid owns tile-local particles tid + THREADS*m ------------------
+    // Branch-free run lookup: the runs are sorted by their first local index and unused inline entries hold
+    // INT_MAX there, so the last run that starts at or before l is found by a compare/select chain on scalars
+    // (a loop with a scalar branch per run and slot cost ~400 SALU instructions per wave BEFORE the first load).
     int g[PPT];
+    {
+        int run_d[kInlineRuns], run_y[kInlineRuns];
 #pragma unroll
-    for (int m = 0; m < PPT; ++m) {
-        const int l = tid + m * kTileThreads;
-        int gi = -1;
-        if (l < n_local) {
+        for (int r = 0; r < kInlineRuns; ++r) { run_y[r] = td.runs[r].y; run_d[r] = td.runs[r].x - td.runs[r].y; }
 #pragma unroll
-            for (int r = 0; r < kInlineRuns; ++r)
-                if (r < run_count && td.runs[r].y <= l) gi = td.runs[r].x + (l - td.runs[r].y);
-            for (int r = kInlineRuns; r < run_count; ++r) {
-                const int2 rn = A.runs_overflow[td.run_overflow + r - kInlineRuns];
-                if (rn.y <= l) gi = rn.x + (l - rn.y);
-            }
+        for (int m = 0; m < PPT; ++m) {
+            const int l = tid + m * kTileThreads;
+            int d = run_d[0];
+#pragma unroll
+            for (int r = 1; r < kInlineRuns; ++r) d = l >= run_y[r] ? run_d[r] : d;
+            int gi = l + d;
+            if (run_count > kInlineRuns)
+                for (int r = kInlineRuns; r < run_count; ++r) {
+                    const int2 rn = A.runs_overflow[td.run_overflow + r - kInlineRuns];
+                    if (rn.y <= l) gi = rn.x + (l - rn.y);
+                }
+            g[m] = l < n_local ? gi : -1;
         }
-        g[m] = gi;
     }
     // ---- the stretch of the stream this kernel needs, staged through an LDS window -----------------
     // virtual program: rounds 0..R-1 (finish the previous substep), MARK, rounds 0..R-1 again (start the next)

@@ -8,6 +8,7 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -353,6 +354,7 @@ void build_device(sb_solver *s) {
             }
             td.n_local = lstart;
             td.run_count = n_runs;
+            for (int32_t r = n_runs; r < sbk::kInlineRuns; ++r) td.runs[r] = make_int2(0, INT32_MAX);   // never selected
             if (lstart > sbk::kLargeTile) throw std::runtime_error("internal: packed tile too large");
             max_local = std::max(max_local, lstart);
             // the pack's program: zip the members' round lists (same type, at most 256 constraints per round)
