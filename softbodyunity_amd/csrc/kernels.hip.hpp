@@ -66,7 +66,7 @@ struct TileArgs {
     const int2 *runs_overflow;
     const uint32_t *stream;
     const TickParams *tp;
-    int32_t max_local;        // LDS carve: [max_local float4][rounds_dwords][pal_dwords][win_dwords]
+    int32_t max_local;        // LDS carve: [max_local float4][rounds_dwords][pal_dwords][win_dwords][16 spare bytes]
     int32_t rounds_dwords;    // round words cached in LDS (multiple of 4, <= kMaxRoundsLds); longer programs read memory
     int32_t pal_dwords;       // largest rest-length dictionary of the tiling, padded to 4 (0 = none)
     int32_t win_dwords;       // constraint window held in LDS (multiple of 4, >= the largest round)
@@ -239,6 +239,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
     uint32_t *s_rounds = reinterpret_cast<uint32_t *>(lds_pos + A.max_local);
     float *s_pal = reinterpret_cast<float *>(s_rounds + A.rounds_dwords);
     uint32_t *cbuf = s_rounds + A.rounds_dwords + A.pal_dwords;
+    f32x3 *lds_spare = reinterpret_cast<f32x3 *>(cbuf + A.win_dwords);   // 16 bytes nobody reads (see the rounds)
     // the tile tables are never written by a kernel: read the descriptor through the constant address space so it
     // stays on the scalar-memory path (s_load), one wide read
     typedef const TileDesc __attribute__((address_space(4))) *ConstTileDescPtr;
@@ -498,12 +499,16 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
                     con[u] = project_distance_nobranch(a, b, cL0[u], tp.at_d) && con[u];
                     ca[u].x = a.x; ca[u].y = a.y; ca[u].z = a.z; cb[u].x = b.x; cb[u].y = b.y; cb[u].z = b.z;
                 }
+                // Unconditional stores: an idle lane or a skipped constraint writes to a spare LDS slot instead. With the
+                // stores under `if (ok)` the compiler sinks each projection into its own branch and runs them one after
+                // the other; this way the independent chains are scheduled together.
 #pragma unroll
-                for (int u = 0; u < kCPL; ++u)
-                    if (con[u]) {
-                        *reinterpret_cast<f32x3 *>(lds_pos + ci[u]) = (f32x3){ca[u].x, ca[u].y, ca[u].z};
-                        *reinterpret_cast<f32x3 *>(lds_pos + ck[u]) = (f32x3){cb[u].x, cb[u].y, cb[u].z};
-                    }
+                for (int u = 0; u < kCPL; ++u) {
+                    f32x3 *da = con[u] ? reinterpret_cast<f32x3 *>(lds_pos + ci[u]) : lds_spare;
+                    f32x3 *db = con[u] ? reinterpret_cast<f32x3 *>(lds_pos + ck[u]) : lds_spare;
+                    *da = (f32x3){ca[u].x, ca[u].y, ca[u].z};
+                    *db = (f32x3){cb[u].x, cb[u].y, cb[u].z};
+                }
             } else if (QUADS) {
 #pragma unroll 1
                 for (int c = tid; c < cnt; c += kTileThreads) {

@@ -459,7 +459,7 @@ void build_device(sb_solver *s) {
         if (const char *e = std::getenv("SB_WIN_DWORDS")) D.win_dwords = std::max(1024, std::min(D.win_dwords, std::atoi(e)) & ~3);   // tuning experiments
         D.pal_dwords = (max_pal + 3) & ~3;
         D.rounds_dwords = std::min(sbk::kMaxRoundsLds, (max_rounds + 3) & ~3);
-        D.lds_bytes = (size_t)D.max_local * sizeof(float4) + (size_t)D.rounds_dwords * 4 + (size_t)D.pal_dwords * 4 + (size_t)D.win_dwords * 4;
+        D.lds_bytes = (size_t)D.max_local * sizeof(float4) + (size_t)D.rounds_dwords * 4 + (size_t)D.pal_dwords * 4 + (size_t)D.win_dwords * 4 + 16;
         D.n_slots = 0;
         for (size_t ci = 0; ci < LT.tile_ids.size(); ++ci) {
             const sbp::Tile &T = G.tiles[LT.tile_ids[ci]];
