@@ -143,3 +143,24 @@ def test_spring_lengths_across_the_float_range(oracle_mod, tile):
     moved = (x != x0).any(1).reshape(-1, 2).any(1)
     L2 = ((pos[0::2].astype(np.float64) - pos[1::2]) ** 2).sum(1)
     assert not moved[L2 < 2.0 ** -97].any() and moved[(L2 > 2.0 ** -95) & (w.reshape(-1, 2).sum(1) > 0)].mean() > 0.9
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_random_irregular_meshes(oracle_mod, seed):
+    # randomized clouds (anisotropic, mixed masses, springs + tets + hinges), random tile size: bit-exact against the oracle
+    from test_plan import _random_mesh
+    rng = np.random.default_rng(2000 + seed)
+    n = int(rng.integers(60, 3000))
+    stretch = [(1, 1, 1), (4, 1, 0.25), (1, 0.05, 1), (8, 8, 0.1)][seed % 4]
+    tile = [32, 64, 256, -1, 512, 128][seed]
+    mesh = _random_mesh(seed, n, stretch)
+    kw = dict(distance_compliance=1e-6, volume_compliance=1e-6, bending_compliance=1e-4, tile_particles=tile)
+    sb = Softbody(mesh, substeps=4, **kw).Start()
+    try:
+        o = make_oracle(oracle_mod, mesh, sb.plan(), compliance=(1e-6, 1e-6, 1e-4))
+        for _ in range(2):
+            sb.step(); o.step(0.02, 4)
+        x, v = sb.get_positions(), sb.get_velocities()
+    finally:
+        sb.OnDestroy()
+    assert np.array_equal(x.view(np.uint32), o.x.view(np.uint32)) and np.array_equal(v.view(np.uint32), o.v.view(np.uint32))

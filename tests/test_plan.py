@@ -133,3 +133,42 @@ def test_plan_rejects_bad_input():
         native.Plan.build(mesh.rest_pos, bad)
     with pytest.raises(native.SoftbodyError):
         native.Plan.build(mesh.rest_pos, mesh.dist_ij, world=3, part_dims=(2, 2, 1))
+
+
+def _random_mesh(seed, n, stretch):
+    """Random cloud + nearest-neighbour springs, tets and hinges over neighbour triples (bounded valence)."""
+    from scipy.spatial import cKDTree
+    from softbodyunity_amd.mesh import SoftbodyMesh
+    rng = np.random.default_rng(seed)
+    side = n ** (1.0 / 3.0)
+    pos = (rng.uniform(0, side, (n, 3)) * np.array(stretch)).astype(np.float32)
+    _, nb = cKDTree(pos).query(pos, k=min(5, n))
+    nb = nb.reshape(n, -1)
+    edges = {(min(i, int(j)), max(i, int(j))) for i in range(n) for j in nb[i, 1:] if int(j) != i}
+    ij = np.array(sorted(edges), np.int32).reshape(-1, 2)
+    quads = np.array([[i, *nb[i, 1:4]] for i in range(0, n, 3) if nb.shape[1] >= 4 and len({i, *map(int, nb[i, 1:4])}) == 4], np.int32).reshape(-1, 4)
+    vol, bend = quads[0::2], quads[1::2]
+    rest = np.linalg.norm(pos[ij[:, 0]] - pos[ij[:, 1]], axis=1).astype(np.float32) * rng.uniform(0.9, 1.1, len(ij)).astype(np.float32)
+    e = lambda q, a, b: pos[q[:, a]] - pos[q[:, b]]
+    vrest = (np.abs(np.einsum("ij,ij->i", e(vol, 1, 0), np.cross(e(vol, 2, 0), e(vol, 3, 0)))) / 6.0).astype(np.float32)
+    brest = np.tile(np.array([[1.0, 0.0]], np.float32), (len(bend), 1))
+    w = rng.choice(np.array([0.0, 1.0, 1.0, 2.0], np.float32), n)
+    return SoftbodyMesh(rest_pos=pos.copy(), pos=pos + rng.normal(0, 0.02, pos.shape).astype(np.float32), vel=np.zeros_like(pos),
+                        inv_mass=w, dist_ij=ij, dist_rest=rest, vol_ijkl=vol, vol_rest=vrest, bend_ijkl=bend, bend_rest=brest)
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_random_meshes_plan_invariants_and_partition_invariance(oracle_mod, seed):
+    # randomized: cloud size, anisotropy, tile size and world size all vary with the seed
+    rng = np.random.default_rng(1000 + seed)
+    n = int(rng.integers(40, 700))
+    stretch = [(1, 1, 1), (4, 1, 0.25), (1, 0.05, 1), (8, 8, 0.1)][seed % 4]
+    tile = [32, 64, 128, -1][int(rng.integers(0, 4))]
+    world = int(rng.integers(2, 5))
+    mesh = _random_mesh(seed, n, stretch)
+    plan = build_plan(mesh, tile_particles=tile)
+    _check_plan(mesh, plan)
+    ref = make_oracle(oracle_mod, mesh, plan, compliance=(1e-6, 1e-6, 1e-4))
+    ref.step(0.02, 3)
+    x, v, _ = run_partitioned(oracle_mod, mesh, world, (0, 0, 0), ticks=1, substeps=3, tile=tile, compliance=(1e-6, 1e-6, 1e-4))
+    assert np.array_equal(x.view(np.uint32), ref.x.view(np.uint32)) and np.array_equal(v.view(np.uint32), ref.v.view(np.uint32))
