@@ -134,8 +134,8 @@ typedef struct {
     int64_t n_constraints_local[3];                 /* distance, volume, bending (incl. redundant cut copies) */
     int32_t n_tilings;                              /* 2 with tiling, 1 without (tile_particles = -1) */
     int32_t n_global_colours;
-    int64_t n_tiles[2];                             /* tiles this rank executes per tiling */
-    int64_t tile_constraints[2];                    /* constraint slots (cross + full) stored per tiling, this rank */
+    int64_t n_tiles[2];                             /* workgroups this rank launches per tiling (under-full tiles share one) */
+    int64_t tile_constraints[2];                    /* constraints stored in the tile streams per tiling, this rank */
     int64_t constraints_in_tiles, constraints_in_global;   /* whole mesh */
     int64_t halo_particles_t1;                      /* ghosts sent before every T1 kernel */
     int64_t halo_particles_global;                  /* ghosts sent per substep for the global colours */
