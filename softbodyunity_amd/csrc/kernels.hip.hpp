@@ -228,7 +228,7 @@ __device__ __forceinline__ bool project_bending(float4 &pa, float4 &pb, float4 &
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Register budget (HIP: second launch-bound = waves per SIMD). LDS allows ~14 tiles per CU, so aim for that many waves.
-template <bool QUADS, int THREADS> constexpr int kWavesPerSimd = QUADS ? (THREADS == 64 ? 3 : 4) : (THREADS == 256 ? 8 : (THREADS == 128 ? 6 : 4));
+template <bool QUADS, int THREADS> constexpr int kWavesPerSimd = QUADS ? (THREADS == 64 ? 3 : 4) : (THREADS == 256 ? 8 : (THREADS == 128 ? 6 : 4));   // 128 lanes: 7 waves (72 VGPRs) measured 1 % slower, 8 spill
 // WPAL = inverse masses are read as one-byte palette indices (the palette entry comes from another lane by ds_bpermute).
 template <int KIND, bool QUADS, int THREADS, int PPT, bool WPAL>
 __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile_kernel(TileArgs A) {
@@ -334,7 +334,13 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
     const int n_pal = td.n_pal;
     // palette follows the round words; lanes without an entry re-read round word 0 (always inside the tile's stream)
     const uint32_t palw = tstream[tid < n_pal ? ((n_rounds_all + 3) & ~3) + tid : 0];
-    constexpr int kW = kCPL > 1 ? 8 : 4;   // uint4 per lane in the first sweep of the window; longer windows loop below
+    // uint4 per lane in the first sweep of the window (issued with the particle loads; idle lanes re-read the tile's
+    // header, so a sweep nobody needs is a wasted load per lane): 2 cover the 4-byte slots of a 512-particle tile at either
+    // width; longer windows finish in the loop below
+#ifndef SB_KW
+#define SB_KW (QUADS ? 4 : 2)
+#endif
+    constexpr int kW = SB_KW;
     const uint32_t n4_first = (min(win_lo + win, d_hi) - win_lo) >> 2;
     const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(tstream + win_lo);
     u32x4 wv[kW];
