@@ -164,3 +164,28 @@ def test_random_irregular_meshes(oracle_mod, seed):
     finally:
         sb.OnDestroy()
     assert np.array_equal(x.view(np.uint32), o.x.view(np.uint32)) and np.array_equal(v.view(np.uint32), o.v.view(np.uint32))
+
+
+def test_create_destroy_cycles_do_not_leak_device_memory():
+    # every handle owns streams, events, graphs, pinned snapshots and device buffers: 40 full life cycles must give the
+    # memory back (hipMemGetInfo through torch)
+    import torch
+    mesh = jelly_cube(24)
+
+    def cycle(readback):
+        sb = Softbody(mesh, substeps=4).Start()
+        sb.step(); sb.step(0.01, 3)
+        if readback:
+            sb.readback_begin(); sb.step(); sb.readback_end()
+        sb.get_positions()
+        sb.OnDestroy()
+
+    for k in range(3):
+        cycle(True)
+    torch.cuda.synchronize()
+    free0, _ = torch.cuda.mem_get_info()
+    for k in range(40):
+        cycle(k % 2 == 0)
+    torch.cuda.synchronize()
+    free1, _ = torch.cuda.mem_get_info()
+    assert free0 - free1 < 8 << 20, f"device memory shrank by {(free0 - free1) / 2**20:.1f} MiB over 40 create/destroy cycles"
