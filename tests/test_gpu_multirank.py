@@ -124,8 +124,11 @@ def _hosted_worker(rank, world, port, tile, mesh_kind, out_dir):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,tile,mesh_kind", [(2, 64, "cube"), (4, 64, "cube"), (2, -1, "cube"), (3, 128, "bunny")])
-def test_multirank_device_path_with_hosted_halo(tmp_path, oracle_mod, world, tile, mesh_kind):
+@pytest.mark.parametrize("world,tile,mesh_kind,lanes", [(2, 64, "cube", ""), (4, 64, "cube", "128"), (2, -1, "cube", ""), (3, 128, "bunny", ""),
+                                                        (2, 128, "bunny", "128")])
+def test_multirank_device_path_with_hosted_halo(tmp_path, oracle_mod, monkeypatch, world, tile, mesh_kind, lanes):
+    if lanes:      # force the 128-lane tile workgroups (normally only launches of >= 10240 tiles use them)
+        monkeypatch.setenv("SB_TILE_LANES", lanes)
     from softbodyunity_amd.mesh import bunny_surrogate, jelly_cube
     from helpers import build_plan, make_oracle
     port = 29700 + (os.getpid() % 1500) + world * 7 + (1 if tile > 0 else 0)
