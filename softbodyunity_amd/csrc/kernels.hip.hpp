@@ -17,7 +17,7 @@ struct TickParams {           // SPEC.md §2 host-side scalars, uploaded once pe
     float pad[2];
 };
 
-// One LDS tile = one workgroup. 128 B, read with scalar loads.
+// One LDS tile (or pack of tiles) = one workgroup. 128 B, read with scalar loads.
 // The tile's constraint stream lives at stream[s_begin ...], 16-byte aligned, in dwords:
 //   [round words, padded to 4] [rest-length palette, padded to 4] [rounds' data]
 // round word: bits 0-9 count, bits 10-12 type (0 distance, 1 volume, 2 bending, 4 = distance, dictionary-coded);
@@ -215,14 +215,16 @@ __device__ __forceinline__ bool project_bending(float4 &pa, float4 &pb, float4 &
     return true;
 }
 
-// One workgroup = one tile; a tile owns one constraint list, cut into rounds of independent constraints (plan.hpp):
+// One workgroup = one tile (or one pack of under-full tiles, solver.hip build_device) of THREADS lanes; a tile owns one
+// constraint list, cut into rounds of at most kRoundSlots independent constraints (plan.hpp):
 //   KIND 0 (first kernel of a tick)  : MARK: v from the velocity array, integrate; the tile's rounds
 //   KIND 1 (every other substep)     : the tile's rounds (finish substep s-1), MARK: v = (x-xprev)/h, integrate
 //                                      (start substep s), the same rounds again
 //   KIND 2 (after the last substep)  : the tile's rounds, MARK: write v, stop
 // Particles AND the tile's constraint stream are staged in LDS with wide coalesced loads issued together,
 // so a tile pays the HBM latency once; rounds then run LDS-to-LDS with one barrier each. Each lane keeps
-// ownership of up to PPT particles for the MARK step. QUADS = the tiling stores 4-vertex rounds.
+// ownership of up to PPT particles for the MARK step and projects kRoundSlots / THREADS constraints per round.
+// QUADS = the tiling stores 4-vertex rounds.
 // Workgroup barrier that orders LDS only (global memory is never exchanged between lanes inside a launch);
 // __syncthreads() would also drain vmcnt, i.e. wait for the xprev stores of the MARK step.
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
