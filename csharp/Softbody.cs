@@ -2,6 +2,7 @@
 //
 // Start()       -> sb_create + sb_set_particles/sb_set_*_constraints + sb_finalize   (plan, upload, capture)
 // FixedUpdate() -> sb_step(Time.fixedDeltaTime, substeps) + sb_get_positions         (one tick, SPEC.md §2)
+//                  asyncReadback: sb_readback_begin/end + GPU vertex normals instead (one tick of latency, no stall)
 // OnDestroy()   -> sb_destroy
 //
 // `useGpu = false` runs the same tick on the CPU through SoftbodyCpuSolver (the C# restatement of
@@ -34,6 +35,8 @@ namespace SoftbodyMI355X
         [SerializeField] bool useGpu = true;
         [SerializeField] int device = 0;
         [SerializeField] int tileParticles = 512;
+        [Tooltip("Render from the previous tick's snapshot: the D2H copy and the normals (computed on the GPU) overlap the next tick.")]
+        [SerializeField] bool asyncReadback = false;
 
         // constraint graph (filled by an authoring script or SoftbodyMeshBuilder before Start)
         public Vector3[] restPositions;
@@ -43,11 +46,14 @@ namespace SoftbodyMI355X
         public int[] distanceIJ; public float[] distanceRest;
         public int[] volumeIJKL; public float[] volumeRest;
         public int[] bendingIJKL; public float[] bendingRestCosSin;
+        public int[] renderTriangles;          // particle indices, 3 per triangle (SoftbodyMeshBuilder: mesh.triangles through particleOfVertex)
 
         IntPtr handle = IntPtr.Zero;
         SoftbodyCpuSolver cpu;
         Mesh mesh;
         GCHandle posPin;
+        Vector3[] normals;
+        bool snapshotPending;
 
         void Start()
         {
@@ -97,10 +103,36 @@ namespace SoftbodyMI355X
                 cpu = new SoftbodyCpuSolver(this, type, id);
             }
             posPin = GCHandle.Alloc(positions, GCHandleType.Pinned);
+            if (useGpu && asyncReadback && renderTriangles != null && renderTriangles.Length >= 3)
+            {
+                SoftbodyNative.Check(SoftbodyNative.sb_set_render_triangles(handle, renderTriangles, renderTriangles.Length / 3), "sb_set_render_triangles");
+                normals = new Vector3[positions.Length];
+            }
         }
 
         void FixedUpdate()
         {
+            if (useGpu && asyncReadback)
+            {
+                // show the snapshot taken after the PREVIOUS tick (its copy and its normals ran beside this tick's kernels),
+                // then queue this tick's snapshot: the main thread never waits for the GPU to finish a tick
+                SoftbodyNative.Check(SoftbodyNative.sb_step(handle, Time.fixedDeltaTime, substeps), "sb_step");
+                SoftbodyNative.Check(SoftbodyNative.sb_readback_begin(handle), "sb_readback_begin");
+                if (snapshotPending)
+                {
+                    SoftbodyNative.Check(SoftbodyNative.sb_readback_end(handle, out IntPtr pos), "sb_readback_end");
+                    CopyVectors(pos, positions);
+                    if (normals != null)
+                    {
+                        SoftbodyNative.Check(SoftbodyNative.sb_readback_get_normals(handle, out IntPtr nrm), "sb_readback_get_normals");
+                        CopyVectors(nrm, normals);
+                    }
+                }
+                snapshotPending = true;
+                mesh.vertices = positions;
+                if (normals != null) mesh.normals = normals; else mesh.RecalculateNormals();
+                return;
+            }
             if (useGpu)
             {
                 SoftbodyNative.Check(SoftbodyNative.sb_step(handle, Time.fixedDeltaTime, substeps), "sb_step");
@@ -129,6 +161,11 @@ namespace SoftbodyMI355X
         internal bool GroundPlane => groundPlane;
         internal Vector3 GroundNormal => groundNormal;
         internal float GroundOffset => groundOffset;
+
+        static unsafe void CopyVectors(IntPtr src, Vector3[] dst)
+        {
+            fixed (Vector3* d = dst) Buffer.MemoryCopy((void*)src, d, (long)dst.Length * 12, (long)dst.Length * 12);
+        }
 
         static void Pin<T>(T[] a, Action<IntPtr> f)
         {

@@ -50,6 +50,13 @@ namespace SoftbodyMI355X
             sb.positions = pos.ToArray();
             sb.distanceIJ = ij.ToArray(); sb.distanceRest = rest.ToArray();
             sb.bendingIJKL = hinge.ToArray(); sb.bendingRestCosSin = hingeRest.ToArray();
+            var rt = new List<int>();          // render triangles in particle indices (GPU vertex normals, SPEC.md 6a)
+            for (int t = 0; t + 2 < triangles.Length; t += 3)
+            {
+                int a = particleOfVertex[triangles[t]], b = particleOfVertex[triangles[t + 1]], c = particleOfVertex[triangles[t + 2]];
+                if (a != b && b != c && a != c) { rt.Add(a); rt.Add(b); rt.Add(c); }
+            }
+            sb.renderTriangles = rt.ToArray();
             return particleOfVertex;   // mesh.vertices[v] = positions[particleOfVertex[v]] after each FixedUpdate
         }
 

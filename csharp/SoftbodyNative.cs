@@ -1,4 +1,4 @@
-// SoftbodyNative.cs — P/Invoke layer over libsoftbody_mi355x.so (include/softbody.h, ABI version 2).
+// SoftbodyNative.cs — P/Invoke layer over libsoftbody_mi355x.so (include/softbody.h, ABI version 3).
 //
 // One [DllImport] per exported function, same name and argument order as the header; the Python twin
 // used by the test-suite is softbodyunity_amd/native.py (tests/test_abi.py keeps the three in sync).
@@ -75,6 +75,8 @@ namespace SoftbodyMI355X
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_state(IntPtr s, IntPtr posXyz, IntPtr velXyz, int n);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_readback_begin(IntPtr s);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_readback_end(IntPtr s, out IntPtr posXyz);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_render_triangles(IntPtr s, int[] triAbc, int m);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_readback_get_normals(IntPtr s, out IntPtr normalXyz);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_get_owner(IntPtr s, IntPtr ownerRankOut, int n);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_profile_begin(IntPtr s);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_profile_end(IntPtr s, out float elapsedMs);

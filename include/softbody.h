@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SB_ABI_VERSION 2
+#define SB_ABI_VERSION 3
 
 typedef enum {
     SB_OK = 0,
@@ -107,6 +107,14 @@ int sb_set_state(sb_solver *s, const float *pos_xyz, const float *vel_xyz, int32
  * until the second sb_readback_begin after it. At most two snapshots may be pending. */
 int sb_readback_begin(sb_solver *s);
 int sb_readback_end(sb_solver *s, const float **pos_xyz_out);
+/* Render normals (SPEC.md 6a; replaces Unity's Mesh.RecalculateNormals on the main thread): give the render
+ * triangles once (particle indices, caller numbering, 3*m ints; m = 0 switches it off), any time after
+ * sb_set_particles. Every later sb_readback_begin then also computes area-weighted vertex normals of the snapshot on
+ * the copy stream and brings them to pinned memory; after the matching sb_readback_end, sb_readback_get_normals
+ * returns n*3 floats (zero for particles in no triangle), valid as long as that snapshot's positions.
+ * Single-rank solvers only (world == 1): a rank of a partitioned solver does not hold its neighbours' particles. */
+int sb_set_render_triangles(sb_solver *s, const int32_t *tri_abc, int32_t m);
+int sb_readback_get_normals(sb_solver *s, const float **normal_xyz_out);
 int sb_get_owner(sb_solver *s, int32_t *owner_rank_out, int32_t n);
 
 /* ---- measurement ----------------------------------------------------------------------------- */

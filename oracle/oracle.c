@@ -260,3 +260,26 @@ void orc_step_tasks(float *x, float *v, const float *w, float *xprev, int n, con
         }
     }
 }
+
+/* SPEC.md §6a: area-weighted vertex normals of a render triangle list on a position snapshot. */
+void orc_vertex_normals(const float *x, int n, const int32_t *tri, int64_t m, float *nrm) {
+    memset(nrm, 0, (size_t)n * 3 * sizeof(float));
+    for (int64_t t = 0; t < m; ++t) {
+        const int32_t a = tri[3 * t], b = tri[3 * t + 1], c = tri[3 * t + 2];
+        float e1[3], e2[3], f[3];
+        sub3(x + 3 * (int64_t)b, x + 3 * (int64_t)a, e1);
+        sub3(x + 3 * (int64_t)c, x + 3 * (int64_t)a, e2);
+        cross3(e1, e2, f);
+        for (int j = 0; j < 3; ++j) {
+            float *d = nrm + 3 * (int64_t)tri[3 * t + j];
+            d[0] = d[0] + f[0]; d[1] = d[1] + f[1]; d[2] = d[2] + f[2];
+        }
+    }
+    for (int v = 0; v < n; ++v) {
+        float *d = nrm + 3 * (int64_t)v;
+        float xx = d[0] * d[0], yy = d[1] * d[1], zz = d[2] * d[2];
+        float L2 = (xx + yy) + zz;
+        if (L2 >= 0x1p-96f) { float L = sqrtf(L2); d[0] = d[0] / L; d[1] = d[1] / L; d[2] = d[2] / L; }
+        else { d[0] = 0.0f; d[1] = 0.0f; d[2] = 0.0f; }
+    }
+}

@@ -56,6 +56,7 @@ def lib():
         _lib.orc_velocity.restype = None
         _lib.orc_scalars_for.restype = None
         _lib.orc_collide.restype = None
+        _lib.orc_vertex_normals.restype = None
     return _lib
 
 
@@ -177,6 +178,14 @@ class Oracle:
         c = self._cons()
         lib().orc_project_range(_p(self.x), _p(self.w), C.byref(c), _p(self.order_type), _p(self.order_id),
                                 C.c_int64(begin), C.c_int64(end), C.byref(s))
+
+
+def vertex_normals(x, tri):
+    """SPEC.md §6a: (N,3) area-weighted vertex normals of the (M,3) triangle list on positions x."""
+    x = _f32(x, (-1, 3)); tri = _i32(tri).reshape(-1, 3)
+    out = np.zeros_like(x)
+    lib().orc_vertex_normals(_p(x), C.c_int(x.shape[0]), _p(tri), C.c_int64(tri.shape[0]), _p(out))
+    return out
 
 
 def parity_error(x, x_ref, x0):

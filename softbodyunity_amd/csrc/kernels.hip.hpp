@@ -573,6 +573,30 @@ __global__ __launch_bounds__(256) void snapshot_kernel(PosView pos, const int32_
     out_xyz[o] = p.x; out_xyz[o + 1] = p.y; out_xyz[o + 2] = p.z;
 }
 
+// SPEC.md §6a: area-weighted vertex normals on a position snapshot in caller numbering. One lane per vertex gathers its
+// incident triangles in ascending order (adj lists built on the host), so the additions happen in the oracle's order.
+__global__ __launch_bounds__(256) void normals_kernel(const float *snap_xyz, const int32_t *adj_off, const int32_t *adj_tri,
+                                                      const int32_t *tri, float *nrm_xyz, int n) {
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= n) return;
+    float nx = 0.0f, ny = 0.0f, nz = 0.0f;
+    for (int k = adj_off[v]; k < adj_off[v + 1]; ++k) {
+        const int t = adj_tri[k];
+        const size_t a = 3 * (size_t)tri[3 * t], b = 3 * (size_t)tri[3 * t + 1], c = 3 * (size_t)tri[3 * t + 2];
+        const V3 xa = {snap_xyz[a], snap_xyz[a + 1], snap_xyz[a + 2]};
+        const V3 e1 = sub3({snap_xyz[b], snap_xyz[b + 1], snap_xyz[b + 2]}, xa);
+        const V3 e2 = sub3({snap_xyz[c], snap_xyz[c + 1], snap_xyz[c + 2]}, xa);
+        const V3 f = cross3(e1, e2);
+        nx = nx + f.x; ny = ny + f.y; nz = nz + f.z;
+    }
+    float xx = nx * nx, yy = ny * ny, zz = nz * nz;
+    float L2 = (xx + yy) + zz;
+    if (L2 >= 0x1p-96f) { float L = sqrt_rn_normal(L2); nx = nx / L; ny = ny / L; nz = nz / L; }
+    else { nx = 0.0f; ny = 0.0f; nz = 0.0f; }
+    const size_t o = 3 * (size_t)v;
+    nrm_xyz[o] = nx; nrm_xyz[o + 1] = ny; nrm_xyz[o + 2] = nz;
+}
+
 // Halo pack / unpack: a ghost travels as 3 floats (position) or, WITH_PREV, 6 floats (position, previous position:
 // the T1 kernels run velocity + integrate on ghosts too). The inverse mass of a ghost is static: uploaded once.
 template <bool WITH_PREV>

@@ -156,6 +156,14 @@ struct sb_solver {
     float *h_snap[2] = {nullptr, nullptr};
     hipEvent_t ev_snap[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
     int snap_head = 0, snap_pending = 0;   // ring of at most two snapshots in flight
+    // render normals of the snapshots (sb_set_render_triangles): incident-triangle lists per particle, caller numbering
+    std::vector<int32_t> render_tri;
+    bool render_dirty = false;             // triangles changed since the last upload
+    DevBuf<int32_t> d_tri, d_adj_off, d_adj_tri;
+    DevBuf<float> d_nrm[2];
+    float *h_nrm[2] = {nullptr, nullptr};
+    bool snap_has_normals[2] = {false, false};
+    int snap_last_ended = -1;
 
     ~sb_solver() {
         for (auto &g : graphs) (void)hipGraphExecDestroy(g.second);
@@ -166,6 +174,7 @@ struct sb_solver {
         gcolours.clear(); halos.clear();
         for (int k = 0; k < 2; ++k) {
             if (h_snap[k]) (void)hipHostFree(h_snap[k]);
+            if (h_nrm[k]) (void)hipHostFree(h_nrm[k]);
             if (ev_snap[k]) (void)hipEventDestroy(ev_snap[k]);
             if (ev_copied[k]) (void)hipEventDestroy(ev_copied[k]);
         }
@@ -1109,6 +1118,33 @@ int sb_readback_begin(sb_solver *s) {
         // ... D2H on the copy stream, overlapping whatever the compute stream does next
         HIP_CHECK(hipStreamWaitEvent(s->copy_stream, s->ev_snap[k], 0));
         HIP_CHECK(hipMemcpyAsync(s->h_snap[k], s->d_snap[k].p, (size_t)s->n * 3 * sizeof(float), hipMemcpyDeviceToHost, s->copy_stream));
+        s->snap_has_normals[k] = false;
+        if (!s->render_tri.empty()) {
+            if (s->render_dirty) {     // (re)build the incident-triangle lists: triangle ids ascending per particle
+                HIP_CHECK(hipStreamSynchronize(s->copy_stream));
+                const int64_t m = (int64_t)s->render_tri.size() / 3;
+                std::vector<int32_t> off((size_t)s->n + 1, 0), adj((size_t)3 * m);
+                for (int64_t c = 0; c < 3 * m; ++c) ++off[(size_t)s->render_tri[c] + 1];
+                for (int32_t v = 0; v < s->n; ++v) off[(size_t)v + 1] += off[v];
+                std::vector<int32_t> cur(off.begin(), off.end() - 1);
+                for (int64_t t = 0; t < m; ++t)
+                    for (int j = 0; j < 3; ++j) adj[(size_t)cur[s->render_tri[3 * t + j]]++] = (int32_t)t;
+                s->d_tri.upload(s->render_tri, s->dev_bytes);
+                s->d_adj_off.upload(off, s->dev_bytes);
+                s->d_adj_tri.upload(adj, s->dev_bytes);
+                for (int q = 0; q < 2; ++q)
+                    if (!s->h_nrm[q]) {
+                        s->d_nrm[q].alloc((size_t)s->n * 3, s->dev_bytes);
+                        HIP_CHECK(hipHostMalloc((void **)&s->h_nrm[q], (size_t)s->n * 3 * sizeof(float), hipHostMallocDefault));
+                    }
+                s->render_dirty = false;
+            }
+            hipLaunchKernelGGL(sbk::normals_kernel, dim3((unsigned)((s->n + 255) / 256)), dim3(256), 0, s->copy_stream, s->d_snap[k].p,
+                               s->d_adj_off.p, s->d_adj_tri.p, s->d_tri.p, s->d_nrm[k].p, (int)s->n);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipMemcpyAsync(s->h_nrm[k], s->d_nrm[k].p, (size_t)s->n * 3 * sizeof(float), hipMemcpyDeviceToHost, s->copy_stream));
+            s->snap_has_normals[k] = true;
+        }
         HIP_CHECK(hipEventRecord(s->ev_copied[k], s->copy_stream));
         ++s->snap_pending;
         return SB_OK;
@@ -1123,9 +1159,33 @@ int sb_readback_end(sb_solver *s, const float **pos_xyz_out) {
         const int k = s->snap_head;
         HIP_CHECK(hipEventSynchronize(s->ev_copied[k]));
         *pos_xyz_out = s->h_snap[k];
+        s->snap_last_ended = k;
         s->snap_head ^= 1; --s->snap_pending;
         return SB_OK;
     });
+}
+
+int sb_set_render_triangles(sb_solver *s, const int32_t *tri, int32_t m) {
+    if (!s || m < 0 || (m > 0 && !tri)) return fail(SB_ERR_INVALID_ARG, "sb_set_render_triangles: bad argument");
+    if (s->n <= 0) return fail(SB_ERR_STATE, "sb_set_render_triangles before sb_set_particles");
+    if (s->desc.world > 1) return fail(SB_ERR_STATE, "sb_set_render_triangles: render normals need a single-rank solver (world == 1)");
+    if (s->snap_pending) return fail(SB_ERR_STATE, "sb_set_render_triangles while a readback is pending");
+    return guarded([&]() -> int {
+        for (int64_t c = 0; c < 3 * (int64_t)m; ++c)
+            if (tri[c] < 0 || tri[c] >= s->n) return fail(SB_ERR_INVALID_ARG, "sb_set_render_triangles: particle index out of range");
+        s->render_tri.assign(tri, tri + 3 * (size_t)m);
+        s->render_dirty = true;
+        s->snap_has_normals[0] = s->snap_has_normals[1] = false;
+        return SB_OK;
+    });
+}
+
+int sb_readback_get_normals(sb_solver *s, const float **out) {
+    if (!s || !out) return fail(SB_ERR_INVALID_ARG, "sb_readback_get_normals: null argument");
+    if (s->snap_last_ended < 0 || !s->snap_has_normals[s->snap_last_ended])
+        return fail(SB_ERR_STATE, "sb_readback_get_normals: no finished readback with render triangles set");
+    *out = s->h_nrm[s->snap_last_ended];
+    return SB_OK;
 }
 
 int sb_get_owner(sb_solver *s, int32_t *owner, int32_t n) {

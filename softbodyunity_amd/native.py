@@ -72,6 +72,8 @@ SIGNATURES = {
     "sb_set_state": (C.c_int, [_P, _P, _P, C.c_int32]),
     "sb_readback_begin": (C.c_int, [_P]),
     "sb_readback_end": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_float))]),
+    "sb_set_render_triangles": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32]),
+    "sb_readback_get_normals": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_float))]),
     "sb_get_owner": (C.c_int, [_P, _P, C.c_int32]),
     "sb_profile_begin": (C.c_int, [_P]),
     "sb_profile_end": (C.c_int, [_P, C.POINTER(C.c_float)]),

@@ -119,11 +119,22 @@ class Softbody:
     def readback_begin(self):
         check(native.lib().sb_readback_begin(self._h))
 
-    def readback_end(self):
-        """-> (N,3) float32 view of the plugin's pinned snapshot (valid until the second readback_begin after it)."""
+    def readback_end(self, normals=False):
+        """-> (N,3) float32 view of the plugin's pinned snapshot (valid until the second readback_begin after it);
+        with normals=True -> (positions, vertex normals) -- needs set_render_triangles (SPEC.md 6a)."""
         p = C.POINTER(C.c_float)()
         check(native.lib().sb_readback_end(self._h, C.byref(p)))
-        return np.ctypeslib.as_array(p, shape=(self.n, 3))
+        pos = np.ctypeslib.as_array(p, shape=(self.n, 3))
+        if not normals:
+            return pos
+        q = C.POINTER(C.c_float)()
+        check(native.lib().sb_readback_get_normals(self._h, C.byref(q)))
+        return pos, np.ctypeslib.as_array(q, shape=(self.n, 3))
+
+    def set_render_triangles(self, tri):
+        """Render triangles (M,3) particle indices: every later readback also brings area-weighted vertex normals."""
+        tri = np.ascontiguousarray(tri, dtype=np.int32).reshape(-1, 3)
+        check(native.lib().sb_set_render_triangles(self._h, tri.ctypes.data_as(C.POINTER(C.c_int32)), tri.shape[0]))
 
     def set_state(self, pos, vel):
         pos = f32(pos, (-1, 3)); vel = f32(vel, (-1, 3))

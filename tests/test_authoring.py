@@ -113,3 +113,61 @@ def test_cloth_through_the_plugin(oracle_mod):
     rel, mabs, bit = oracle_mod.parity_error(x, o.x, m.pos)
     assert rel <= 1e-4 and bit
     assert x[:, 1].min() < -0.1                        # it did swing down (0.2 s of fall)
+
+
+# ---- render normals (SPEC.md §6a) ------------------------------------------------------------
+
+def test_oracle_vertex_normals_known_answers(oracle_mod):
+    V, F = grid_cloth(6)                                   # flat sheet in the xz plane... whichever: all normals equal
+    nrm = oracle_mod.vertex_normals(V, F)
+    n0 = nrm[0]
+    assert np.allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-6)
+    assert np.all(nrm == n0), "a flat sheet has one exact normal"
+    assert np.count_nonzero(n0) == 1 and abs(abs(n0).max() - 1.0) == 0.0
+    # reversing the winding flips the sign exactly
+    assert np.array_equal(oracle_mod.vertex_normals(V, F[:, ::-1]), -nrm)
+    # closed cube: the normal of a corner particle is the normalised sum of the face areas it touches
+    Vc, Fc = unity_cube()
+    m, pov = from_triangle_mesh(Vc, Fc)
+    tri = pov[Fc]
+    nc = oracle_mod.vertex_normals(m.rest_pos, tri)
+    centre = m.rest_pos.mean(0)
+    out = m.rest_pos - centre
+    assert np.all(np.einsum("ij,ij->i", nc, out) > 0) and np.allclose(np.linalg.norm(nc, axis=1), 1, atol=1e-6)
+    # a particle in no triangle, a degenerate triangle: zero normal, no NaN
+    x = np.array([[0, 0, 0], [1, 0, 0], [2, 0, 0], [5, 5, 5]], np.float32)
+    z = oracle_mod.vertex_normals(x, np.array([[0, 1, 2]], np.int32))
+    assert not z.any()
+
+
+@pytest.mark.gpu
+def test_gpu_render_normals_match_the_oracle(oracle_mod):
+    from softbodyunity_amd import Softbody, native
+    V, F = grid_cloth(40)
+    rng = np.random.default_rng(3)
+    V = V + rng.normal(0, 0.05, V.shape).astype(np.float32)
+    m, pov = from_triangle_mesh(V, F)
+    tri = pov[F]
+    m.inv_mass[:40] = 0.0
+    sb = Softbody(m, substeps=6, tile_particles=128, bending_compliance=1e-4).Start()
+    try:
+        with pytest.raises(native.SoftbodyError):          # no triangles yet
+            sb.readback_begin(); sb.readback_end(normals=True)
+        sb.set_render_triangles(tri)
+        for k in range(3):
+            sb.step()
+            sb.readback_begin()
+            sb.step()                                        # the next tick overlaps the copy and the normals kernel
+            pos, nrm = sb.readback_end(normals=True)
+            ref = oracle_mod.vertex_normals(pos, tri)
+            assert np.array_equal(nrm.view(np.uint32), ref.view(np.uint32)), f"snapshot {k}"
+            assert np.allclose(np.linalg.norm(nrm, axis=1), 1.0, atol=1e-5)
+        # fewer triangles: particles that lost all their triangles read zero
+        sb.set_render_triangles(tri[: len(tri) // 2])
+        sb.readback_begin(); pos, nrm = sb.readback_end(normals=True)
+        assert np.array_equal(nrm.view(np.uint32), oracle_mod.vertex_normals(pos, tri[: len(tri) // 2]).view(np.uint32))
+        assert (np.linalg.norm(nrm, axis=1) == 0).any()
+        with pytest.raises(native.SoftbodyError):
+            sb.set_render_triangles(np.array([[0, 1, m.n]], np.int32))
+    finally:
+        sb.OnDestroy()
