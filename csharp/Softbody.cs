@@ -37,6 +37,8 @@ namespace SoftbodyMI355X
         [SerializeField] int tileParticles = 512;
         [Tooltip("Render from the previous tick's snapshot: the D2H copy and the normals (computed on the GPU) overlap the next tick.")]
         [SerializeField] bool asyncReadback = false;
+        [Tooltip("With asyncReadback: copy only the particles the render triangles use (a volumetric body renders its surface only); the MeshFilter's mesh is rebuilt over that set.")]
+        [SerializeField] bool renderSetOnly = false;
 
         // constraint graph (filled by an authoring script or SoftbodyMeshBuilder before Start)
         public Vector3[] restPositions;
@@ -107,6 +109,21 @@ namespace SoftbodyMI355X
             {
                 SoftbodyNative.Check(SoftbodyNative.sb_set_render_triangles(handle, renderTriangles, renderTriangles.Length / 3), "sb_set_render_triangles");
                 normals = new Vector3[positions.Length];
+                if (renderSetOnly)
+                {
+                    // the plugin's render set = the particles the triangles use, ascending: rebuild the mesh over exactly that set
+                    SoftbodyNative.Check(SoftbodyNative.sb_set_readback_render_set_only(handle, 1), "sb_set_readback_render_set_only");
+                    var used = new System.Collections.Generic.SortedSet<int>(renderTriangles);
+                    var compactOf = new System.Collections.Generic.Dictionary<int, int>();
+                    var compactPos = new Vector3[used.Count];
+                    foreach (int p in used) { compactPos[compactOf.Count] = positions[p]; compactOf[p] = compactOf.Count; }
+                    var tri = new int[renderTriangles.Length];
+                    for (int k = 0; k < tri.Length; ++k) tri[k] = compactOf[renderTriangles[k]];
+                    posPin.Free();
+                    positions = compactPos; normals = new Vector3[compactPos.Length];
+                    posPin = GCHandle.Alloc(positions, GCHandleType.Pinned);
+                    mesh.Clear(); mesh.vertices = positions; mesh.triangles = tri;
+                }
             }
         }
 

@@ -77,6 +77,8 @@ namespace SoftbodyMI355X
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_readback_end(IntPtr s, out IntPtr posXyz);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_render_triangles(IntPtr s, int[] triAbc, int m);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_readback_get_normals(IntPtr s, out IntPtr normalXyz);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_readback_render_set_only(IntPtr s, int renderSetOnly);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_readback_get_render_set(IntPtr s, out IntPtr ids, out int count);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_get_owner(IntPtr s, IntPtr ownerRankOut, int n);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_profile_begin(IntPtr s);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_profile_end(IntPtr s, out float elapsedMs);

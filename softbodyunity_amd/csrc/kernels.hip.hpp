@@ -576,12 +576,16 @@ __global__ __launch_bounds__(256) void snapshot_kernel(PosView pos, const int32_
 // SPEC.md §6a: area-weighted vertex normals on a position snapshot in caller numbering. One lane per vertex gathers its
 // incident triangles in ascending order (adj lists built on the host), so the additions happen in the oracle's order.
 __global__ __launch_bounds__(256) void normals_kernel(const float *snap_xyz, const int32_t *adj_off, const int32_t *adj_tri,
-                                                      const int32_t *tri, float *nrm_xyz, int n) {
-    const int v = blockIdx.x * 256 + threadIdx.x;
-    if (v >= n) return;
+                                                      const int32_t *tri, float *nrm_xyz, int n, const int32_t *subset,
+                                                      float *subset_pos_xyz) {
+    // subset == nullptr: lane k handles particle k and writes normal k. Otherwise lane k handles particle subset[k] and
+    // writes compact entry k of the normals AND of the positions (the render set travels to the host on its own).
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= n) return;
+    const int v = subset ? subset[k] : k;
     float nx = 0.0f, ny = 0.0f, nz = 0.0f;
-    for (int k = adj_off[v]; k < adj_off[v + 1]; ++k) {
-        const int t = adj_tri[k];
+    for (int q = adj_off[v]; q < adj_off[v + 1]; ++q) {
+        const int t = adj_tri[q];
         const size_t a = 3 * (size_t)tri[3 * t], b = 3 * (size_t)tri[3 * t + 1], c = 3 * (size_t)tri[3 * t + 2];
         const V3 xa = {snap_xyz[a], snap_xyz[a + 1], snap_xyz[a + 2]};
         const V3 e1 = sub3({snap_xyz[b], snap_xyz[b + 1], snap_xyz[b + 2]}, xa);
@@ -593,8 +597,12 @@ __global__ __launch_bounds__(256) void normals_kernel(const float *snap_xyz, con
     float L2 = (xx + yy) + zz;
     if (L2 >= 0x1p-96f) { float L = sqrt_rn_normal(L2); nx = nx / L; ny = ny / L; nz = nz / L; }
     else { nx = 0.0f; ny = 0.0f; nz = 0.0f; }
-    const size_t o = 3 * (size_t)v;
+    const size_t o = 3 * (size_t)k;
     nrm_xyz[o] = nx; nrm_xyz[o + 1] = ny; nrm_xyz[o + 2] = nz;
+    if (subset) {
+        const size_t sv = 3 * (size_t)v;
+        subset_pos_xyz[o] = snap_xyz[sv]; subset_pos_xyz[o + 1] = snap_xyz[sv + 1]; subset_pos_xyz[o + 2] = snap_xyz[sv + 2];
+    }
 }
 
 // Halo pack / unpack: a ghost travels as 3 floats (position) or, WITH_PREV, 6 floats (position, previous position:

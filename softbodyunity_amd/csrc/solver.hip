@@ -159,7 +159,12 @@ struct sb_solver {
     // render normals of the snapshots (sb_set_render_triangles): incident-triangle lists per particle, caller numbering
     std::vector<int32_t> render_tri;
     bool render_dirty = false;             // triangles changed since the last upload
-    DevBuf<int32_t> d_tri, d_adj_off, d_adj_tri;
+    DevBuf<int32_t> d_tri, d_adj_off, d_adj_tri, d_render_set;
+    std::vector<int32_t> render_set;       // particles used by the render triangles, ascending
+    bool render_set_only = false;          // readbacks bring the render set only (compact positions + normals)
+    DevBuf<float> d_cpos[2];               // compact positions of the render set
+    float *h_cpos[2] = {nullptr, nullptr};
+    bool snap_compact[2] = {false, false};
     DevBuf<float> d_nrm[2];
     float *h_nrm[2] = {nullptr, nullptr};
     bool snap_has_normals[2] = {false, false};
@@ -175,6 +180,7 @@ struct sb_solver {
         for (int k = 0; k < 2; ++k) {
             if (h_snap[k]) (void)hipHostFree(h_snap[k]);
             if (h_nrm[k]) (void)hipHostFree(h_nrm[k]);
+            if (h_cpos[k]) (void)hipHostFree(h_cpos[k]);
             if (ev_snap[k]) (void)hipEventDestroy(ev_snap[k]);
             if (ev_copied[k]) (void)hipEventDestroy(ev_copied[k]);
         }
@@ -1117,32 +1123,45 @@ int sb_readback_begin(sb_solver *s) {
         HIP_CHECK(hipEventRecord(s->ev_snap[k], s->stream));
         // ... D2H on the copy stream, overlapping whatever the compute stream does next
         HIP_CHECK(hipStreamWaitEvent(s->copy_stream, s->ev_snap[k], 0));
-        HIP_CHECK(hipMemcpyAsync(s->h_snap[k], s->d_snap[k].p, (size_t)s->n * 3 * sizeof(float), hipMemcpyDeviceToHost, s->copy_stream));
+        const bool compact = s->render_set_only && !s->render_tri.empty();
+        if (!compact)
+            HIP_CHECK(hipMemcpyAsync(s->h_snap[k], s->d_snap[k].p, (size_t)s->n * 3 * sizeof(float), hipMemcpyDeviceToHost, s->copy_stream));
         s->snap_has_normals[k] = false;
+        s->snap_compact[k] = compact;
         if (!s->render_tri.empty()) {
             if (s->render_dirty) {     // (re)build the incident-triangle lists: triangle ids ascending per particle
                 HIP_CHECK(hipStreamSynchronize(s->copy_stream));
                 const int64_t m = (int64_t)s->render_tri.size() / 3;
                 std::vector<int32_t> off((size_t)s->n + 1, 0), adj((size_t)3 * m);
                 for (int64_t c = 0; c < 3 * m; ++c) ++off[(size_t)s->render_tri[c] + 1];
-                for (int32_t v = 0; v < s->n; ++v) off[(size_t)v + 1] += off[v];
+                s->render_set.clear();
+                for (int32_t v = 0; v < s->n; ++v) { if (off[(size_t)v + 1]) s->render_set.push_back(v); off[(size_t)v + 1] += off[v]; }
                 std::vector<int32_t> cur(off.begin(), off.end() - 1);
                 for (int64_t t = 0; t < m; ++t)
                     for (int j = 0; j < 3; ++j) adj[(size_t)cur[s->render_tri[3 * t + j]]++] = (int32_t)t;
                 s->d_tri.upload(s->render_tri, s->dev_bytes);
                 s->d_adj_off.upload(off, s->dev_bytes);
                 s->d_adj_tri.upload(adj, s->dev_bytes);
-                for (int q = 0; q < 2; ++q)
+                s->d_render_set.upload(s->render_set, s->dev_bytes);
+                for (int q = 0; q < 2; ++q) {
                     if (!s->h_nrm[q]) {
                         s->d_nrm[q].alloc((size_t)s->n * 3, s->dev_bytes);
                         HIP_CHECK(hipHostMalloc((void **)&s->h_nrm[q], (size_t)s->n * 3 * sizeof(float), hipHostMallocDefault));
                     }
+                    s->d_cpos[q].alloc(s->render_set.size() * 3, s->dev_bytes);
+                    if (s->h_cpos[q]) { (void)hipHostFree(s->h_cpos[q]); s->h_cpos[q] = nullptr; }
+                    HIP_CHECK(hipHostMalloc((void **)&s->h_cpos[q], std::max<size_t>(s->render_set.size(), 1) * 3 * sizeof(float), hipHostMallocDefault));
+                }
                 s->render_dirty = false;
             }
-            hipLaunchKernelGGL(sbk::normals_kernel, dim3((unsigned)((s->n + 255) / 256)), dim3(256), 0, s->copy_stream, s->d_snap[k].p,
-                               s->d_adj_off.p, s->d_adj_tri.p, s->d_tri.p, s->d_nrm[k].p, (int)s->n);
+            const int count = compact ? (int)s->render_set.size() : (int)s->n;
+            hipLaunchKernelGGL(sbk::normals_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s->copy_stream, s->d_snap[k].p,
+                               s->d_adj_off.p, s->d_adj_tri.p, s->d_tri.p, s->d_nrm[k].p, count,
+                               compact ? s->d_render_set.p : (const int32_t *)nullptr, compact ? s->d_cpos[k].p : (float *)nullptr);
             HIP_CHECK(hipGetLastError());
-            HIP_CHECK(hipMemcpyAsync(s->h_nrm[k], s->d_nrm[k].p, (size_t)s->n * 3 * sizeof(float), hipMemcpyDeviceToHost, s->copy_stream));
+            HIP_CHECK(hipMemcpyAsync(s->h_nrm[k], s->d_nrm[k].p, (size_t)count * 3 * sizeof(float), hipMemcpyDeviceToHost, s->copy_stream));
+            if (compact)
+                HIP_CHECK(hipMemcpyAsync(s->h_cpos[k], s->d_cpos[k].p, (size_t)count * 3 * sizeof(float), hipMemcpyDeviceToHost, s->copy_stream));
             s->snap_has_normals[k] = true;
         }
         HIP_CHECK(hipEventRecord(s->ev_copied[k], s->copy_stream));
@@ -1158,7 +1177,7 @@ int sb_readback_end(sb_solver *s, const float **pos_xyz_out) {
         int rc = set_device(s); if (rc) return rc;
         const int k = s->snap_head;
         HIP_CHECK(hipEventSynchronize(s->ev_copied[k]));
-        *pos_xyz_out = s->h_snap[k];
+        *pos_xyz_out = s->snap_compact[k] ? s->h_cpos[k] : s->h_snap[k];
         s->snap_last_ended = k;
         s->snap_head ^= 1; --s->snap_pending;
         return SB_OK;
@@ -1175,6 +1194,7 @@ int sb_set_render_triangles(sb_solver *s, const int32_t *tri, int32_t m) {
             if (tri[c] < 0 || tri[c] >= s->n) return fail(SB_ERR_INVALID_ARG, "sb_set_render_triangles: particle index out of range");
         s->render_tri.assign(tri, tri + 3 * (size_t)m);
         s->render_dirty = true;
+        if (m == 0) s->render_set_only = false;
         s->snap_has_normals[0] = s->snap_has_normals[1] = false;
         return SB_OK;
     });
@@ -1185,6 +1205,23 @@ int sb_readback_get_normals(sb_solver *s, const float **out) {
     if (s->snap_last_ended < 0 || !s->snap_has_normals[s->snap_last_ended])
         return fail(SB_ERR_STATE, "sb_readback_get_normals: no finished readback with render triangles set");
     *out = s->h_nrm[s->snap_last_ended];
+    return SB_OK;
+}
+
+int sb_set_readback_render_set_only(sb_solver *s, int32_t on) {
+    if (!s) return fail(SB_ERR_INVALID_ARG, "sb_set_readback_render_set_only: null handle");
+    if (s->snap_pending) return fail(SB_ERR_STATE, "sb_set_readback_render_set_only while a readback is pending");
+    if (on && s->render_tri.empty()) return fail(SB_ERR_STATE, "sb_set_readback_render_set_only: set the render triangles first");
+    s->render_set_only = on != 0;
+    return SB_OK;
+}
+
+int sb_readback_get_render_set(sb_solver *s, const int32_t **ids, int32_t *count) {
+    if (!s || !ids || !count) return fail(SB_ERR_INVALID_ARG, "sb_readback_get_render_set: null argument");
+    if (s->snap_last_ended < 0 || !s->snap_has_normals[s->snap_last_ended])
+        return fail(SB_ERR_STATE, "sb_readback_get_render_set: no finished readback with render triangles set");
+    *ids = s->render_set.data();
+    *count = (int32_t)s->render_set.size();
     return SB_OK;
 }
 

@@ -74,6 +74,8 @@ SIGNATURES = {
     "sb_readback_end": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_float))]),
     "sb_set_render_triangles": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32]),
     "sb_readback_get_normals": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_float))]),
+    "sb_set_readback_render_set_only": (C.c_int, [_P, C.c_int32]),
+    "sb_readback_get_render_set": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int32)]),
     "sb_get_owner": (C.c_int, [_P, _P, C.c_int32]),
     "sb_profile_begin": (C.c_int, [_P]),
     "sb_profile_end": (C.c_int, [_P, C.POINTER(C.c_float)]),

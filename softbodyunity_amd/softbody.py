@@ -32,6 +32,7 @@ class Softbody:
         self.unique_id = unique_id
         self.ground_plane = ground_plane   # None or (nx, ny, nz, d): n.x >= d
         self._h = None
+        self._render_set_only = False
         self.vertices = None  # what the C# component assigns to mesh.vertices after each FixedUpdate
 
     # ---- MonoBehaviour surface ------------------------------------------------------------------
@@ -121,15 +122,30 @@ class Softbody:
 
     def readback_end(self, normals=False):
         """-> (N,3) float32 view of the plugin's pinned snapshot (valid until the second readback_begin after it);
-        with normals=True -> (positions, vertex normals) -- needs set_render_triangles (SPEC.md 6a)."""
+        with normals=True -> (positions, vertex normals) -- needs set_render_triangles (SPEC.md 6a). In render-set-only
+        mode both arrays are compact, (count,3), entry k belonging to particle render_set()[k]."""
         p = C.POINTER(C.c_float)()
         check(native.lib().sb_readback_end(self._h, C.byref(p)))
-        pos = np.ctypeslib.as_array(p, shape=(self.n, 3))
+        rows = self.n
+        if self._render_set_only:
+            rows = len(self.render_set())
+        pos = np.ctypeslib.as_array(p, shape=(rows, 3))
         if not normals:
             return pos
         q = C.POINTER(C.c_float)()
         check(native.lib().sb_readback_get_normals(self._h, C.byref(q)))
-        return pos, np.ctypeslib.as_array(q, shape=(self.n, 3))
+        return pos, np.ctypeslib.as_array(q, shape=(rows, 3))
+
+    def set_readback_render_set_only(self, on=True):
+        """Readbacks bring only the particles the render triangles use (compact arrays)."""
+        check(native.lib().sb_set_readback_render_set_only(self._h, 1 if on else 0))
+        self._render_set_only = bool(on)
+
+    def render_set(self):
+        """Particle ids (ascending) of the compact readback entries; valid after a finished readback."""
+        ids = C.POINTER(C.c_int32)(); cnt = C.c_int32()
+        check(native.lib().sb_readback_get_render_set(self._h, C.byref(ids), C.byref(cnt)))
+        return np.ctypeslib.as_array(ids, shape=(cnt.value,)) if cnt.value else np.zeros(0, np.int32)
 
     def set_render_triangles(self, tri):
         """Render triangles (M,3) particle indices: every later readback also brings area-weighted vertex normals."""

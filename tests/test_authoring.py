@@ -171,3 +171,35 @@ def test_gpu_render_normals_match_the_oracle(oracle_mod):
             sb.set_render_triangles(np.array([[0, 1, m.n]], np.int32))
     finally:
         sb.OnDestroy()
+
+
+@pytest.mark.gpu
+def test_gpu_render_set_only_readback_is_the_compact_view_of_the_full_one(oracle_mod):
+    # a volumetric body renders its surface: the readback can bring only the particles the render triangles use
+    from softbodyunity_amd import Softbody, jelly_cube
+    sys_path_tools = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))), "tools")
+    __import__("sys").path.insert(0, sys_path_tools)
+    from readback_bench import surface_triangles
+    n = 20
+    mesh = jelly_cube(n)
+    tri = surface_triangles(n)
+    sb = Softbody(mesh, substeps=5).Start()
+    try:
+        sb.set_render_triangles(tri)
+        sb.step(); sb.readback_begin()
+        full_pos, full_nrm = (a.copy() for a in sb.readback_end(normals=True))
+        sb.set_readback_render_set_only(True)
+        sb.readback_begin()                                  # same state, compact view
+        pos, nrm = sb.readback_end(normals=True)
+        ids = sb.render_set()
+        assert len(ids) == n ** 3 - (n - 2) ** 3 and np.array_equal(ids, np.unique(tri))
+        assert pos.shape == (len(ids), 3) and np.array_equal(pos, full_pos[ids]) and np.array_equal(nrm, full_nrm[ids])
+        assert np.array_equal(nrm.view(np.uint32), oracle_mod.vertex_normals(full_pos, tri)[ids].view(np.uint32))
+        # outward normals on the cube's faces
+        c = full_pos.mean(0)
+        assert (np.einsum("ij,ij->i", nrm, pos - c) > 0).mean() > 0.99
+        sb.set_readback_render_set_only(False)
+        sb.readback_begin()
+        assert sb.readback_end().shape == (mesh.n, 3)
+    finally:
+        sb.OnDestroy()
