@@ -573,6 +573,16 @@ __global__ __launch_bounds__(256) void snapshot_kernel(PosView pos, const int32_
     out_xyz[o] = p.x; out_xyz[o + 1] = p.y; out_xyz[o + 2] = p.z;
 }
 
+// Snapshot of the render set only: entry subset[k] of the caller-numbered snapshot <- particle local_of_subset[k].
+__global__ __launch_bounds__(256) void snapshot_subset_kernel(PosView pos, const int32_t *subset, const int32_t *local_of_subset,
+                                                             float *out_xyz, int count) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
+    const float4 p = pv_load(pos, local_of_subset[k]);
+    const size_t o = 3 * (size_t)subset[k];
+    out_xyz[o] = p.x; out_xyz[o + 1] = p.y; out_xyz[o + 2] = p.z;
+}
+
 // SPEC.md §6a: area-weighted vertex normals on a position snapshot in caller numbering. One lane per vertex gathers its
 // incident triangles in ascending order (adj lists built on the host), so the additions happen in the oracle's order.
 __global__ __launch_bounds__(256) void normals_kernel(const float *snap_xyz, const int32_t *adj_off, const int32_t *adj_tri,

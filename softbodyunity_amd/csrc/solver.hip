@@ -159,7 +159,7 @@ struct sb_solver {
     // render normals of the snapshots (sb_set_render_triangles): incident-triangle lists per particle, caller numbering
     std::vector<int32_t> render_tri;
     bool render_dirty = false;             // triangles changed since the last upload
-    DevBuf<int32_t> d_tri, d_adj_off, d_adj_tri, d_render_set;
+    DevBuf<int32_t> d_tri, d_adj_off, d_adj_tri, d_render_set, d_render_local;
     std::vector<int32_t> render_set;       // particles used by the render triangles, ascending
     bool render_set_only = false;          // readbacks bring the render set only (compact positions + normals)
     DevBuf<float> d_cpos[2];               // compact positions of the render set
@@ -1117,43 +1117,51 @@ int sb_readback_begin(sb_solver *s) {
         flush_deferred(s);
         const int k = (s->snap_head + s->snap_pending) & 1;
         // snapshot on the compute stream (ordered after every tick enqueued so far, before the next one) ...
-        if (s->n_owned)
+        const bool compact = s->render_set_only && !s->render_tri.empty();
+        if (!s->render_tri.empty() && s->render_dirty) {     // (re)build the incident-triangle lists: triangle ids ascending per particle
+            HIP_CHECK(hipStreamSynchronize(s->copy_stream));
+            const int64_t m = (int64_t)s->render_tri.size() / 3;
+            std::vector<int32_t> off((size_t)s->n + 1, 0), adj((size_t)3 * m);
+            for (int64_t c = 0; c < 3 * m; ++c) ++off[(size_t)s->render_tri[c] + 1];
+            s->render_set.clear();
+            for (int32_t v = 0; v < s->n; ++v) { if (off[(size_t)v + 1]) s->render_set.push_back(v); off[(size_t)v + 1] += off[v]; }
+            std::vector<int32_t> cur(off.begin(), off.end() - 1);
+            for (int64_t t = 0; t < m; ++t)
+                for (int j = 0; j < 3; ++j) adj[(size_t)cur[s->render_tri[3 * t + j]]++] = (int32_t)t;
+            std::vector<int32_t> local_of(s->render_set.size());      // world == 1: local numbering = the planner's new numbering
+            for (size_t q = 0; q < local_of.size(); ++q) local_of[q] = s->plan->plan.new_of_old[s->render_set[q]];
+            s->d_tri.upload(s->render_tri, s->dev_bytes);
+            s->d_adj_off.upload(off, s->dev_bytes);
+            s->d_adj_tri.upload(adj, s->dev_bytes);
+            s->d_render_set.upload(s->render_set, s->dev_bytes);
+            s->d_render_local.upload(local_of, s->dev_bytes);
+            for (int q = 0; q < 2; ++q) {
+                if (!s->h_nrm[q]) {
+                    s->d_nrm[q].alloc((size_t)s->n * 3, s->dev_bytes);
+                    HIP_CHECK(hipHostMalloc((void **)&s->h_nrm[q], (size_t)s->n * 3 * sizeof(float), hipHostMallocDefault));
+                }
+                s->d_cpos[q].alloc(s->render_set.size() * 3, s->dev_bytes);
+                if (s->h_cpos[q]) { (void)hipHostFree(s->h_cpos[q]); s->h_cpos[q] = nullptr; }
+                HIP_CHECK(hipHostMalloc((void **)&s->h_cpos[q], std::max<size_t>(s->render_set.size(), 1) * 3 * sizeof(float), hipHostMallocDefault));
+            }
+            s->render_dirty = false;
+        }
+        if (compact) {      // only the render set leaves the device: snapshot just those particles
+            const int cnt = (int)s->render_set.size();
+            if (cnt)
+                hipLaunchKernelGGL(sbk::snapshot_subset_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s->stream, s->pos_view(),
+                                   s->d_render_set.p, s->d_render_local.p, s->d_snap[k].p, cnt);
+        } else if (s->n_owned)
             hipLaunchKernelGGL(sbk::snapshot_kernel, dim3((unsigned)((s->n_owned + 255) / 256)), dim3(256), 0, s->stream,
                                s->pos_view(), s->d_local_to_old.p, s->d_snap[k].p, (int)s->n_owned);
         HIP_CHECK(hipEventRecord(s->ev_snap[k], s->stream));
         // ... D2H on the copy stream, overlapping whatever the compute stream does next
         HIP_CHECK(hipStreamWaitEvent(s->copy_stream, s->ev_snap[k], 0));
-        const bool compact = s->render_set_only && !s->render_tri.empty();
         if (!compact)
             HIP_CHECK(hipMemcpyAsync(s->h_snap[k], s->d_snap[k].p, (size_t)s->n * 3 * sizeof(float), hipMemcpyDeviceToHost, s->copy_stream));
         s->snap_has_normals[k] = false;
         s->snap_compact[k] = compact;
         if (!s->render_tri.empty()) {
-            if (s->render_dirty) {     // (re)build the incident-triangle lists: triangle ids ascending per particle
-                HIP_CHECK(hipStreamSynchronize(s->copy_stream));
-                const int64_t m = (int64_t)s->render_tri.size() / 3;
-                std::vector<int32_t> off((size_t)s->n + 1, 0), adj((size_t)3 * m);
-                for (int64_t c = 0; c < 3 * m; ++c) ++off[(size_t)s->render_tri[c] + 1];
-                s->render_set.clear();
-                for (int32_t v = 0; v < s->n; ++v) { if (off[(size_t)v + 1]) s->render_set.push_back(v); off[(size_t)v + 1] += off[v]; }
-                std::vector<int32_t> cur(off.begin(), off.end() - 1);
-                for (int64_t t = 0; t < m; ++t)
-                    for (int j = 0; j < 3; ++j) adj[(size_t)cur[s->render_tri[3 * t + j]]++] = (int32_t)t;
-                s->d_tri.upload(s->render_tri, s->dev_bytes);
-                s->d_adj_off.upload(off, s->dev_bytes);
-                s->d_adj_tri.upload(adj, s->dev_bytes);
-                s->d_render_set.upload(s->render_set, s->dev_bytes);
-                for (int q = 0; q < 2; ++q) {
-                    if (!s->h_nrm[q]) {
-                        s->d_nrm[q].alloc((size_t)s->n * 3, s->dev_bytes);
-                        HIP_CHECK(hipHostMalloc((void **)&s->h_nrm[q], (size_t)s->n * 3 * sizeof(float), hipHostMallocDefault));
-                    }
-                    s->d_cpos[q].alloc(s->render_set.size() * 3, s->dev_bytes);
-                    if (s->h_cpos[q]) { (void)hipHostFree(s->h_cpos[q]); s->h_cpos[q] = nullptr; }
-                    HIP_CHECK(hipHostMalloc((void **)&s->h_cpos[q], std::max<size_t>(s->render_set.size(), 1) * 3 * sizeof(float), hipHostMallocDefault));
-                }
-                s->render_dirty = false;
-            }
             const int count = compact ? (int)s->render_set.size() : (int)s->n;
             hipLaunchKernelGGL(sbk::normals_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s->copy_stream, s->d_snap[k].p,
                                s->d_adj_off.p, s->d_adj_tri.p, s->d_tri.p, s->d_nrm[k].p, count,
