@@ -152,6 +152,7 @@ struct sb_solver {
     // asynchronous render readback (sb_readback_begin / sb_readback_end): two snapshot slots
     hipStream_t copy_stream = nullptr;
     DevBuf<int32_t> d_local_to_old;
+    DevBuf<float> d_get_scratch;           // caller-numbered staging of the blocking sb_get_* calls (world == 1)
     DevBuf<float> d_snap[2];
     float *h_snap[2] = {nullptr, nullptr};
     hipEvent_t ev_snap[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
@@ -1051,21 +1052,28 @@ static int get_state(sb_solver *s, float *out, int32_t n, bool velocity) {
         int rc = set_device(s); if (rc) return rc;
         const sbp::LocalPlan &L = s->plan->local;
         flush_deferred(s);
+        if (s->desc.world == 1) {
+            // single rank: every entry is ours, so the permutation to caller numbering runs on the GPU and one copy
+            // lands in the caller's array (the host-side scatter below costs 25 ms for 16.7 M particles)
+            if (!s->d_local_to_old.p) s->d_local_to_old.upload(L.local_to_old, s->dev_bytes);
+            if (!s->d_get_scratch.p) s->d_get_scratch.alloc((size_t)s->n * 3, s->dev_bytes);
+            sbk::PosView src = s->pos_view();
+            if (velocity) src.xyz = s->d_vel.p;
+            hipLaunchKernelGGL(sbk::snapshot_kernel, dim3((unsigned)((s->n_owned + 255) / 256)), dim3(256), 0, s->stream, src,
+                               s->d_local_to_old.p, s->d_get_scratch.p, (int)s->n_owned);
+            HIP_CHECK(hipGetLastError());
+            HIP_CHECK(hipMemcpyAsync(out, s->d_get_scratch.p, (size_t)s->n * 3 * sizeof(float), hipMemcpyDeviceToHost, s->stream));
+            HIP_CHECK(hipStreamSynchronize(s->stream));
+            return SB_OK;
+        }
         HIP_CHECK(hipStreamSynchronize(s->stream));
-        if (velocity) {
-            std::vector<float> h((size_t)s->n_owned * 3);
-            if (s->n_owned) HIP_CHECK(hipMemcpy(h.data(), s->d_vel.p, h.size() * sizeof(float), hipMemcpyDeviceToHost));
-            for (int64_t l = 0; l < s->n_owned; ++l) {
-                int32_t o = L.local_to_old[l];
-                out[3 * (size_t)o] = h[3 * l]; out[3 * (size_t)o + 1] = h[3 * l + 1]; out[3 * (size_t)o + 2] = h[3 * l + 2];
-            }
-        } else {
-            s->h_stage.resize((size_t)s->n_owned * 3);
-            if (s->n_owned) HIP_CHECK(hipMemcpy(s->h_stage.data(), s->d_pos3.p, (size_t)s->n_owned * 3 * sizeof(float), hipMemcpyDeviceToHost));
-            for (int64_t l = 0; l < s->n_owned; ++l) {
-                int32_t o = L.local_to_old[l];
-                for (int c = 0; c < 3; ++c) out[3 * (size_t)o + c] = s->h_stage[3 * (size_t)l + c];
-            }
+        // world > 1: only the entries this rank owns may be written (the caller merges the ranks' arrays)
+        s->h_stage.resize((size_t)s->n_owned * 3);
+        const float *src = velocity ? s->d_vel.p : s->d_pos3.p;
+        if (s->n_owned) HIP_CHECK(hipMemcpy(s->h_stage.data(), src, (size_t)s->n_owned * 3 * sizeof(float), hipMemcpyDeviceToHost));
+        for (int64_t l = 0; l < s->n_owned; ++l) {
+            int32_t o = L.local_to_old[l];
+            for (int c = 0; c < 3; ++c) out[3 * (size_t)o + c] = s->h_stage[3 * (size_t)l + c];
         }
         return SB_OK;
     });
@@ -1104,7 +1112,7 @@ int sb_readback_begin(sb_solver *s) {
         int rc = set_device(s); if (rc) return rc;
         if (!s->copy_stream) {
             HIP_CHECK(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
-            s->d_local_to_old.upload(s->plan->local.local_to_old, s->dev_bytes);
+            if (!s->d_local_to_old.p) s->d_local_to_old.upload(s->plan->local.local_to_old, s->dev_bytes);
             for (int k = 0; k < 2; ++k) {
                 s->d_snap[k].alloc((size_t)s->n * 3, s->dev_bytes);
                 HIP_CHECK(hipMemset(s->d_snap[k].p, 0, (size_t)s->n * 3 * sizeof(float)));
