@@ -299,3 +299,40 @@ def test_both_workgroup_widths_match_the_oracle(oracle_mod, bunny20k, monkeypatc
     assert bit and np.array_equal(v.view(np.uint32), o.v.view(np.uint32)), (rel, mabs)
     rel, mabs, bit, x, v, o, st = _run_pair(oracle_mod, bunny20k, ticks=2, substeps=6, compliance=(1e-7, 1e-7, 1e-5), tile_particles=256)
     assert bit and np.array_equal(v.view(np.uint32), o.v.view(np.uint32)), (rel, mabs)
+
+
+def test_bench_configuration_256_properties(monkeypatch):
+    # BASELINE.json:9 at full size (16.8 M particles, 50.1 M springs): no oracle run, size-independent properties instead --
+    # (1) the rest lattice is a bitwise fixed point without gravity, (2) both workgroup widths and the unpacked launch
+    # give the same bits after two ticks of the perturbed cube, (3) the centre of mass stays put, springs relax
+    rest = jelly_cube(256, perturb=0.0)
+    sb = Softbody(rest, gravity=(0, 0, 0), substeps=20).Start()
+    try:
+        sb.step(); sb.step()
+        assert np.array_equal(sb.get_positions().view(np.uint32), rest.pos.view(np.uint32)) and not sb.get_velocities().any()
+        assert sb.stats()["n_tiles"][0] == 32768
+    finally:
+        sb.OnDestroy()
+    del rest
+    mesh = jelly_cube(256)
+    runs = []
+    for env in ({"SB_TILE_LANES": "128"}, {"SB_TILE_LANES": "256"}, {"SB_NO_PACK": "1"}):
+        for k in ("SB_TILE_LANES", "SB_NO_PACK"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        sb = Softbody(mesh, gravity=(0, 0, 0), substeps=20).Start()
+        try:
+            sb.step(); sb.step()
+            runs.append((sb.get_positions().copy(), sb.get_velocities().copy()))
+        finally:
+            sb.OnDestroy()
+    for x, v in runs[1:]:
+        assert np.array_equal(x.view(np.uint32), runs[0][0].view(np.uint32)) and np.array_equal(v.view(np.uint32), runs[0][1].view(np.uint32))
+    x = runs[0][0]
+    assert np.isfinite(x).all()
+    assert np.abs(x.astype(np.float64).mean(0) - mesh.pos.astype(np.float64).mean(0)).max() < 1e-4
+    ij = mesh.dist_ij[::97]
+    d0 = np.linalg.norm(mesh.pos[ij[:, 0]] - mesh.pos[ij[:, 1]], axis=1) - 1.0
+    d1 = np.linalg.norm(x[ij[:, 0]] - x[ij[:, 1]], axis=1) - 1.0
+    assert np.abs(d1).mean() < 0.5 * np.abs(d0).mean()
