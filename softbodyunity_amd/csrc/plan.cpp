@@ -6,6 +6,9 @@
 #include <cstring>
 #include <numeric>
 #include <stdexcept>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
 
 namespace sbp {
 namespace {
@@ -24,6 +27,17 @@ inline void set_bit(Mask128 &m, int c) {
 }
 
 const int kVerts[3] = {2, 4, 4};
+
+struct PlanTimer {      // SB_PLAN_TIMING=1: phase times of build_plan on stderr
+    bool on = std::getenv("SB_PLAN_TIMING") != nullptr;
+    std::chrono::steady_clock::time_point t = std::chrono::steady_clock::now();
+    void lap(const char *what) {
+        if (!on) return;
+        auto n = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[plan] %-28s %8.1f ms\n", what, std::chrono::duration<double, std::milli>(n - t).count());
+        t = n;
+    }
+};
 
 struct Cons {  // view over the three input arrays
     const Input *in;
@@ -116,6 +130,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
     const int32_t n = in.n;
     if (n <= 0) throw std::runtime_error("no particles");
     if (opts.world < 1 || opts.rank < 0 || opts.rank >= opts.world) throw std::runtime_error("bad rank/world");
+    PlanTimer timer;
     Cons C{&in};
     P.n = n;
     P.m[0] = in.m_d; P.m[1] = in.m_v; P.m[2] = in.m_b;
@@ -131,6 +146,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
             }
         }
     }
+    timer.lap("validate");
     // ---- geometry: spacing estimate, bounding box --------------------------------------------
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
     for (int32_t p = 0; p < n; ++p)
@@ -201,6 +217,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
     }
     const int cap = tiling ? std::min(kMaxTileLocal, std::max(2 * target, 64)) : 512;
 
+    timer.lap("geometry + cells");
     // ---- tiling T1 (shifted cells), computed first so that T0 can order its particles by T1 tile ----
     std::vector<int32_t> t1_of_old(n, 0);
     int32_t n_t1 = 0;
@@ -223,6 +240,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         for (int32_t c = 0; c < n_t1; ++c)
             for (int32_t q = begins[c]; q < begins[c + 1]; ++q) t1_of_old[bys[q]] = c;
     }
+    timer.lap("tiling T1");
     // ---- tiling T0 (aligned cells, grouped by owner) ---------------------------------------------
     std::vector<int32_t> byc(n);
     std::iota(byc.begin(), byc.end(), 0);
@@ -262,6 +280,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
     P.new_of_old.resize(n);
     for (int32_t q = 0; q < n; ++q) P.new_of_old[byc[q]] = q;
 
+    timer.lap("tiling T0");
     // ---- tiles: runs and tile-local indices ------------------------------------------------------
     std::vector<int32_t> lidx[2];           // tile-local index of every particle (new numbering)
     const std::vector<int32_t> *tile_of[2] = {&t0_of_old, &t1_of_old};
@@ -318,6 +337,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         }
     }
 
+    timer.lap("runs");
     // ---- classify constraints --------------------------------------------------------------------
     // bit0: inside T0, bit1: inside T1
     std::vector<uint8_t> cls[3];
@@ -332,6 +352,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         }
     }
 
+    timer.lap("classify");
     // ---- static split: S0 (run on T0 tiles) / S1 (run on T1 tiles) -------------------------------
     // own[t][k]: 0 -> S0, 1 -> S1, 2 -> global colours. Constraints inside only one tiling have no choice. The ones
     // inside both are labelled by alternating propagation: within one type and one direction bucket (distance
@@ -402,6 +423,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         for (int64_t k = 0; k < M; ++k) if (label[k] >= 0) own[t][k] = (uint8_t)label[k];
     }
 
+    timer.lap("static split");
     // ---- tile programs ---------------------------------------------------------------------------
     // seq[tl] = (type,id) of S_tl in execution order; tile slices recorded in the tiles
     std::vector<uint8_t> seq_type[2];
@@ -470,6 +492,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         }
     }
 
+    timer.lap("tile programs");
     // ---- global colours for constraints inside neither tiling ------------------------------------
     {
         std::vector<Mask128> gused;
@@ -497,6 +520,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
     }
     P.cons_in_tiles = P.m[0] + P.m[1] + P.m[2] - P.cons_in_global;
 
+    timer.lap("global colours");
     // ---- published orders per parity --------------------------------------------------------------
     // parity p: S_p on the tiles of T_p, the global colours, S_(1-p) on the tiles of T_(1-p)
     for (int p = 0; p < 2; ++p) {
@@ -544,6 +568,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
             for (int p = 0; p < 2; ++p)
                 for (Phase &ph : P.phases[p]) if (ph.kind != 0 && ph.tiling == 1) ph.halo_slot = 1;
     }
+    timer.lap("published orders");
 }
 
 void extract_local(const Plan &P, const Input &in, int rank, LocalPlan &L) {
