@@ -66,7 +66,38 @@ void resolve_dims(int world, const float ext[3], const int want[3], int dims[3])
 }
 
 // Greedy colouring of `count` constraints over an index space. used[] must be zero for the touched
-// indices on entry and is zeroed again on exit. Returns the colour count, -1 if more than 128 are needed.
+// indices on entry and is zeroed again on exit. Returns the colour count. Up to 128 colours run on one
+// 128-bit mask per index; a graph that needs more (a hub particle with hundreds of springs) is recoloured by
+// the general routine below with masks as wide as it takes -- same rule (lowest colour free at every endpoint,
+// constraints in the given order), so the result for <= 128 colours is the same either way.
+template <class GetVerts>
+int greedy_colour_wide(int64_t count, int nverts, GetVerts get, size_t index_space, std::vector<int> &colour_out) {
+    colour_out.assign(count, 0);
+    std::vector<std::vector<uint64_t>> used(index_space);     // only touched indices ever grow
+    std::vector<uint64_t> m;
+    int ncol = 0;
+    for (int64_t k = 0; k < count; ++k) {
+        const int32_t *v = get(k);
+        m.clear();
+        for (int a = 0; a < nverts; ++a) {
+            const std::vector<uint64_t> &u = used[v[a]];
+            if (u.size() > m.size()) m.resize(u.size(), 0);
+            for (size_t w = 0; w < u.size(); ++w) m[w] |= u[w];
+        }
+        int c = -1;
+        for (size_t w = 0; w < m.size() && c < 0; ++w) if (~m[w]) c = (int)(64 * w) + __builtin_ctzll(~m[w]);
+        if (c < 0) c = (int)(64 * m.size());
+        for (int a = 0; a < nverts; ++a) {
+            std::vector<uint64_t> &u = used[v[a]];
+            if (u.size() <= (size_t)c / 64) u.resize((size_t)c / 64 + 1, 0);
+            u[(size_t)c / 64] |= 1ull << (c % 64);
+        }
+        colour_out[k] = c;
+        ncol = std::max(ncol, c + 1);
+    }
+    return ncol;
+}
+
 template <class GetVerts>
 int greedy_colour(int64_t count, int nverts, GetVerts get, std::vector<Mask128> &used, std::vector<int> &colour_out) {
     colour_out.resize(count);
@@ -85,6 +116,7 @@ int greedy_colour(int64_t count, int nverts, GetVerts get, std::vector<Mask128> 
         const int32_t *v = get(k);
         for (int a = 0; a < nverts; ++a) used[v[a]] = Mask128();
     }
+    if (ncol < 0) ncol = greedy_colour_wide(count, nverts, get, used.size(), colour_out);
     return ncol;
 }
 
@@ -460,7 +492,6 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
                     for (int a = 0; a < nv; ++a) lv[k * nv + a] = lidx[tl][P.new_of_old[v[a]]];
                 }
                 int ncol = greedy_colour(cnt, nv, [&](int64_t k) { return lv.data() + (size_t)k * nv; }, used, col_tmp);
-                if (ncol < 0) throw std::runtime_error("a tile needs more than 128 colours (particle valence too high)");
                 std::vector<std::vector<int32_t>> by(ncol);
                 for (int64_t k = 0; k < cnt; ++k) by[col_tmp[k]].push_back((int32_t)k);
                 for (auto &colv : by) {
@@ -505,7 +536,6 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
             if (gused.empty()) gused.assign(n, Mask128());
             const int nv = kVerts[t];
             int ncol = greedy_colour((int64_t)left.size(), nv, [&](int64_t k) { return C.idx(t, left[k]); }, gused, colr);
-            if (ncol < 0) throw std::runtime_error("constraint graph needs more than 128 colours");
             size_t base = P.gcolours.size();
             P.gcolours.resize(base + ncol);
             for (int c = 0; c < ncol; ++c) P.gcolours[base + c].type = t;

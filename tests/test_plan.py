@@ -172,3 +172,29 @@ def test_random_meshes_plan_invariants_and_partition_invariance(oracle_mod, seed
     ref.step(0.02, 3)
     x, v, _ = run_partitioned(oracle_mod, mesh, world, (0, 0, 0), ticks=1, substeps=3, tile=tile, compliance=(1e-6, 1e-6, 1e-4))
     assert np.array_equal(x.view(np.uint32), ref.x.view(np.uint32)) and np.array_equal(v.view(np.uint32), ref.v.view(np.uint32))
+
+
+def _hub_mesh(n_sat=300, seed=4):
+    """One hub particle joined to every satellite (valence n_sat) + a ring through the satellites."""
+    from softbodyunity_amd.mesh import SoftbodyMesh
+    rng = np.random.default_rng(seed)
+    d = rng.normal(size=(n_sat, 3)); d /= np.linalg.norm(d, axis=1)[:, None]
+    pos = np.concatenate([[[0.0, 0.0, 0.0]], d * rng.uniform(0.8, 1.2, (n_sat, 1))]).astype(np.float32)
+    ij = [(0, 1 + k) for k in range(n_sat)] + [(1 + k, 1 + (k + 1) % n_sat) for k in range(n_sat)]
+    ij = np.array(ij, np.int32)
+    rest = (np.linalg.norm(pos[ij[:, 0]] - pos[ij[:, 1]], axis=1) * 0.9).astype(np.float32)
+    return SoftbodyMesh(rest_pos=pos.copy(), pos=pos.copy(), vel=np.zeros_like(pos), inv_mass=np.ones(len(pos), np.float32),
+                        dist_ij=ij, dist_rest=rest)
+
+
+@pytest.mark.parametrize("tile", [512, -1])
+def test_hub_particle_needs_more_than_128_colours(oracle_mod, tile):
+    # a particle of valence 300 needs 300 colours: the planner falls back to wide colour masks (no limit)
+    mesh = _hub_mesh()
+    plan = build_plan(mesh, tile_particles=tile)
+    _check_plan(mesh, plan)
+    assert len(plan.groups(0)) - 1 >= 300
+    ref = make_oracle(oracle_mod, mesh, plan)
+    ref.step(0.02, 2)
+    x, v, _ = run_partitioned(oracle_mod, mesh, 2, (0, 0, 0), ticks=1, substeps=2, tile=tile)
+    assert np.array_equal(x.view(np.uint32), ref.x.view(np.uint32))
