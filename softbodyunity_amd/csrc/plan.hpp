@@ -28,6 +28,7 @@ struct Opts {
     int rank = 0, world = 1;
     int dims[3] = {0, 0, 0};
     int tile_particles = 512;  // -1: no tiling
+    bool bank_aware_lanes = true;   // order the constraints of a round for conflict-free LDS gathers (SB_NO_BANK_ORDER: A/B runs)
 };
 
 struct Run {            // a contiguous range of particles
@@ -38,6 +39,7 @@ struct Run {            // a contiguous range of particles
 constexpr int kRoundThreads = 256;          // constraints per round (one per lane of a 256-thread workgroup)
 constexpr int kMaxTileLocal = 1024;         // particles staged per tile (4 per lane)
 constexpr int kMaxTileRuns = 64;
+constexpr int kLdsGroup = 8;                // lanes whose 16-byte LDS accesses are served together (measured: 8 beats 16, 32, 64)
 
 struct Tile {
     int32_t owner;          // owning rank if all its particles have one owner, else -1

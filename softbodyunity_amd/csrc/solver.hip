@@ -873,6 +873,7 @@ int sb_finalize(sb_solver *s) {
         o.rank = s->desc.rank; o.world = s->desc.world;
         for (int a = 0; a < 3; ++a) o.dims[a] = s->desc.part_dims[a];
         o.tile_particles = s->desc.tile_particles;
+        o.bank_aware_lanes = !std::getenv("SB_NO_BANK_ORDER");
         s->plan = std::make_unique<sb_plan>();
         sbp::build_plan(in, o, s->plan->plan);
         sbp::extract_local(s->plan->plan, in, o.rank, s->plan->local);
@@ -1303,6 +1304,7 @@ int sb_plan_build(const float *rest, int32_t n, const int32_t *dist_ij, int32_t 
             for (int a = 0; a < 3; ++a) o.dims[a] = opts->part_dims[a];
             o.tile_particles = opts->tile_particles == 0 ? 512 : opts->tile_particles;
         }
+        o.bank_aware_lanes = !std::getenv("SB_NO_BANK_ORDER");
         sbp::Input in = make_input(rest, n, dist_ij, m_d, vol, m_v, bend, m_b);
         auto p = std::make_unique<sb_plan>();
         sbp::build_plan(in, o, p->plan);
