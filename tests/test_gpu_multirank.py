@@ -1,7 +1,8 @@
-"""Two ranks through the real RCCL halo path. The GPU box has ONE device, and RCCL refuses two ranks on one
-device unless told otherwise, so this test runs only when RCCL accepts the duplicate (it is skipped, not
-failed, when communicator creation is refused). The schedule itself is covered bit-exactly on CPU by
-tests/test_plan.py and tests/test_multirank_gloo.py."""
+"""Ranks through the real RCCL halo path. On a box with at least as many GPUs as ranks every rank takes its own
+device (real xGMI exchange, bit-exact against the oracle). The usual GPU box has ONE device, and RCCL refuses two
+ranks on one device, so there the test is skipped (not failed) when communicator creation is refused; the
+multi-rank device path is then covered by the hosted-halo and loopback tests below, and the schedule bit-exactly on
+CPU by tests/test_plan.py and tests/test_multirank_gloo.py."""
 import os
 import sys
 
@@ -13,13 +14,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
+def _device_count():
+    import ctypes as C
+    n = C.c_int(0)
+    try:
+        if C.CDLL("libamdhip64.so").hipGetDeviceCount(C.byref(n)) != 0:
+            return 0
+    except OSError:
+        return 0
+    return n.value
+
+
 def _worker(rank, world, uid, tile, out_dir):
     sys.path.insert(0, ROOT)
     from softbodyunity_amd import Softbody, native
     from softbodyunity_amd.mesh import jelly_cube
     mesh = jelly_cube(24, pin_top=True)
+    device = rank if _device_count() >= world else 0      # one GPU per rank when the box has them
     try:
-        sb = Softbody(mesh, substeps=6, device=0, rank=rank, world=world, tile_particles=tile, unique_id=uid).Start()
+        sb = Softbody(mesh, substeps=6, device=device, rank=rank, world=world, tile_particles=tile, unique_id=uid).Start()
     except native.SoftbodyError as e:
         open(os.path.join(out_dir, f"err{rank}.txt"), "w").write(str(e))
         return
@@ -30,23 +43,27 @@ def _worker(rank, world, uid, tile, out_dir):
     sb.OnDestroy()
 
 
-@pytest.mark.parametrize("tile", [64, -1])
-def test_two_ranks_one_device_rccl(tmp_path, oracle_mod, tile):
+@pytest.mark.parametrize("world,tile", [(2, 64), (2, -1), (4, 64)])
+def test_ranks_through_real_rccl(tmp_path, oracle_mod, world, tile):
     from softbodyunity_amd import comm_unique_id
     from softbodyunity_amd.mesh import jelly_cube
     from helpers import build_plan, make_oracle
+    if world > 2 and _device_count() < world:
+        pytest.skip(f"needs {world} GPUs")
     os.environ.setdefault("NCCL_DEBUG", "WARN")
     uid = comm_unique_id()
-    mp.spawn(_worker, args=(2, uid, tile, str(tmp_path)), nprocs=2, join=True)
+    mp.spawn(_worker, args=(world, uid, tile, str(tmp_path)), nprocs=world, join=True)
     errs = [f for f in os.listdir(tmp_path) if f.startswith("err")]
     if errs:
+        if _device_count() >= world:
+            pytest.fail("RCCL communicator failed with one GPU per rank: " + open(tmp_path / errs[0]).read()[:300])
         pytest.skip("RCCL refused two ranks on one device: " + open(tmp_path / errs[0]).read()[:200])
     mesh = jelly_cube(24, pin_top=True)
     ref = make_oracle(oracle_mod, mesh, build_plan(mesh, tile_particles=tile))
     for _ in range(3):
         ref.step(0.02, 6)
     x = np.zeros_like(ref.x); v = np.zeros_like(ref.v)
-    for r in range(2):
+    for r in range(world):
         d = np.load(tmp_path / f"rank{r}.npz")
         x[d["owned"]] = d["x"][d["owned"]]; v[d["owned"]] = d["v"][d["owned"]]
         if tile > 0:
