@@ -141,7 +141,8 @@ def main():
         names = ["tile_kernel<1> on T0 (rounds + collide/velocity/integrate + rounds)",
                  "tile_kernel<1> on T1 (rounds + collide/velocity/integrate + rounds)"]
         names += [f"global colour {c}" for c in range(G)]
-        names += ["tile_kernel<0> (first kernel of a tick)", "tile_kernel<2> (last kernel of a tick)"]
+        names += ["tile_kernel<0> (first kernel of a tick)", "tile_kernel<2> (last kernel of a tick)",
+                  "tile_kernel<3> on the T2 layers (constraints inside neither T0 nor T1)"]
         # ALGORITHMIC bytes per launch: a mid-tick tile kernel does one velocity update (36 B)
         # + one integrate (52 B) per particle and projects every constraint it stores TWICE (before and after
         # the MARK step: the tail of one substep and the head of the next), 68 B each time
@@ -153,6 +154,7 @@ def main():
             alg_bytes.append(68.0 * int(mask0[ph0[c]["order_begin"]:ph0[c]["order_end"]].sum()))
         last = (args.substeps & 1) if stats["n_tilings"] == 2 else 0
         alg_bytes += [52.0 * owned + 68.0 * stats["tile_constraints"][0], 36.0 * owned + 68.0 * stats["tile_constraints"][last]]
+        alg_bytes.append(68.0 * stats["t2_constraints"])
         k_dom = int(np.argmax(slot_ms))
         launches = max(int(slot_cnt[k_dom]), 1)
         dom_ms = float(slot_ms[k_dom]) / launches

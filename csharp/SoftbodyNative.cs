@@ -34,6 +34,7 @@ namespace SoftbodyMI355X
         public long nTilesT0, nTilesT1, tileConstraintsT0, tileConstraintsT1;
         public long constraintsInTiles, constraintsInGlobal;
         public long haloParticlesT1, haloParticlesGlobal, deviceBytes;
+        public long nT2Layers, nT2Tiles, t2Constraints;
     }
 
     [StructLayout(LayoutKind.Sequential)]

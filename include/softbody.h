@@ -131,13 +131,13 @@ int sb_profile_end(sb_solver *s, float *elapsed_ms_out);
 int sb_synchronize(sb_solver *s);
 /* One tick launched eagerly with a HIP-event pair around every kernel launch on the solver's stream.
  * Slots: 0 / 1 = mid-tick tile kernels on tiling T0 / T1 (rounds + velocity/integrate + rounds),
- * 2+c = global colour c, 2+G = the first kernel of the tick, 3+G = the last (G = n_global_colours).
- * n_slots must be 4 + n_global_colours (sb_get_stats). Same results as sb_step. */
+ * 2+c = global colour c, 2+G = the first kernel of the tick, 3+G = the last, 4+G = the kernels of the T2 layers
+ * (G = n_global_colours). n_slots must be 5 + n_global_colours (sb_get_stats). Same results as sb_step. */
 int sb_step_profiled(sb_solver *s, float dt, int32_t substeps, float *slot_ms_out, int32_t *slot_launches_out,
                      int32_t n_slots);
 /* Test hooks (used by tests/test_gpu_multirank.py to check the multi-rank device path on a box with one
- * GPU, where RCCL cannot form a communicator): run ONE launch of a tick — tile kernel K_it (gcolour = -1)
- * or global colour `gcolour` of the substep that K_it started — without any ghost exchange, and move one
+ * GPU, where RCCL cannot form a communicator): run ONE launch of a tick — tile kernel K_it (gcolour = -1),
+ * global colour `gcolour` of the substep that K_it started, or T2 layer l of that substep (gcolour = -2 - l) — without any ghost exchange, and move one
  * halo slot's send / receive buffer through host memory. Buffer layout = what goes over the wire: peers in
  * increasing rank order, each peer's particles back to back, 3 floats (position) per particle, slot 1: 6 floats
  * (position, previous position). */
@@ -155,6 +155,8 @@ typedef struct {
     int64_t halo_particles_t1;                      /* ghosts sent before every T1 kernel */
     int64_t halo_particles_global;                  /* ghosts sent per substep for the global colours */
     int64_t device_bytes;                           /* device memory held by the solver */
+    int64_t n_t2_layers;                            /* third-tiling layers (constraints inside neither T0 nor T1 that got LDS tiles) */
+    int64_t n_t2_tiles, t2_constraints;             /* workgroups per substep / constraints of all T2 layers, this rank */
 } sb_stats;
 int sb_get_stats(sb_solver *s, sb_stats *out);
 

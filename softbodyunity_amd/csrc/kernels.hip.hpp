@@ -26,7 +26,8 @@ struct TickParams {           // SPEC.md §2 host-side scalars, uploaded once pe
 // count x {i | j<<12 | palette index<<24} (one dword each) with the values in the tile's palette;
 // a 4-vertex round stores count x {i0|i1<<16, i2|i3<<16, rest.x, rest.y}.
 struct TileDesc {
-    int32_t n_local, run_count, n_rounds, pad0;
+    int32_t n_local, run_count, n_rounds;
+    int32_t gather_begin;      // KIND 3 (T2 tiles): the tile's particles are gather[gather_begin .. +n_local) instead of runs
     uint32_t s_begin;          // dword offset of the tile's stream
     uint32_t s_hdr;            // dwords of round words + palette (each padded to 4): round data starts at s_begin + s_hdr
     uint32_t s_len;            // total dwords (multiple of 4)
@@ -66,6 +67,7 @@ struct TileArgs {
     const int2 *runs_overflow;
     const uint32_t *stream;
     const TickParams *tp;
+    const int32_t *gather;    // KIND 3: particle lists of the sparse T2 tiles (device numbering)
     int32_t max_local;        // LDS carve: [max_local float4][rounds_dwords][pal_dwords][win_dwords][16 spare bytes]
     int32_t rounds_dwords;    // round words cached in LDS (multiple of 4, <= kMaxRoundsLds); longer programs read memory
     int32_t pal_dwords;       // largest rest-length dictionary of the tiling, padded to 4 (0 = none)
@@ -221,6 +223,7 @@ __device__ __forceinline__ bool project_bending(float4 &pa, float4 &pb, float4 &
 //   KIND 1 (every other substep)     : the tile's rounds (finish substep s-1), MARK: v = (x-xprev)/h, integrate
 //                                      (start substep s), the same rounds again
 //   KIND 2 (after the last substep)  : the tile's rounds, MARK: write v, stop
+//   KIND 3 (T2 layer, every substep)  : the tile's rounds once, no MARK; the particles come from an explicit list
 // Particles AND the tile's constraint stream are staged in LDS with wide coalesced loads issued together,
 // so a tile pays the HBM latency once; rounds then run LDS-to-LDS with one barrier each. Each lane keeps
 // ownership of up to PPT particles for the MARK step and projects kRoundSlots / THREADS constraints per round.
@@ -268,7 +271,13 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
     // INT_MAX there, so the last run that starts at or before l is found by a compare/select chain on scalars
     // (a loop with a scalar branch per run and slot cost ~400 SALU instructions per wave BEFORE the first load).
     int g[PPT];
-    {
+    if (KIND == 3) {
+#pragma unroll
+        for (int m = 0; m < PPT; ++m) {
+            const int l = tid + m * kTileThreads;
+            g[m] = l < n_local ? A.gather[td.gather_begin + l] : -1;
+        }
+    } else {
         int run_d[kInlineRuns], run_y[kInlineRuns];
 #pragma unroll
         for (int r = 0; r < kInlineRuns; ++r) { run_y[r] = td.runs[r].y; run_d[r] = td.runs[r].x - td.runs[r].y; }
@@ -291,7 +300,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
     // virtual program: rounds 0..R-1 (finish the previous substep), MARK, rounds 0..R-1 again (start the next)
     const int R = n_rounds_all;
     const int v_begin = KIND == 0 ? R : 0;
-    const int v_end = KIND == 2 ? R + 1 : 2 * R + 1;
+    const int v_end = KIND == 3 ? R : (KIND == 2 ? R + 1 : 2 * R + 1);
     const uint32_t d_lo = td.s_hdr;
     const uint32_t d_hi = td.s_len;
     const uint32_t win = (uint32_t)A.win_dwords;
@@ -325,7 +334,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
         X[m].x = A.pos.xyz[3 * (size_t)gc + 0]; X[m].y = A.pos.xyz[3 * (size_t)gc + 1]; X[m].z = A.pos.xyz[3 * (size_t)gc + 2];
         if (WPAL) { wi[m] = A.w8[gc]; X[m].w = 0.0f; } else { wi[m] = 0; X[m].w = A.pos.w[gc]; }
         pvx[m] = pvy[m] = pvz[m] = 0.0f;
-        if (KIND != 0) { pvx[m] = A.prev[3 * (size_t)gc + 0]; pvy[m] = A.prev[3 * (size_t)gc + 1]; pvz[m] = A.prev[3 * (size_t)gc + 2]; }
+        if (KIND != 0 && KIND != 3) { pvx[m] = A.prev[3 * (size_t)gc + 0]; pvy[m] = A.prev[3 * (size_t)gc + 1]; pvz[m] = A.prev[3 * (size_t)gc + 2]; }
     }
     const bool rounds_in_lds = n_rounds_all <= A.rounds_dwords;
     const uint32_t rw = tstream[max(min(tid, n_rounds_all - 1), 0)];        // (an empty program still has a 16-byte header)

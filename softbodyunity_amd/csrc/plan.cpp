@@ -316,7 +316,6 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
     timer.lap("tiling T0");
     // ---- tiles: runs and tile-local indices ------------------------------------------------------
     std::vector<int32_t> lidx[2];           // tile-local index of every particle (new numbering)
-    const std::vector<int32_t> *tile_of[2] = {&t0_of_old, &t1_of_old};
     const int32_t n_tiles[2] = {n_t0, tiling ? n_t1 : 0};
     {
         Tiling &A = P.T[0];
@@ -458,39 +457,42 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
 
     timer.lap("static split");
     // ---- tile programs ---------------------------------------------------------------------------
-    // seq[tl] = (type,id) of S_tl in execution order; tile slices recorded in the tiles
-    std::vector<uint8_t> seq_type[2];
-    std::vector<int32_t> seq_id[2];
-    std::vector<int64_t> seq_groups[2];   // group boundaries (end offsets) inside seq
-    for (int tl = 0; tl < 2; ++tl) {
-        if (n_tiles[tl] == 0) continue;
+    // seq[tl] = (type,id) of the tiling's constraints in execution order; tile slices recorded in the tiles
+    std::vector<uint8_t> seq_type[3];
+    std::vector<int32_t> seq_id[3];
+    std::vector<int64_t> seq_groups[3];   // group boundaries (end offsets) inside seq
+    // programs of the tiles [tile_begin, tile_end) of tiling tl: the constraints with own code `code`, bucketed by tof
+    // (tile of a particle, caller numbering), tile-local indices from lmap (new numbering)
+    auto build_programs = [&](int tl, int32_t tile_begin, int32_t tile_end, const std::vector<int32_t> &tof,
+                              const std::vector<int32_t> &lmap, uint8_t code) {
+        if (tile_end <= tile_begin) return;
         Tiling &TT = P.T[tl];
-        const std::vector<int32_t> &tof = *tile_of[tl];
         std::vector<int64_t> off[3];
         std::vector<int32_t> lst[3];
+        const int32_t nt = tile_end - tile_begin;
         for (int t = 0; t < 3; ++t) {
             auto &o = off[t];
-            o.assign((size_t)n_tiles[tl] + 1, 0);
-            for (int64_t k = 0; k < C.count(t); ++k) if (own[t][k] == tl) ++o[tof[C.idx(t, k)[0]] + 1];
-            for (int32_t c = 0; c < n_tiles[tl]; ++c) o[c + 1] += o[c];
-            lst[t].resize(o[n_tiles[tl]]);
+            o.assign((size_t)nt + 1, 0);
+            for (int64_t k = 0; k < C.count(t); ++k) if (own[t][k] == code) ++o[tof[C.idx(t, k)[0]] - tile_begin + 1];
+            for (int32_t c = 0; c < nt; ++c) o[c + 1] += o[c];
+            lst[t].resize(o[nt]);
             std::vector<int64_t> cur(o.begin(), o.end() - 1);
-            for (int64_t k = 0; k < C.count(t); ++k) if (own[t][k] == tl) lst[t][cur[tof[C.idx(t, k)[0]]]++] = (int32_t)k;
+            for (int64_t k = 0; k < C.count(t); ++k) if (own[t][k] == code) lst[t][cur[tof[C.idx(t, k)[0]] - tile_begin]++] = (int32_t)k;
         }
-        for (int32_t c = 0; c < n_tiles[tl]; ++c) {
+        for (int32_t c = tile_begin; c < tile_end; ++c) {
             Tile &tile = TT.tiles[c];
             tile.round_begin = (int32_t)TT.rounds.size();
             tile.d_begin = (int64_t)TT.t_dist.size(); tile.q_begin = (int64_t)TT.t_quad_id.size();
             tile.seq_begin = (int64_t)seq_id[tl].size();
             for (int t = 0; t < 3; ++t) {
-                const int32_t *it = lst[t].data() + off[t][c];
-                const int64_t cnt = off[t][c + 1] - off[t][c];
+                const int32_t *it = lst[t].data() + off[t][c - tile_begin];
+                const int64_t cnt = off[t][c - tile_begin + 1] - off[t][c - tile_begin];
                 if (cnt == 0) continue;
                 const int nv = kVerts[t];
                 lv.resize((size_t)cnt * nv);
                 for (int64_t k = 0; k < cnt; ++k) {
                     const int32_t *v = C.idx(t, it[k]);
-                    for (int a = 0; a < nv; ++a) lv[k * nv + a] = lidx[tl][P.new_of_old[v[a]]];
+                    for (int a = 0; a < nv; ++a) lv[k * nv + a] = lmap[P.new_of_old[v[a]]];
                 }
                 int ncol = greedy_colour(cnt, nv, [&](int64_t k) { return lv.data() + (size_t)k * nv; }, used, col_tmp);
                 std::vector<std::vector<int32_t>> by(ncol);
@@ -548,6 +550,100 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
             tile.n_rounds = (int32_t)TT.rounds.size() - tile.round_begin;
             tile.d_end = (int64_t)TT.t_dist.size(); tile.q_end = (int64_t)TT.t_quad_id.size();
         }
+    };
+    if (n_tiles[0]) build_programs(0, 0, n_tiles[0], t0_of_old, lidx[0], 0);
+    if (n_tiles[1]) build_programs(1, 0, n_tiles[1], t1_of_old, lidx[1], 1);
+
+    // ---- third tiling T2, in layers ----------------------------------------------------------------
+    // A constraint inside neither T0 nor T1 (it crosses a T0 plane on one axis and a T1 plane on another: about one in
+    // ten on a tet mesh) would need a global colour, i.e. one tiny launch per colour and substep. Most of them fit a
+    // cell of another shifted grid: such constraints are projected in LDS by one extra tile kernel per substep and
+    // layer, on sparse tiles that hold just the particles they touch (explicit particle lists instead of runs). Up to
+    // kMaxT2Layers grids with different shifts are tried in turn on what is still left. Like a T1 tile, a T2 tile that
+    // spans ranks is projected redundantly by every rank that owns one of its particles, on ghosts refreshed just
+    // before (one halo slot per layer, positions only): the plan does not depend on the partition.
+    if (tiling && opts.third_tiling) {
+        struct Cand { int64_t key; uint8_t type; int32_t id; };
+        std::vector<Cand> cand;
+        std::vector<int32_t> t2_of_old, lidx2, members;
+        // layer shifts (fractions of a cell): first the middle of the widest gap between the T0 and T1 planes, then a
+        // golden-ratio walk, skipping positions within 6 % of a cell of any plane already in use
+        std::vector<double> planes = {0.0, shift_frac, 1.0};
+        double next_frac = shift_frac + 0.5 * (1.0 - shift_frac);
+        for (int layer = 0; layer < kMaxT2Layers; ++layer) {
+            double frac = next_frac;
+            for (int tries = 0; tries < 32; ++tries) {
+                bool close = false;
+                for (double pl : planes) close |= std::fabs(frac - pl) < 0.06;
+                if (!close) break;
+                frac += 0.381966011250105; frac -= std::floor(frac);
+            }
+            planes.push_back(frac);
+            next_frac = frac + 0.381966011250105; next_frac -= std::floor(next_frac);
+            auto cell2 = [&](int32_t q) {
+                int64_t s3[3];
+                for (int a = 0; a < 3; ++a) {
+                    double r = (in.rest[3 * (int64_t)q + a] - org[a]) / cs;
+                    s3[a] = std::min(std::max((int)std::floor(r - frac) + 1, 0), nc[a]);
+                }
+                return (s3[2] * (nc[1] + 1) + s3[1]) * (nc[0] + 1) + s3[0];
+            };
+            cand.clear();
+            int64_t left = 0;
+            for (int t = 0; t < 3; ++t)
+                for (int64_t k = 0; k < C.count(t); ++k) {
+                    if (own[t][k] != 2) continue;
+                    ++left;
+                    const int32_t *v = C.idx(t, k);
+                    const int64_t c0 = cell2(v[0]);
+                    bool same = true;
+                    for (int a = 1; a < kVerts[t]; ++a) same &= cell2(v[a]) == c0;
+                    if (same) cand.push_back({c0, (uint8_t)t, (int32_t)k});
+                }
+            if (left == 0) break;
+            if (cand.empty()) continue;
+            std::stable_sort(cand.begin(), cand.end(), [](const Cand &x, const Cand &y) { return x.key < y.key; });
+            t2_of_old.assign(n, -1);
+            lidx2.assign(n, -1);
+            Tiling &T2 = P.T[2];
+            const int32_t tile_begin = (int32_t)T2.tiles.size();
+            const uint8_t code = (uint8_t)(3 + layer);
+            for (size_t b = 0; b < cand.size();) {
+                size_t e = b + 1;
+                while (e < cand.size() && cand[e].key == cand[b].key) ++e;
+                members.clear();
+                for (size_t q = b; q < e; ++q) {
+                    const int32_t *v = C.idx(cand[q].type, cand[q].id);
+                    for (int a = 0; a < kVerts[cand[q].type]; ++a) members.push_back(P.new_of_old[v[a]]);
+                }
+                std::sort(members.begin(), members.end());
+                members.erase(std::unique(members.begin(), members.end()), members.end());
+                if ((int)members.size() <= kMaxTileLocal) {      // an over-full cell keeps its constraints for the next layer / the global colours
+                    Tile t = Tile();
+                    t.owner = P.owner_of_old[P.old_of_new[members[0]]];
+                    for (int32_t mq : members) if (P.owner_of_old[P.old_of_new[mq]] != t.owner) t.owner = -1;
+                    t.run_begin = 0; t.run_count = 0;
+                    t.n_local = (int32_t)members.size();
+                    t.gather_begin = (int64_t)T2.gather.size();
+                    const int32_t id = (int32_t)T2.tiles.size();
+                    for (size_t q = 0; q < members.size(); ++q) {
+                        T2.gather.push_back(members[q]);
+                        lidx2[members[q]] = (int32_t)q;
+                        t2_of_old[P.old_of_new[members[q]]] = id;
+                    }
+                    T2.max_local = std::max(T2.max_local, t.n_local);
+                    T2.tiles.push_back(t);
+                    for (size_t q = b; q < e; ++q) own[cand[q].type][cand[q].id] = code;
+                }
+                b = e;
+            }
+            const int32_t tile_end = (int32_t)T2.tiles.size();
+            if (tile_end > tile_begin) {
+                build_programs(2, tile_begin, tile_end, t2_of_old, lidx2, code);
+                P.t2_layers.push_back({tile_begin, tile_end});
+            }
+        }
+        for (int t = 0; t < 3; ++t) for (auto &o : own[t]) if (o > 3) o = 3;       // 3 = some T2 layer
     }
 
     timer.lap("tile programs");
@@ -579,19 +675,24 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
 
     timer.lap("global colours");
     // ---- published orders per parity --------------------------------------------------------------
-    // parity p: S_p on the tiles of T_p, the global colours, S_(1-p) on the tiles of T_(1-p)
+    // parity p: S_p on the tiles of T_p, S2 on the tiles of T2, the global colours, S_(1-p) on the tiles of T_(1-p)
     for (int p = 0; p < 2; ++p) {
         auto &ot = P.order_type[p]; auto &oi = P.order_id[p];
         auto &tasks = P.task_off[p]; auto &groups = P.group_off[p];
         tasks.push_back(0); groups.push_back(0);
-        auto append_tiles = [&](int tl, int kind) {
-            Phase ph; ph.kind = kind; ph.type = -1; ph.tiling = tl; ph.gcolour = -1; ph.halo_slot = -1;
+        auto append_tiles = [&](int tl, int kind, int32_t tile_begin = 0, int32_t tile_end = -1, int layer = -1) {
+            if (tile_end < 0) tile_end = (int32_t)P.T[tl].tiles.size();
+            if (tile_end <= tile_begin) return;
+            Phase ph; ph.kind = kind; ph.type = -1; ph.tiling = tl; ph.gcolour = -1; ph.halo_slot = -1; ph.layer = layer;
             ph.order_begin = (int64_t)oi.size(); ph.task_begin = (int64_t)tasks.size() - 1;
-            const int64_t base = (int64_t)oi.size();
-            ot.insert(ot.end(), seq_type[tl].begin(), seq_type[tl].end());
-            oi.insert(oi.end(), seq_id[tl].begin(), seq_id[tl].end());
-            for (int64_t g : seq_groups[tl]) groups.push_back(base + g);
-            for (Tile &tile : P.T[tl].tiles) {
+            // the tiles' constraints are one contiguous slice of the tiling's sequence
+            const int64_t sb = P.T[tl].tiles[tile_begin].seq_begin, se = P.T[tl].tiles[tile_end - 1].seq_end;
+            const int64_t base = (int64_t)oi.size() - sb;
+            ot.insert(ot.end(), seq_type[tl].begin() + sb, seq_type[tl].begin() + se);
+            oi.insert(oi.end(), seq_id[tl].begin() + sb, seq_id[tl].begin() + se);
+            for (int64_t g : seq_groups[tl]) if (g > sb && g <= se) groups.push_back(base + g);
+            for (int32_t c = tile_begin; c < tile_end; ++c) {
+                Tile &tile = P.T[tl].tiles[c];
                 tile.order_begin[p] = base + tile.seq_begin; tile.order_end[p] = base + tile.seq_end;
                 if (tile.seq_end > tile.seq_begin) tasks.push_back(base + tile.seq_end);
             }
@@ -600,6 +701,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         };
         const int first = tiling ? p : 0;
         if (!P.T[first].tiles.empty()) append_tiles(first, 1);
+        for (size_t ly = 0; ly < P.t2_layers.size(); ++ly) append_tiles(2, 3, P.t2_layers[ly].first, P.t2_layers[ly].second, (int)ly);
         for (size_t gc = 0; gc < P.gcolours.size(); ++gc) {
             const GColour &g = P.gcolours[gc];
             Phase ph; ph.kind = 0; ph.type = g.type; ph.tiling = -1; ph.gcolour = (int)gc;
@@ -617,6 +719,15 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         if (tiling && !P.T[1 - p].tiles.empty()) append_tiles(1 - p, 2);
         if ((int64_t)oi.size() != P.m[0] + P.m[1] + P.m[2]) throw std::runtime_error("planner lost constraints");
     }
+    // T2 layers whose tiles span ranks need ghost positions: one halo slot per layer, after the global colours' slots
+    if (opts.world > 1)
+        for (size_t ly = 0; ly < P.t2_layers.size(); ++ly) {
+            bool multi2 = false;
+            for (int32_t c = P.t2_layers[ly].first; c < P.t2_layers[ly].second; ++c) multi2 |= P.T[2].tiles[c].owner < 0;
+            if (multi2)
+                for (int p = 0; p < 2; ++p)
+                    for (Phase &ph : P.phases[p]) if (ph.kind == 3 && ph.layer == (int)ly) ph.halo_slot = 2 + (int)P.gcolours.size() + (int)ly;
+        }
     // halo slot 1: T1 tiles with more than one owner need ghosts (positions and previous positions)
     if (tiling && opts.world > 1) {
         bool multi = false;
@@ -644,18 +755,34 @@ void extract_local(const Plan &P, const Input &in, int rank, LocalPlan &L) {
     // either side is this rank
     struct Need { int32_t slot, consumer, nw; };
     std::vector<Need> needs;
-    L.halo.resize(2 + P.gcolours.size());
+    L.halo.resize(2 + P.gcolours.size() + P.t2_layers.size());
     for (auto &h : L.halo) { h.send_idx.assign(world, {}); h.recv_idx.assign(world, {}); }
     for (int p = 0; p < 2; ++p) L.order_mask[p].assign(P.order_id[p].size(), 0);
     std::vector<int> owners;
     // tiles
-    for (int tl = 0; tl < 2; ++tl) {
+    for (int tl = 0; tl < 3; ++tl) {
         const Tiling &TT = P.T[tl];
         for (int32_t c = 0; c < (int32_t)TT.tiles.size(); ++c) {
             const Tile &tile = TT.tiles[c];
             bool mine;
             if (tile.owner >= 0) {
                 mine = tile.owner == rank;
+            } else if (tl == 2) {
+                int32_t layer_of_t2 = 0;
+                while (layer_of_t2 + 1 < (int32_t)P.t2_layers.size() && c >= P.t2_layers[layer_of_t2].second) ++layer_of_t2;
+                owners.clear();
+                for (int32_t q = 0; q < tile.n_local; ++q) owners.push_back(owner_new(TT.gather[tile.gather_begin + q]));
+                std::sort(owners.begin(), owners.end());
+                owners.erase(std::unique(owners.begin(), owners.end()), owners.end());
+                mine = std::binary_search(owners.begin(), owners.end(), rank);
+                for (int32_t q = 0; q < tile.n_local; ++q) {
+                    const int32_t nw = TT.gather[tile.gather_begin + q];
+                    const int ow = owner_new(nw);
+                    for (int cons : owners) {
+                        if (cons == ow || (cons != rank && ow != rank)) continue;
+                        needs.push_back({2 + (int32_t)P.gcolours.size() + layer_of_t2, cons, nw});
+                    }
+                }
             } else {
                 owners.clear();
                 for (int r = 0; r < tile.run_count; ++r) owners.push_back(owner_new(TT.runs[tile.run_begin + r].start));
@@ -729,11 +856,22 @@ void extract_local(const Plan &P, const Input &in, int rank, LocalPlan &L) {
         if (nd.consumer == rank) H.recv_idx[ow].push_back(local_of_new[nd.nw]);
         else if (ow == rank) H.send_idx[nd.consumer].push_back(local_of_new[nd.nw]);
     }
-    for (int tl = 0; tl < 2; ++tl) {
+    for (int tl = 0; tl < 3; ++tl) {
         LocalTiling &LT = L.T[tl];
         LT.run_begin.push_back(0);
+        LT.gather_begin.push_back(0);
         for (int32_t c : LT.tile_ids) {
             const Tile &tile = P.T[tl].tiles[c];
+            if (tl == 2) {      // sparse tile: explicit particle list instead of runs
+                for (int32_t q = 0; q < tile.n_local; ++q) {
+                    const int32_t li = local_of_new[P.T[2].gather[tile.gather_begin + q]];
+                    if (li < 0) throw std::runtime_error("internal: T2 tile particle not resident");
+                    LT.gather.push_back(li);
+                }
+                LT.gather_begin.push_back((int32_t)LT.gather.size());
+                LT.run_begin.push_back((int32_t)LT.runs.size());
+                continue;
+            }
             for (int r = 0; r < tile.run_count; ++r) {
                 const Run &rn = P.T[tl].runs[tile.run_begin + r];
                 int32_t ls = local_of_new[rn.start];

@@ -8,10 +8,12 @@
 //   S0 / S1   : a static split of the constraints: S0 is projected on the tiles of T0, S1 on the tiles of T1
 //               (a constraint can only go where all its particles share a tile; constraints inside both
 //               tilings are assigned so that colour classes stay whole and the two sides balance)
-//   G         : constraints inside neither tiling, greedy edge-coloured, one global kernel per colour
+//   T2 layers : constraints inside neither tiling that share a cell of one of up to six further shifted grids: sparse
+//               LDS tiles (explicit particle lists), one extra tile kernel per layer and substep
+//   G         : what is left, greedy edge-coloured, one global kernel per colour
 //
 //   substep of parity p (0,1,0,1,... restarting at 0 every tick) projects, in this order,
-//     S_p on T_p's tiles, then G, then S_(1-p) on T_(1-p)'s tiles       (tile by tile, round by round)
+//     S_p on T_p's tiles, then the T2 layers, then G, then S_(1-p) on T_(1-p)'s tiles   (tile by tile, round by round)
 //
 // S_q of one substep and S_q of the next are the same constraint list on the same tiles, so the GPU runs
 // them in ONE kernel with the per-particle velocity update + integrate between them: every particle and
@@ -20,6 +22,7 @@
 #pragma once
 #include <cstdint>
 #include <string>
+#include <utility>
 #include <vector>
 
 namespace sbp {
@@ -28,6 +31,7 @@ struct Opts {
     int rank = 0, world = 1;
     int dims[3] = {0, 0, 0};
     int tile_particles = 512;  // -1: no tiling
+    bool third_tiling = true;       // constraints inside neither T0 nor T1 get LDS tiles of their own (T2) where they can (SB_NO_T2: A/B runs)
     bool bank_aware_lanes = true;   // order the constraints of a round for conflict-free LDS gathers (SB_NO_BANK_ORDER: A/B runs)
 };
 
@@ -39,6 +43,7 @@ struct Run {            // a contiguous range of particles
 constexpr int kRoundThreads = 256;          // constraints per round (one per lane of a 256-thread workgroup)
 constexpr int kMaxTileLocal = 1024;         // particles staged per tile (4 per lane)
 constexpr int kMaxTileRuns = 64;
+constexpr int kMaxT2Layers = 6;             // shifted grids tried in turn for the constraints inside neither T0 nor T1
 constexpr int kLdsGroup = 8;                // lanes whose 16-byte LDS accesses are served together (measured: 8 beats 16, 32, 64)
 
 struct Tile {
@@ -51,6 +56,7 @@ struct Tile {
     int64_t d_end, q_end;
     int64_t seq_begin, seq_end; // slice of the tiling's sequence
     int64_t order_begin[2], order_end[2];   // slices of the two published orders
+    int64_t gather_begin = 0;               // T2 only: the tile's particles are Tiling::gather[gather_begin .. +n_local) (run_count == 0)
 };
 
 struct Tiling {
@@ -63,6 +69,7 @@ struct Tiling {
     std::vector<uint32_t> t_quad;       // 2 words per 4-vertex constraint
     std::vector<int32_t> t_quad_id;     // original id within its type
     std::vector<uint8_t> t_quad_type;   // 1 volume, 2 bending
+    std::vector<int32_t> gather;        // T2 only: particle lists (global-new numbering), ascending inside a tile
     int32_t max_local = 0, max_runs = 0;
 };
 
@@ -73,13 +80,16 @@ struct GColour {            // one global colour: constraints of one type that s
 };
 
 struct Phase {              // one entry of a parity's phase list (inspection / oracle task parallelism)
-    int kind;               // 0 global colour, 1 = S_p on T_p's tiles (first in the substep), 2 = S_(1-p) on T_(1-p)'s tiles (last)
+    int kind;               // 0 global colour, 1 = S_p on T_p's tiles (first in the substep), 2 = S_(1-p) on T_(1-p)'s tiles (last),
+                            // 3 = S2 on T2's tiles (after kind 1, before the global colours)
     int type;               // kind 0: constraint type, else -1
     int tiling;             // kind 1/2: which tiling's tiles; kind 0: -1
     int gcolour;            // kind 0: index into Plan::gcolours
     int64_t order_begin, order_end;
     int64_t task_begin, task_end;
-    int halo_slot;          // -1 none; 1 = before the T1 kernel (x and xprev); 2+c = before global colour c (x)
+    int halo_slot;          // -1 none; 1 = before the T1 kernel (x and xprev); 2+c = before global colour c (x);
+                            // 2+|gcolours|+l = before the kernel of T2 layer l (x)
+    int layer = -1;         // kind 3: which T2 layer
 };
 
 struct Plan {
@@ -90,7 +100,8 @@ struct Plan {
     bool tiling = true;
     // particle numbering
     std::vector<int32_t> new_of_old, old_of_new, owner_of_old;
-    Tiling T[2];            // T[1] is empty when tiling is off
+    Tiling T[3];            // T[1] is empty when tiling is off; T[2] (sparse, single-owner tiles) only when constraints lie inside neither
+    std::vector<std::pair<int32_t, int32_t>> t2_layers;     // tile ranges [begin, end) of T[2], one per layer, in execution order
     std::vector<GColour> gcolours;
     // published orders per substep parity (original constraint ids)
     std::vector<uint8_t> order_type[2];
@@ -107,6 +118,8 @@ struct LocalTiling {
     std::vector<int32_t> tile_ids;          // global tile ids, execution order
     std::vector<Run> runs;                  // local numbering, concatenated per tile
     std::vector<int32_t> run_begin;         // per local tile (+1)
+    std::vector<int32_t> gather;            // T2: local particle indices, concatenated per tile
+    std::vector<int32_t> gather_begin;      // T2: per local tile (+1)
 };
 struct LocalGColour {
     int type;
@@ -121,7 +134,7 @@ struct LocalPlan {
     int rank = 0, world = 1;
     int64_t n_owned = 0;
     std::vector<int32_t> local_to_old;      // owned first (global-new order), then ghosts
-    LocalTiling T[2];
+    LocalTiling T[3];
     std::vector<LocalGColour> gcolours;
     std::vector<HaloSlot> halo;             // slot 0 unused, 1 = before T1 kernels, 2+c = before global colour c
     std::vector<uint8_t> order_mask[2];     // which order entries this rank executes

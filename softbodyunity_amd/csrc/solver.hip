@@ -17,6 +17,7 @@
 #include <memory>
 #include <stdexcept>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "../../include/softbody.h"
@@ -79,6 +80,7 @@ struct DevTiling {
     DevBuf<sbk::TileDesc> tiles;
     DevBuf<int2> runs_overflow;
     DevBuf<uint32_t> stream;     // per tile: [round words][rest-length dictionary][round data], see kernels.hip.hpp
+    DevBuf<int32_t> gather;      // T2: particle lists of the tiles (local numbering)
 };
 
 struct DevGColour {
@@ -131,7 +133,8 @@ struct sb_solver {
     DevBuf<float> d_prev, d_vel;
     DevBuf<sbk::TickParams> d_tp;
     DevBuf<float> d_sendbuf, d_recvbuf;   // 3 (slot 1: 6) floats per ghost, peers back to back
-    DevTiling tiling[2];
+    DevTiling tiling[3];             // T0, T1, and the sparse T2 tiles (all layers; see t2_layer_range)
+    std::vector<std::pair<int32_t, int32_t>> t2_layer_range;   // device-tile ranges of tiling[2], one per T2 layer
     std::vector<std::unique_ptr<DevGColour>> gcolours;
     std::vector<std::unique_ptr<DevHalo>> halos;   // indexed by halo slot
     sbk::TickParams tp_host{};
@@ -260,7 +263,7 @@ void build_device(sb_solver *s) {
     HIP_CHECK(hipMemset(s->d_prev.p, 0, (size_t)s->n_local * 3 * sizeof(float)));
     s->d_tp.alloc(1, s->dev_bytes);
     // tilings: re-base this rank's tiles onto compact device arrays
-    for (int tl = 0; tl < 2; ++tl) {
+    for (int tl = 0; tl < 3; ++tl) {
         const sbp::Tiling &G = P.T[tl];
         sbp::LocalTiling LT = L.T[tl];     // copy: T0 is re-ordered boundary tiles first
         DevTiling &D = s->tiling[tl];
@@ -292,15 +295,24 @@ void build_device(sb_solver *s) {
         // them one after the other (the published order); only the number of workgroups changes.
         const size_t n_plan_tiles = LT.tile_ids.size();
         const int capacity = sbk::kSmallTile;         // packs stay small tiles; plan tiles above that size are left alone
+        // only tiles with short programs share a workgroup (the rim of a lattice: 3-4 rounds): zipping long programs of
+        // an irregular mesh (40+ rounds per tile) lengthens them, and such launches do not fill the chip anyway
+        constexpr int kPackMaxRounds = 8;
         std::vector<std::vector<int32_t>> packs;      // members (indices into LT.tile_ids), in execution order
         {
             std::vector<int32_t> pack_of(n_plan_tiles, -1), cand;
-            auto cls = [&](int32_t ci) { return ci < D.n_boundary ? 0 : 1; };
+            auto layer_of = [&](int32_t plan_tile) {
+                int ly = 0;
+                while (ly + 1 < (int)P.t2_layers.size() && plan_tile >= P.t2_layers[ly].second) ++ly;
+                return ly;
+            };
+            auto cls = [&](int32_t ci) { return tl == 2 ? layer_of(LT.tile_ids[ci]) : (ci < D.n_boundary ? 0 : 1); };
             auto size_of = [&](int32_t ci) { return G.tiles[LT.tile_ids[ci]].n_local; };
             auto runs_of = [&](int32_t ci) { return LT.run_begin[ci + 1] - LT.run_begin[ci]; };
             if (s->pack_tiles)
                 for (size_t ci = 0; ci < n_plan_tiles; ++ci)
-                    if (size_of((int32_t)ci) < capacity && runs_of((int32_t)ci) <= sbk::kInlineRuns) cand.push_back((int32_t)ci);
+                    if (size_of((int32_t)ci) < capacity && runs_of((int32_t)ci) <= sbk::kInlineRuns &&
+                        G.tiles[LT.tile_ids[ci]].n_rounds <= kPackMaxRounds) cand.push_back((int32_t)ci);
             std::sort(cand.begin(), cand.end(), [&](int32_t a, int32_t b) {
                 if (cls(a) != cls(b)) return cls(a) < cls(b);
                 if (size_of(a) != size_of(b)) return size_of(a) > size_of(b);
@@ -338,9 +350,20 @@ void build_device(sb_solver *s) {
             }
             D.n_boundary = n_boundary_packs;
         }
+        if (tl == 2) {
+            s->t2_layer_range.assign(P.t2_layers.size(), {0, 0});
+            for (size_t pk = 0; pk < packs.size(); ++pk) {
+                int ly = 0;
+                while (ly + 1 < (int)P.t2_layers.size() && LT.tile_ids[packs[pk][0]] >= P.t2_layers[ly].second) ++ly;
+                auto &rg = s->t2_layer_range[ly];
+                if (rg.second == rg.first) rg.first = (int32_t)pk;
+                rg.second = (int32_t)pk + 1;
+            }
+        }
         std::vector<sbk::TileDesc> tiles;
         std::vector<int2> overflow;
         std::vector<uint32_t> stream;
+        std::vector<int32_t> dev_gather;
         int32_t max_local = 0;
         uint32_t max_data = 4;
         int32_t max_pal = 0, max_rounds = 0;
@@ -358,6 +381,11 @@ void build_device(sb_solver *s) {
                 const int32_t ci = members[m];
                 const sbp::Tile &T = G.tiles[LT.tile_ids[ci]];
                 base[m] = lstart;
+                if (tl == 2) {
+                    if (m == 0) td.gather_begin = (int32_t)dev_gather.size();
+                    for (int32_t q = LT.gather_begin[ci]; q < LT.gather_begin[ci + 1]; ++q) dev_gather.push_back(LT.gather[q]);
+                    lstart += LT.gather_begin[ci + 1] - LT.gather_begin[ci];
+                }
                 for (int32_t r = LT.run_begin[ci]; r < LT.run_begin[ci + 1]; ++r, ++n_runs) {
                     const sbp::Run &rn = LT.runs[r];
                     if (n_runs < sbk::kInlineRuns) td.runs[n_runs] = make_int2(rn.start, lstart);
@@ -483,6 +511,7 @@ void build_device(sb_solver *s) {
         }
         D.tiles.upload(tiles, s->dev_bytes); D.runs_overflow.upload(overflow, s->dev_bytes);
         D.stream.upload(stream, s->dev_bytes);
+        D.gather.upload(dev_gather, s->dev_bytes);
     }
     for (const sbp::LocalGColour &LG : L.gcolours) {
         auto D = std::make_unique<DevGColour>();
@@ -570,6 +599,7 @@ void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = 
     A.pos = s->pos_view(); A.w8 = s->d_w8.p; A.wpal = s->d_wpal.p; A.prev = s->d_prev.p; A.vel = s->d_vel.p;
     A.tiles = D.tiles.p; A.runs_overflow = D.runs_overflow.p; A.stream = D.stream.p;
     A.tp = s->d_tp.p;
+    A.gather = D.gather.p;
     A.max_local = D.max_local; A.win_dwords = D.win_dwords; A.tile_base = tile_begin; A.pal_dwords = D.pal_dwords; A.rounds_dwords = D.rounds_dwords;
     const bool small = D.max_local <= sbk::kSmallTile;   // every tile <= 512 particles
     // narrow (2-wave) workgroups once the launch oversubscribes the chip; wide ones while every tile is resident at once
@@ -612,6 +642,16 @@ void launch_tick_kernel(sb_solver *s, int it, int substeps, LaunchTimer *lt, int
     else if (it < substeps) launch_tile<1>(s, D, tile_begin, tile_end);
     else launch_tile<2>(s, D, tile_begin, tile_end);
     if (lt && D.n_tiles) lt->end();
+}
+
+// The kernel of one T2 layer (constraints inside neither T0 nor T1, in LDS tiles of their own), after its ghost refresh.
+void launch_t2_layer(sb_solver *s, int layer, LaunchTimer *lt, bool with_halo = true) {
+    const auto rg = s->t2_layer_range[layer];
+    if (with_halo) halo_exchange(s, 2 + (int)s->gcolours.size() + layer);
+    if (rg.second <= rg.first) return;
+    if (lt) lt->begin(4 + (int)s->gcolours.size());
+    launch_tile<3>(s, s->tiling[2], rg.first, rg.second);
+    if (lt) lt->end();
 }
 
 void launch_gcolour(sb_solver *s, int gc, LaunchTimer *lt) {
@@ -663,6 +703,7 @@ void enqueue_substeps(sb_solver *s, int substeps, LaunchTimer *lt = nullptr, boo
         if (it == 0 && fused_first) launch_tick_kernel(s, 2, 4, lt);   // an even, interior step index: KIND 1 on T0
         else launch_tick_kernel(s, it, substeps, lt);
         if (it == substeps) break;
+        for (size_t ly = 0; ly < s->t2_layer_range.size(); ++ly) launch_t2_layer(s, (int)ly, lt);
         for (size_t gc = 0; gc < s->gcolours.size(); ++gc) {
             halo_exchange(s, 2 + (int)gc);
             launch_gcolour(s, (int)gc, lt);
@@ -874,14 +915,15 @@ int sb_finalize(sb_solver *s) {
         for (int a = 0; a < 3; ++a) o.dims[a] = s->desc.part_dims[a];
         o.tile_particles = s->desc.tile_particles;
         o.bank_aware_lanes = !std::getenv("SB_NO_BANK_ORDER");
+        o.third_tiling = !std::getenv("SB_NO_T2");
         s->plan = std::make_unique<sb_plan>();
         sbp::build_plan(in, o, s->plan->plan);
         sbp::extract_local(s->plan->plan, in, o.rank, s->plan->local);
         build_device(s);
         // opt in to the LDS size the largest tile needs
-        for (int tl = 0; tl < 2; ++tl)
+        for (int tl = 0; tl < 3; ++tl)
             if (s->tiling[tl].lds_bytes > 64 * 1024) throw std::runtime_error("internal: tile LDS budget exceeded");
-        if (s->desc.world > 1 && s->comm && s->plan->plan.tiling && s->gcolours.empty() && s->halos.size() > 1 &&
+        if (s->desc.world > 1 && s->comm && s->plan->plan.tiling && s->gcolours.empty() && s->t2_layer_range.empty() && s->halos.size() > 1 &&
             s->halos[1]->active() && std::getenv("SB_HALO_OVERLAP")) {
             // opt-in: on the one measurement available (RCCL loopback on one GPU, 8-rank share of 256^3) splitting the T0
             // launch and running the exchange beside the interior tiles was 10 % SLOWER than the serialised schedule
@@ -949,7 +991,7 @@ int sb_step_profiled(sb_solver *s, float dt, int32_t substeps, float *slot_ms, i
     if (!s || !slot_ms || !slot_launches) return fail(SB_ERR_INVALID_ARG, "sb_step_profiled: null argument");
     if (!s->finalized) return fail(SB_ERR_STATE, "sb_step_profiled before sb_finalize");
     if (!(dt > 0.0f) || substeps <= 0) return fail(SB_ERR_INVALID_ARG, "sb_step_profiled: dt and substeps must be positive");
-    if (n_slots != (int32_t)s->gcolours.size() + 4) return fail(SB_ERR_INVALID_ARG, "sb_step_profiled: n_slots must be 4 + n_global_colours");
+    if (n_slots != (int32_t)s->gcolours.size() + 5) return fail(SB_ERR_INVALID_ARG, "sb_step_profiled: n_slots must be 5 + n_global_colours");
     return guarded([&]() -> int {
         int rc = set_device(s); if (rc) return rc;
         flush_deferred(s);
@@ -978,7 +1020,10 @@ int sb_debug_launch(sb_solver *s, float dt, int32_t substeps, int32_t it, int32_
         int rc = set_device(s); if (rc) return rc;
         flush_deferred(s);
         upload_tick_params(s, dt, substeps);
-        if (gcolour < 0) launch_tick_kernel(s, it, substeps, nullptr);
+        if (gcolour <= -2) {
+            if (-2 - gcolour >= (int32_t)s->t2_layer_range.size()) return fail(SB_ERR_INVALID_ARG, "sb_debug_launch: no such T2 layer");
+            launch_t2_layer(s, -2 - gcolour, nullptr, false);
+        } else if (gcolour < 0) launch_tick_kernel(s, it, substeps, nullptr);
         else launch_gcolour(s, gcolour, nullptr);
         HIP_CHECK(hipGetLastError());
         HIP_CHECK(hipStreamSynchronize(s->stream));
@@ -1281,11 +1326,14 @@ int sb_get_stats(sb_solver *s, sb_stats *out) {
     out->n_tilings = P.tiling ? 2 : 1;
     out->n_global_colours = (int32_t)P.gcolours.size();
     for (int tl = 0; tl < 2; ++tl) { out->n_tiles[tl] = s->tiling[tl].n_tiles; out->tile_constraints[tl] = s->tiling[tl].n_slots; }
+    out->n_t2_layers = (int64_t)s->t2_layer_range.size();
+    out->n_t2_tiles = s->tiling[2].n_tiles;
+    out->t2_constraints = s->tiling[2].n_slots;
     out->constraints_in_tiles = P.cons_in_tiles;
     out->constraints_in_global = P.cons_in_global;
     for (size_t slot = 0; slot < s->halos.size(); ++slot) {
         const int64_t cnt = s->halos[slot]->send_off.back();
-        if (slot == 1) out->halo_particles_t1 = cnt; else out->halo_particles_global += cnt;
+        if (slot == 1) out->halo_particles_t1 = cnt; else out->halo_particles_global += cnt;   // global colours and T2 layers
     }
     out->device_bytes = s->dev_bytes;
     return SB_OK;
@@ -1305,6 +1353,7 @@ int sb_plan_build(const float *rest, int32_t n, const int32_t *dist_ij, int32_t 
             o.tile_particles = opts->tile_particles == 0 ? 512 : opts->tile_particles;
         }
         o.bank_aware_lanes = !std::getenv("SB_NO_BANK_ORDER");
+        o.third_tiling = !std::getenv("SB_NO_T2");
         sbp::Input in = make_input(rest, n, dist_ij, m_d, vol, m_v, bend, m_b);
         auto p = std::make_unique<sb_plan>();
         sbp::build_plan(in, o, p->plan);

@@ -176,7 +176,7 @@ class Softbody:
 
     def step_profiled(self, dt=None, substeps=None):
         """One eager tick with HIP events around every launch -> (ms per slot, launches per slot)."""
-        k = self.stats()["n_global_colours"] + 4
+        k = self.stats()["n_global_colours"] + 5
         ms = np.zeros(k, np.float32); cnt = np.zeros(k, np.int32)
         check(native.lib().sb_step_profiled(self._h, self.fixed_delta_time if dt is None else dt,
                                             self.substeps if substeps is None else substeps, ptr(ms), ptr(cnt), k))

@@ -31,7 +31,7 @@ class RankSim:
 
     Mirrors the GPU kernel sequence of one tick: kernel K_s runs on tiling T_(s&1) and does
     S_T (the tiling's constraint list) for substep s-1, the velocity update + integrate, S_T again for substep s; the global colours of
-    substep s follow. Ghosts are refreshed before every T1 kernel (slot 1: x and xprev) and before every
+    substep s follow (first the T2 tile kernel, which touches owned particles only). Ghosts are refreshed before every T1 kernel (slot 1: x and xprev) and before every
     cut global colour (slot 2+c: x)."""
 
     def __init__(self, oracle_mod, mesh, rank, world, dims, tile, gravity, damping, compliance):
@@ -62,6 +62,11 @@ class RankSim:
         for ph, (b, e) in zip(phases, off):
             if ph["kind"] in kinds and (tiling is None or ph["tiling"] == tiling):
                 self.o.project_range(s, b, e)
+
+    def project_phase(self, s, parity, index):
+        t, ids, phases, off = self.local[parity]
+        self.o.order_type, self.o.order_id = t, ids
+        self.o.project_range(s, *off[index])
 
     def gcolour_phases(self, parity):
         t, ids, phases, off = self.local[parity]
@@ -99,6 +104,12 @@ def run_tick(ranks, s, substeps, tiling_on, exchange):
             if it < substeps:
                 R.o.integrate(s)
                 R.project(s, it & 1, kinds=(1,), tiling=tl)         # S_tl starts substep it
+        if it < substeps:
+            for k3, ph0 in enumerate(p for p in ranks[0].local[it & 1][2] if p["kind"] == 3):     # T2 layers, in order
+                if ph0["halo_slot"] >= 0:
+                    exchange(ph0["halo_slot"], False)                # ghosts of T2 tiles that span ranks (positions only)
+                for R in ranks:
+                    R.project_phase(s, it & 1, [i for i, p in enumerate(R.local[it & 1][2]) if p["kind"] == 3][k3])
         if it == substeps:
             break
         n_g = len(ranks[0].gcolour_phases(it & 1))

@@ -44,7 +44,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(native.SbDesc) == 48
     assert C.sizeof(native.SbPlanOpts) == 24
     assert C.sizeof(native.SbPhaseInfo) == 48
-    assert C.sizeof(native.SbStats) == 8 * 2 + 8 * 3 + 4 * 2 + 8 * 4 + 8 * 5
+    assert C.sizeof(native.SbStats) == 8 * 2 + 8 * 3 + 4 * 2 + 8 * 4 + 8 * 5 + 8 * 3
 
 
 def test_loads_without_gpu_and_fails_loudly():

@@ -97,6 +97,7 @@ def _hosted_worker(rank, world, port, tile, mesh_kind, out_dir):
     n_slots = plan.halo_slot_count()
     halos = [plan.halo(k, world) for k in range(n_slots)]
     G = sb.stats()["n_global_colours"]
+    n_t2 = sb.stats()["n_t2_layers"]
     tiling = sb.stats()["n_tilings"] == 2
 
     def exchange(slot):
@@ -131,6 +132,9 @@ def _hosted_worker(rank, world, port, tile, mesh_kind, out_dir):
             native.check(L.sb_debug_launch(sb._h, dt, S, it, -1))
             if it == S:
                 break
+            for ly in range(n_t2):                       # T2 layers: their own ghost refresh, then the layer's kernel
+                exchange(2 + G + ly)
+                native.check(L.sb_debug_launch(sb._h, dt, S, it, -2 - ly))
             for gc in range(G):
                 exchange(2 + gc)
                 native.check(L.sb_debug_launch(sb._h, dt, S, it, gc))

@@ -78,10 +78,19 @@ def test_pinned_top_layer_and_damping_and_compliance(oracle_mod):
     assert np.array_equal(x[top], mesh.pos[top])
 
 
-def test_full_stencil_mixed_tile_and_global(oracle_mod):
+@pytest.mark.parametrize("third_tiling", [True, False])
+def test_full_stencil_mixed_tile_and_global(oracle_mod, monkeypatch, third_tiling):
+    # diagonal springs lie inside neither T0 nor T1: with the third tiling they run in the T2 layers' LDS tiles, without
+    # it in global colours between the two tile phases
+    if not third_tiling:
+        monkeypatch.setenv("SB_NO_T2", "1")
     mesh = jelly_cube(14, stencil="full")
     rel, mabs, bit, x, v, o, st = _run_pair(oracle_mod, mesh, ticks=5, substeps=10, tile_particles=64, compliance=(1e-7, 0, 0))
-    assert st["n_global_colours"] > 0 and st["constraints_in_tiles"] > 0 and st["constraints_in_global"] > 0
+    assert st["constraints_in_tiles"] > 0
+    if third_tiling:
+        assert st["n_t2_layers"] > 0 and st["t2_constraints"] > 0 and st["n_t2_tiles"] > 0
+    else:
+        assert st["n_t2_layers"] == 0 and st["n_global_colours"] > 0 and st["constraints_in_global"] > 0
     assert rel <= TOL and bit
 
 
