@@ -169,7 +169,8 @@ typedef struct {
     int32_t tile_particles;
 } sb_plan_opts;
 typedef struct {
-    int32_t kind;               /* 0 = global colour, 1 = a tiling's tiles, first phase of the substep, 2 = the other tiling's tiles, last phase */
+    int32_t kind;               /* 0 = global colour, 1 = a tiling's tiles, first phase of the substep, 2 = the other tiling's tiles,
+                                   last phase, 3 = the sparse tiles of one T2 layer (after kind 1, before the global colours) */
     int32_t type;               /* kind 0: constraint type 0/1/2; else -1 */
     int32_t tiling;             /* kind 1/2: 0 or 1; kind 0: -1 */
     int32_t halo_slot;          /* -1 none; 1 = before the T1 tile kernel; 2+c = before global colour c */
