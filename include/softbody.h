@@ -173,7 +173,8 @@ typedef struct {
                                    last phase, 3 = the sparse tiles of one T2 layer (after kind 1, before the global colours) */
     int32_t type;               /* kind 0: constraint type 0/1/2; else -1 */
     int32_t tiling;             /* kind 1/2: 0 or 1; kind 0: -1 */
-    int32_t halo_slot;          /* -1 none; 1 = before the T1 tile kernel; 2+c = before global colour c */
+    int32_t halo_slot;          /* -1 none; 1 = before the T1 tile kernel; 2+c = before global colour c;
+                                   2+G+l = before the kernel of T2 layer l (G = number of global colours) */
     int64_t order_begin, order_end; /* slice of the parity's published order */
     int64_t task_begin, task_end;   /* slice of the task table: tasks of one phase touch disjoint particles */
 } sb_phase_info;
