@@ -12,6 +12,18 @@ Launch: `python bench.py` (N=1) or
  bench.py --gpus N --steps K --warmup W` — one process per GPU. torch.distributed (gloo) carries only the
 control plane (unique-id broadcast, barriers, max-over-ranks); the ghost exchange itself is RCCL
 send/recv inside the plugin on its own HIP stream.
+
+Self-verification (outside the timed region, `config.parity`):
+  golden : an order-independent checksum of the positions + velocities the timed run ended with (after warmup + steps
+           ticks; ranks add their partial sums) against tests/golden/state_checksums.json, which
+           tests/golden/make_checksums.py generated from the CPU oracle for 1..40 ticks of the 64^3 and 256^3 cubes;
+  small  : the same number of ticks on a 40^3 cube through the plugin against the oracle run live, bit for bit;
+  live   : (N = 1, with the CPU baseline) the solver is reset to the initial state and advanced as many ticks as the
+           cpu_baseline leg advanced the oracle on the SAME mesh; positions and velocities compared bit for bit.
+Roofline block: `achieved`/`frac` are HBM traffic per launch / kernel time against the 8 TB/s peak, with the traffic
+taken from the PMC counters (profiles/hbm_traffic.json) after checking it against the compulsory-bytes model of the
+tables actually uploaded (sb_get_stats launch_bytes); the SURVEY 8d algorithmic-bytes figure is kept beside it as
+`frac_algorithmic` with the on-chip reuse factor.
 """
 import argparse
 import json
@@ -32,6 +44,13 @@ def b_alg(n_particles, n_constraints):
     return 52.0 * n_particles + 68.0 * n_constraints + 36.0 * n_particles
 
 
+def _golden_entry(n, substeps, tile):
+    path = os.path.join(ROOT, "tests", "golden", "state_checksums.json")
+    if not os.path.exists(path):
+        return None
+    return json.load(open(path)).get(f"cube{n}_s{substeps}_tile{tile}")
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -42,7 +61,10 @@ def main():
     ap.add_argument("--tile", type=int, default=512, help="target particles per LDS tile, -1 = global colours only")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-n", type=int, default=0, help="cube edge for the CPU baseline sample (0 = auto)")
+    ap.add_argument("--no-parity", action="store_true", help="skip the self-verification legs (profiling runs)")
+    ap.add_argument("--cpu-sample-n", type=int, default=0, help="cube edge for the CPU baseline sample (0 = the workload itself)")
+    ap.add_argument("--allow-stale-traffic", action="store_true",
+                    help="do not fail when profiles/hbm_traffic.json disagrees with the compulsory-bytes model (used while re-measuring it)")
     ap.add_argument("--loopback-world", type=int, default=0,
                     help="diagnostic: run as rank 0 of this many ranks with SB_TEST_LOOPBACK (RCCL self-exchange on one GPU); "
                          "the reported value counts only the particles this rank owns")
@@ -74,6 +96,7 @@ def main():
     device = local_rank if (n_dev == 0 or local_rank < n_dev) else local_rank % n_dev
 
     from softbodyunity_amd import Softbody, comm_unique_id, jelly_cube
+    from softbodyunity_amd.verify import add_checksums, schedule_hash, state_checksum
 
     t_setup = time.time()
     mesh = jelly_cube(args.n)
@@ -120,6 +143,36 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    # ---- self-verification, leg 1: the state the timed run ended with, against the oracle's golden checksum ------
+    total_ticks = args.warmup + args.steps
+    parity = {"ticks": total_ticks}
+    loopback = args.loopback_world > 1
+    if not args.no_parity and not loopback:
+        owned_mask = sb.owner() == rank
+        ids = np.nonzero(owned_mask)[0]
+        x_end = sb.get_positions(); v_end = sb.get_velocities()
+        finite = bool(np.isfinite(x_end[ids]).all())
+        part = state_checksum(x_end[ids], v_end[ids], ids)
+        if dist is not None:
+            parts = [None] * world
+            dist.all_gather_object(parts, part)
+            fin = [None] * world
+            dist.all_gather_object(fin, finite)
+            finite = all(fin)
+        else:
+            parts = [part]
+        checksum = add_checksums(parts)
+        golden = _golden_entry(args.n, args.substeps, args.tile)
+        want = golden["ticks"].get(str(total_ticks)) if golden else None
+        parity["golden"] = {"n": N, "checksum": f"0x{checksum:016x}", "expected": want,
+                            "bitwise": (int(want, 16) == checksum) if want else None,
+                            "source": "tests/golden/state_checksums.json (CPU oracle, tests/golden/make_checksums.py)"}
+        if golden and world == 1 and rank == 0:
+            parity["golden"]["schedule_matches"] = schedule_hash(sb.plan()) == golden["schedule"]
+        del x_end, v_end
+    else:
+        finite = bool(np.isfinite(sb.get_positions()[sb.owner() == rank]).all())
+
     # per-kernel HIP-event timing on the solver's stream: a few extra eager ticks, outside the timed region
     prof_ticks = 2
     slot_ms = None
@@ -128,9 +181,8 @@ def main():
         slot_ms = ms.astype(np.float64) if slot_ms is None else slot_ms + ms
         slot_cnt = cnt
     slot_ms /= prof_ticks
-    finite = bool(np.isfinite(sb.get_positions()[sb.owner() == rank]).all())
 
-    if args.loopback_world > 1:
+    if loopback:
         N = int(stats["n_particles_owned"])      # diagnostic mode: only this rank's share is simulated
     value = N * args.substeps * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
@@ -147,29 +199,50 @@ def main():
         # + one integrate (52 B) per particle and projects every constraint it stores TWICE (before and after
         # the MARK step: the tail of one substep and the head of the next), 68 B each time
         alg_bytes = [88.0 * owned + 2 * 68.0 * stats["tile_constraints"][t] for t in (0, 1)]
+        # compulsory HBM bytes per launch from the tables actually uploaded (sb_get_stats): the model the PMC figure is checked against
+        lb = stats["launch_bytes"]
+        model_bytes = [float(lb[0]), float(lb[1])]
         mask0 = None
         for c in range(G):
             if mask0 is None:
                 plan = sb.plan(); mask0 = plan.local_order_mask(0).astype(bool); ph0 = [p for p in plan.phases(0) if p["kind"] == 0]
-            alg_bytes.append(68.0 * int(mask0[ph0[c]["order_begin"]:ph0[c]["order_end"]].sum()))
+            cnt_c = int(mask0[ph0[c]["order_begin"]:ph0[c]["order_end"]].sum())
+            alg_bytes.append(68.0 * cnt_c)
+            model_bytes.append(68.0 * cnt_c)      # global colours gather/scatter straight on HBM: no on-chip reuse to model
         last = (args.substeps & 1) if stats["n_tilings"] == 2 else 0
         alg_bytes += [52.0 * owned + 68.0 * stats["tile_constraints"][0], 36.0 * owned + 68.0 * stats["tile_constraints"][last]]
         alg_bytes.append(68.0 * stats["t2_constraints"])
+        model_bytes += [float(lb[2]), float(lb[3]) if last == 0 else float(lb[1] - (lb[0] - lb[3])), float(lb[4])]
         k_dom = int(np.argmax(slot_ms))
         launches = max(int(slot_cnt[k_dom]), 1)
         dom_ms = float(slot_ms[k_dom]) / launches
-        achieved = alg_bytes[k_dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        traffic = None
+        # HBM traffic per launch of the dominant kernel: PMC counters (profiles/hbm_traffic.json, produced by
+        # tools/prof_summary.py from separate FETCH_SIZE / WRITE_SIZE passes) -- accepted only when within 3 % of the
+        # compulsory-bytes model of THIS build's tables, so the file cannot go stale unnoticed
+        traffic, traffic_src, traffic_meta = None, None, None
+        key = f"n{args.n}_tile{args.tile}_gpus{world}"
         tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))
-                key = f"n{args.n}_tile{args.tile}_gpus{world}"
-                if key in tj and str(k_dom) in tj[key]:
-                    traffic = tj[key][str(k_dom)]
-            except Exception:
+        tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+        if not loopback and key in tj and str(k_dom) in tj[key]:
+            traffic = float(tj[key][str(k_dom)])
+            traffic_meta = tj[key].get("meta")
+            dev = abs(traffic - model_bytes[k_dom]) / model_bytes[k_dom]
+            if dev > 0.03:    # the entry was measured on another kernel / data layout
+                msg = (f"profiles/hbm_traffic.json[{key}][{k_dom}] = {traffic:.4g} B disagrees with the compulsory-bytes model "
+                       f"{model_bytes[k_dom]:.4g} B of this build by {100 * dev:.1f} %: re-measure (tools/profile_round.sh)")
+                if not args.allow_stale_traffic:
+                    raise SystemExit("bench.py: " + msg)
+                print("WARNING: " + msg, file=sys.stderr)
                 traffic = None
+            else:
+                traffic_src = "pmc"
+        elif args.n == 256 and args.tile == 512 and world == 1 and not loopback and not args.allow_stale_traffic:
+            raise SystemExit(f"bench.py: profiles/hbm_traffic.json has no PMC entry for {key} slot {k_dom}")
+        hbm_bytes = traffic if traffic is not None else model_bytes[k_dom]
+        achieved = hbm_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+        alg_rate = alg_bytes[k_dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
         job_alg = b_alg(N, M) * value / N   # algorithmic B/s of the whole job
+        parity["finite"] = finite
         out = {
             "metric": "particle-substeps/sec", "value": value, "unit": "particle-substeps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
@@ -177,26 +250,35 @@ def main():
             "config": {"workload": f"{args.n}^3 jelly cube, structural springs (N={N}, M={M}), {args.substeps} substeps/tick, "
                                    f"dt=0.02, explicit index-array graph, tile_particles={args.tile}",
                        "partition": "x".join(str(d) for d in _dims(world)), "graph_replay": (not args.no_graph) and world == 1,
-                       "finite": finite},
+                       "finite": finite, "parity": parity},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
+                         "traffic_source": traffic_src or "none for this configuration: achieved/frac use the compulsory-bytes model",
+                         "traffic_measured_on": traffic_meta,
+                         "model_bytes_per_launch": model_bytes[k_dom],
+                         "traffic_over_model": (traffic / model_bytes[k_dom]) if traffic else None,
                          "kernel": names[k_dom], "kernel_avg_ms": dom_ms, "kernel_launches_per_tick": launches,
                          "algorithmic_bytes_per_launch": alg_bytes[k_dom],
-                         "traffic_GBps": (traffic / (dom_ms * 1e-3) / 1e9) if traffic else None,
-                         "frac_traffic": (traffic / (dom_ms * 1e-3) / HBM_PEAK) if traffic else None,
-                         "note": "achieved/frac use ALGORITHMIC bytes (SURVEY 8d: 88 B/particle + 68 B per projected constraint per "
-                                 "mid-tick launch); the tile kernel keeps positions in LDS across ~3.6 algorithmic passes, so frac > 1 "
-                                 "is on-chip reuse, not a measurement error: traffic (PMC FETCH/WRITE_SIZE) and frac_traffic "
-                                 "give the HBM side",
-                         "job_algorithmic_GBps": job_alg / 1e9, "job_frac": job_alg / (HBM_PEAK * world),
+                         "algorithmic_GBps": alg_rate, "frac_algorithmic": alg_rate / (HBM_PEAK / 1e9),
+                         "reuse_factor": alg_bytes[k_dom] / hbm_bytes,
+                         "note": "achieved/frac = HBM bytes per launch (PMC FETCH_SIZE/WRITE_SIZE where measured for this "
+                                 "configuration, else the compulsory-bytes model of the uploaded tables) / kernel time, against "
+                                 "8 TB/s. frac_algorithmic uses the SURVEY 8d figure (88 B/particle + 68 B per projected "
+                                 "constraint per mid-tick launch); it exceeds 1 because the tile kernel serves those accesses "
+                                 "from LDS (reuse_factor = algorithmic / HBM bytes)",
+                         "job_algorithmic_GBps": job_alg / 1e9, "job_frac_algorithmic": job_alg / (HBM_PEAK * world),
                          "B_alg_per_particle_substep": b_alg(N, M) / N,
                          "tick_ms_hip_events": ev_ms / args.steps,
                          "per_slot_ms_per_tick": {names[k]: float(slot_ms[k]) for k in range(len(names))},
                          "per_slot_launches_per_tick": {names[k]: int(slot_cnt[k]) for k in range(len(names))}},
             "setup_seconds": setup_s, "plan": stats,
         }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(mesh, sb, args)
+        if world == 1 and not loopback and not args.no_parity:
+            parity["small"] = small_parity(total_ticks, args, device)
+        if world == 1 and not loopback and not args.no_cpu_baseline:
+            out["cpu_baseline"], live = cpu_baseline(mesh, sb, args)
+            if live is not None:
+                parity["live"] = live
     sb.OnDestroy()
     if dist is not None:
         dist.barrier()
@@ -211,16 +293,43 @@ def _dims(world):
     return {1: (1, 1, 1), 2: (2, 1, 1), 4: (2, 2, 1), 8: (2, 2, 2)}.get(world, (world, 1, 1))
 
 
-def cpu_baseline(mesh, sb, args):
-    """The CPU oracle (kind "port": the reference has no CPU path to time, /root/reference/README.md:1),
-    on this box's host cores, over a bounded sample of the same workload."""
+def _oracle_tools():
     from oracle import oracle
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     from helpers import build_plan, make_oracle
+    return oracle, build_plan, make_oracle
+
+
+def small_parity(ticks, args, device):
+    """Checker leg: the same number of ticks on a 40^3 cube, plugin vs the CPU oracle run live, bit for bit."""
+    from softbodyunity_amd import Softbody, jelly_cube
+    oracle, _, make_oracle = _oracle_tools()
+    m = jelly_cube(40)
+    sb = Softbody(m, substeps=args.substeps, device=device, tile_particles=args.tile, use_graph=not args.no_graph).Start()
+    try:
+        o = make_oracle(oracle, m, sb.plan())
+        for _ in range(ticks):
+            sb.step()
+            o.step(0.02, args.substeps)
+        x = sb.get_positions(); v = sb.get_velocities()
+    finally:
+        sb.OnDestroy()
+    rel, mabs, bit = oracle.parity_error(x, o.x, m.pos)
+    return {"n": m.n, "ticks": ticks, "rel": rel, "max_abs": mabs,
+            "bitwise": bool(bit and np.array_equal(v.view(np.uint32), o.v.view(np.uint32)))}
+
+
+def cpu_baseline(mesh, sb, args):
+    """The CPU oracle (kind "port": the reference has no CPU path to time, /root/reference/README.md:1), on this box's
+    host cores, over a bounded sample of the same workload: by default the workload's own mesh, one sequential tick
+    (Unity FixedUpdate semantics) and then task-parallel ticks. When the sample IS the workload the oracle's final
+    state doubles as the checker of a live parity leg: the solver is reset and advanced the same number of ticks."""
+    oracle, build_plan, make_oracle = _oracle_tools()
     from softbodyunity_amd import jelly_cube
-    n_s = args.cpu_sample_n or min(args.n, 128)
-    m = mesh if n_s == args.n else jelly_cube(n_s)
-    plan = sb.plan() if n_s == args.n else build_plan(m, tile_particles=args.tile)
+    n_s = args.cpu_sample_n or args.n
+    same = n_s == args.n
+    m = mesh if same else jelly_cube(n_s)
+    plan = sb.plan() if same else build_plan(m, tile_particles=args.tile)
     o = make_oracle(oracle, m, plan)
     S = args.substeps
     t0 = time.perf_counter(); ticks = 0
@@ -246,11 +355,21 @@ def cpu_baseline(mesh, sb, args):
                 model = line.split(":", 1)[1].strip(); break
     except OSError:
         pass
+    live = None
+    if same and not args.no_parity:
+        sb.set_state(m.pos, m.vel)
+        for _ in range(ticks + pt):
+            sb.step()
+        x = sb.get_positions(); v = sb.get_velocities()
+        rel, mabs, bit = oracle.parity_error(x, o.x, m.pos)
+        live = {"n": m.n, "ticks": ticks + pt, "rel": rel, "max_abs": mabs,
+                "bitwise": bool(bit and np.array_equal(v.view(np.uint32), o.v.view(np.uint32))),
+                "checker": "oracle/oracle.c on the workload's own mesh (the cpu_baseline sample), same initial state"}
     return {"value": v1, "unit": "particle-substeps/s", "cores": 1, "kind": "port",
             "sample": f"{ticks} tick(s) x {S} substeps of the {n_s}^3 cube, sequential oracle (Unity FixedUpdate semantics), "
                       f"same published schedule",
             "all_cores": {"value": vp, "cores": cores, "sample": f"{pt} tick(s), task-parallel oracle (OpenMP)"},
-            "cpu_model": model}
+            "cpu_model": model}, live
 
 
 if __name__ == "__main__":

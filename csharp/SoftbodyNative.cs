@@ -35,6 +35,8 @@ namespace SoftbodyMI355X
         public long constraintsInTiles, constraintsInGlobal;
         public long haloParticlesT1, haloParticlesGlobal, deviceBytes;
         public long nT2Layers, nT2Tiles, t2Constraints;
+        // compulsory HBM bytes of one launch: mid-tick on T0 / T1, first, last kernel of a tick, all T2 layers of a substep
+        public long launchBytesMidT0, launchBytesMidT1, launchBytesFirst, launchBytesLast, launchBytesT2;
     }
 
     [StructLayout(LayoutKind.Sequential)]

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SB_ABI_VERSION 3
+#define SB_ABI_VERSION 4
 
 typedef enum {
     SB_OK = 0,
@@ -104,7 +104,9 @@ int sb_set_state(sb_solver *s, const float *pos_xyz, const float *vel_xyz, int32
  * (a small kernel on the compute stream) and starts a D2H copy into plugin-owned pinned memory on a second
  * stream; the next sb_step overlaps with that copy. sb_readback_end waits for the OLDEST pending snapshot and
  * returns a pointer to n*3 floats in caller numbering (entries of particles another rank owns stay 0), valid
- * until the second sb_readback_begin after it. At most two snapshots may be pending. */
+ * until the second sb_readback_begin after it (the plugin keeps three snapshot buffers for at most two pending
+ * snapshots, so the buffer handed out last is never the next one filled). sb_set_render_triangles re-allocates the
+ * render-set buffers and invalidates pointers returned earlier. */
 int sb_readback_begin(sb_solver *s);
 int sb_readback_end(sb_solver *s, const float **pos_xyz_out);
 /* Render normals (SPEC.md 6a; replaces Unity's Mesh.RecalculateNormals on the main thread): give the render
@@ -157,6 +159,12 @@ typedef struct {
     int64_t device_bytes;                           /* device memory held by the solver */
     int64_t n_t2_layers;                            /* third-tiling layers (constraints inside neither T0 nor T1 that got LDS tiles) */
     int64_t n_t2_tiles, t2_constraints;             /* workgroups per substep / constraints of all T2 layers, this rank */
+    /* Compulsory HBM bytes of ONE launch (every array the kernel touches counted once: particle state read and written,
+     * the tiles' constraint streams, descriptors and particle lists), from the tables actually uploaded -- the model the
+     * PMC-measured traffic in profiles/ is checked against (bench.py). Indexed like the slots of sb_step_profiled with
+     * G = 0: 0 / 1 = mid-tick kernel on T0 / T1, 2 = first kernel of a tick, 3 = last kernel of a tick (on T0; on T1 it
+     * moves launch_bytes[1] - (launch_bytes[0] - launch_bytes[3])), 4 = all T2 layers of one substep. */
+    int64_t launch_bytes[5];
 } sb_stats;
 int sb_get_stats(sb_solver *s, sb_stats *out);
 

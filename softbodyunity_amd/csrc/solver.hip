@@ -74,6 +74,8 @@ struct DevTiling {
     int32_t n_tiles = 0;
     size_t lds_bytes = 0;
     int64_t n_slots = 0;         // constraints stored in the tile streams
+    int64_t staged_particles = 0;   // sum of n_local over the device tiles
+    int64_t stream_bytes = 0;    // bytes of the tile streams (round words, palettes, slots)
     int32_t max_local = 0, win_dwords = 4, pal_dwords = 0, rounds_dwords = 0;
     int32_t n_boundary = 0;      // T0 with world > 1: the first n_boundary tiles hold every particle some peer needs
     bool has_quads = false;
@@ -139,7 +141,10 @@ struct sb_solver {
     std::vector<std::unique_ptr<DevHalo>> halos;   // indexed by halo slot
     sbk::TickParams tp_host{};
     bool tp_valid = false;
-    std::map<int, hipGraphExec_t> graphs;      // key = substeps * 4 + (1: tick starts with the fused kernel) + (2: last kernel deferred)
+    struct CachedGraph { hipGraphExec_t exec; uint64_t last_use; };
+    std::map<int, CachedGraph> graphs;         // key = substeps * 4 + (1: tick starts with the fused kernel) + (2: last kernel deferred)
+    uint64_t graph_clock = 0;                  // least recently used entry is evicted beyond kMaxGraphs (a host that varies substeps)
+    static constexpr size_t kMaxGraphs = 8;
     // Lazy tick boundary: the last kernel of a tick (rounds + collide + velocity write) is deferred; if the next tick
     // has the same parameters it is FUSED with that tick's first kernel into one ordinary mid-tick kernel, otherwise
     // (or whenever state is read or written) it is flushed first. Results are identical either way.
@@ -156,32 +161,35 @@ struct sb_solver {
     hipStream_t copy_stream = nullptr;
     DevBuf<int32_t> d_local_to_old;
     DevBuf<float> d_get_scratch;           // caller-numbered staging of the blocking sb_get_* calls (world == 1)
-    DevBuf<float> d_snap[2];
-    float *h_snap[2] = {nullptr, nullptr};
-    hipEvent_t ev_snap[2] = {nullptr, nullptr}, ev_copied[2] = {nullptr, nullptr};
-    int snap_head = 0, snap_pending = 0;   // ring of at most two snapshots in flight
+    // three slots, at most two pending: the slot sb_readback_end handed out last is never the next one to be filled, so
+    // its pointer stays valid until the SECOND sb_readback_begin after it (softbody.h)
+    static constexpr int kSnapSlots = 3;
+    DevBuf<float> d_snap[kSnapSlots];
+    float *h_snap[kSnapSlots] = {nullptr, nullptr, nullptr};
+    hipEvent_t ev_snap[kSnapSlots] = {nullptr, nullptr, nullptr}, ev_copied[kSnapSlots] = {nullptr, nullptr, nullptr};
+    int snap_head = 0, snap_pending = 0;   // ring: slots snap_head .. snap_head + snap_pending - 1 (mod kSnapSlots) are in flight
     // render normals of the snapshots (sb_set_render_triangles): incident-triangle lists per particle, caller numbering
     std::vector<int32_t> render_tri;
     bool render_dirty = false;             // triangles changed since the last upload
     DevBuf<int32_t> d_tri, d_adj_off, d_adj_tri, d_render_set, d_render_local;
     std::vector<int32_t> render_set;       // particles used by the render triangles, ascending
     bool render_set_only = false;          // readbacks bring the render set only (compact positions + normals)
-    DevBuf<float> d_cpos[2];               // compact positions of the render set
-    float *h_cpos[2] = {nullptr, nullptr};
-    bool snap_compact[2] = {false, false};
-    DevBuf<float> d_nrm[2];
-    float *h_nrm[2] = {nullptr, nullptr};
-    bool snap_has_normals[2] = {false, false};
+    DevBuf<float> d_cpos[kSnapSlots];      // compact positions of the render set
+    float *h_cpos[kSnapSlots] = {nullptr, nullptr, nullptr};
+    bool snap_compact[kSnapSlots] = {false, false, false};
+    DevBuf<float> d_nrm[kSnapSlots];
+    float *h_nrm[kSnapSlots] = {nullptr, nullptr, nullptr};
+    bool snap_has_normals[kSnapSlots] = {false, false, false};
     int snap_last_ended = -1;
 
     ~sb_solver() {
-        for (auto &g : graphs) (void)hipGraphExecDestroy(g.second);
+        for (auto &g : graphs) (void)hipGraphExecDestroy(g.second.exec);
         if (comm) (void)ncclCommDestroy(comm);
         if (ev_boundary) (void)hipEventDestroy(ev_boundary);
         if (ev_halo) (void)hipEventDestroy(ev_halo);
         if (comm_stream) (void)hipStreamDestroy(comm_stream);
         gcolours.clear(); halos.clear();
-        for (int k = 0; k < 2; ++k) {
+        for (int k = 0; k < kSnapSlots; ++k) {
             if (h_snap[k]) (void)hipHostFree(h_snap[k]);
             if (h_nrm[k]) (void)hipHostFree(h_nrm[k]);
             if (h_cpos[k]) (void)hipHostFree(h_cpos[k]);
@@ -509,6 +517,9 @@ void build_device(sb_solver *s) {
             const sbp::Tile &T = G.tiles[LT.tile_ids[ci]];
             D.n_slots += (T.d_end - T.d_begin) + (T.q_end - T.q_begin);
         }
+        D.staged_particles = 0;
+        for (const sbk::TileDesc &td : tiles) D.staged_particles += td.n_local;
+        D.stream_bytes = (int64_t)stream.size() * 4;
         D.tiles.upload(tiles, s->dev_bytes); D.runs_overflow.upload(overflow, s->dev_bytes);
         D.stream.upload(stream, s->dev_bytes);
         D.gather.upload(dev_gather, s->dev_bytes);
@@ -573,12 +584,17 @@ void halo_exchange(sb_solver *s, int slot, hipStream_t st = nullptr) {
                                s->d_prev.p, D.send_idx.p, s->d_sendbuf.p, ns);
     }
     NCCL_CHECK(ncclGroupStart());
-    for (size_t k = 0; k < D.peers.size(); ++k) {
-        int cs = D.send_off[k + 1] - D.send_off[k], cr = D.recv_off[k + 1] - D.recv_off[k];
-        if (s->loopback) cs = cr = std::min(cs, cr);   // a self-exchange must post equal sizes (real peers always do)
-        const size_t fl = with_prev ? 6 : 3;   // floats per ghost; one message per peer and direction
-        if (cs) NCCL_CHECK(ncclSend(s->d_sendbuf.p + fl * D.send_off[k], fl * (size_t)cs, ncclFloat, s->loopback ? 0 : D.peers[k], s->comm, st));
-        if (cr) NCCL_CHECK(ncclRecv(s->d_recvbuf.p + fl * D.recv_off[k], fl * (size_t)cr, ncclFloat, s->loopback ? 0 : D.peers[k], s->comm, st));
+    try {
+        for (size_t k = 0; k < D.peers.size(); ++k) {
+            int cs = D.send_off[k + 1] - D.send_off[k], cr = D.recv_off[k + 1] - D.recv_off[k];
+            if (s->loopback) cs = cr = std::min(cs, cr);   // a self-exchange must post equal sizes (real peers always do)
+            const size_t fl = with_prev ? 6 : 3;   // floats per ghost; one message per peer and direction
+            if (cs) NCCL_CHECK(ncclSend(s->d_sendbuf.p + fl * D.send_off[k], fl * (size_t)cs, ncclFloat, s->loopback ? 0 : D.peers[k], s->comm, st));
+            if (cr) NCCL_CHECK(ncclRecv(s->d_recvbuf.p + fl * D.recv_off[k], fl * (size_t)cr, ncclFloat, s->loopback ? 0 : D.peers[k], s->comm, st));
+        }
+    } catch (...) {
+        (void)ncclGroupEnd();      // never leave the group open behind an error
+        throw;
     }
     NCCL_CHECK(ncclGroupEnd());
     if (nr) {
@@ -977,9 +993,17 @@ int sb_step(sb_solver *s, float dt, int32_t substeps) {
                 hipError_t e = hipGraphInstantiate(&ge, g, nullptr, nullptr, 0);
                 (void)hipGraphDestroy(g);
                 if (e != hipSuccess) throw HipError(SB_ERR_HIP, std::string("hipGraphInstantiate: ") + hipGetErrorString(e));
-                it = s->graphs.emplace(key, ge).first;
+                if (s->graphs.size() >= sb_solver::kMaxGraphs) {     // evict the least recently used executable
+                    auto old = s->graphs.begin();
+                    for (auto q = s->graphs.begin(); q != s->graphs.end(); ++q) if (q->second.last_use < old->second.last_use) old = q;
+                    HIP_CHECK(hipStreamSynchronize(s->stream));          // it may still be running
+                    (void)hipGraphExecDestroy(old->second.exec);
+                    s->graphs.erase(old);
+                }
+                it = s->graphs.emplace(key, sb_solver::CachedGraph{ge, 0}).first;
             }
-            HIP_CHECK(hipGraphLaunch(it->second, s->stream));
+            it->second.last_use = ++s->graph_clock;
+            HIP_CHECK(hipGraphLaunch(it->second.exec, s->stream));
         }
         s->deferred = can_defer;
         s->deferred_substeps = substeps;
@@ -1159,7 +1183,7 @@ int sb_readback_begin(sb_solver *s) {
         if (!s->copy_stream) {
             HIP_CHECK(hipStreamCreateWithFlags(&s->copy_stream, hipStreamNonBlocking));
             if (!s->d_local_to_old.p) s->d_local_to_old.upload(s->plan->local.local_to_old, s->dev_bytes);
-            for (int k = 0; k < 2; ++k) {
+            for (int k = 0; k < sb_solver::kSnapSlots; ++k) {
                 s->d_snap[k].alloc((size_t)s->n * 3, s->dev_bytes);
                 HIP_CHECK(hipMemset(s->d_snap[k].p, 0, (size_t)s->n * 3 * sizeof(float)));
                 HIP_CHECK(hipHostMalloc((void **)&s->h_snap[k], (size_t)s->n * 3 * sizeof(float), hipHostMallocDefault));
@@ -1169,7 +1193,7 @@ int sb_readback_begin(sb_solver *s) {
             }
         }
         flush_deferred(s);
-        const int k = (s->snap_head + s->snap_pending) & 1;
+        const int k = (s->snap_head + s->snap_pending) % sb_solver::kSnapSlots;
         // snapshot on the compute stream (ordered after every tick enqueued so far, before the next one) ...
         const bool compact = s->render_set_only && !s->render_tri.empty();
         if (!s->render_tri.empty() && s->render_dirty) {     // (re)build the incident-triangle lists: triangle ids ascending per particle
@@ -1189,7 +1213,7 @@ int sb_readback_begin(sb_solver *s) {
             s->d_adj_tri.upload(adj, s->dev_bytes);
             s->d_render_set.upload(s->render_set, s->dev_bytes);
             s->d_render_local.upload(local_of, s->dev_bytes);
-            for (int q = 0; q < 2; ++q) {
+            for (int q = 0; q < sb_solver::kSnapSlots; ++q) {
                 if (!s->h_nrm[q]) {
                     s->d_nrm[q].alloc((size_t)s->n * 3, s->dev_bytes);
                     HIP_CHECK(hipHostMalloc((void **)&s->h_nrm[q], (size_t)s->n * 3 * sizeof(float), hipHostMallocDefault));
@@ -1241,7 +1265,7 @@ int sb_readback_end(sb_solver *s, const float **pos_xyz_out) {
         HIP_CHECK(hipEventSynchronize(s->ev_copied[k]));
         *pos_xyz_out = s->snap_compact[k] ? s->h_cpos[k] : s->h_snap[k];
         s->snap_last_ended = k;
-        s->snap_head ^= 1; --s->snap_pending;
+        s->snap_head = (s->snap_head + 1) % sb_solver::kSnapSlots; --s->snap_pending;
         return SB_OK;
     });
 }
@@ -1257,7 +1281,7 @@ int sb_set_render_triangles(sb_solver *s, const int32_t *tri, int32_t m) {
         s->render_tri.assign(tri, tri + 3 * (size_t)m);
         s->render_dirty = true;
         if (m == 0) s->render_set_only = false;
-        s->snap_has_normals[0] = s->snap_has_normals[1] = false;
+        for (bool &b : s->snap_has_normals) b = false;
         return SB_OK;
     });
 }
@@ -1336,6 +1360,22 @@ int sb_get_stats(sb_solver *s, sb_stats *out) {
         if (slot == 1) out->halo_particles_t1 = cnt; else out->halo_particles_global += cnt;   // global colours and T2 layers
     }
     out->device_bytes = s->dev_bytes;
+    {   // compulsory bytes per launch (see softbody.h): particle state + the tables a launch reads
+        const int64_t mb = s->w_palette ? 1 : 4;     // inverse mass: palette index or float
+        auto tables = [&](const DevTiling &D) { return D.stream_bytes + (int64_t)D.n_tiles * (int64_t)sizeof(sbk::TileDesc) + (int64_t)D.runs_overflow.count * 8; };
+        for (int tl = 0; tl < 2; ++tl) {
+            const DevTiling &D = s->tiling[tl];
+            if (!D.n_tiles) continue;
+            out->launch_bytes[tl] = D.staged_particles * (12 + mb + 12 + 12 + 12) + tables(D);   // x, w, xprev in; x, xprev out
+        }
+        const DevTiling &D0 = s->tiling[0];
+        if (D0.n_tiles) {
+            out->launch_bytes[2] = D0.staged_particles * (12 + mb + 12 + 12 + 12) + tables(D0);  // x, w, v in; x, xprev out
+            out->launch_bytes[3] = D0.staged_particles * (12 + mb + 12 + 12 + 12) + tables(D0);  // x, w, xprev in; x, v out
+        }
+        const DevTiling &D2 = s->tiling[2];
+        if (D2.n_tiles) out->launch_bytes[4] = D2.staged_particles * (4 + 12 + mb + 12) + tables(D2);
+    }
     return SB_OK;
 }
 

@@ -33,7 +33,8 @@ class SbStats(C.Structure):
                 ("n_tiles", C.c_int64 * 2), ("tile_constraints", C.c_int64 * 2), ("constraints_in_tiles", C.c_int64),
                 ("constraints_in_global", C.c_int64), ("halo_particles_t1", C.c_int64),
                 ("halo_particles_global", C.c_int64), ("device_bytes", C.c_int64),
-                ("n_t2_layers", C.c_int64), ("n_t2_tiles", C.c_int64), ("t2_constraints", C.c_int64)]
+                ("n_t2_layers", C.c_int64), ("n_t2_tiles", C.c_int64), ("t2_constraints", C.c_int64),
+                ("launch_bytes", C.c_int64 * 5)]
 
     def as_dict(self):
         out = {}

@@ -1,0 +1,114 @@
+"""All ranks of a spatially split solver inside ONE process on ONE GPU, with the host as the wire (test infrastructure).
+
+A GPU box has one device, RCCL refuses two ranks on one device, and at most 6 processes may use the card: the 8-rank
+configurations (BASELINE.json:10, :11) therefore run here as 8 solver handles of one process. Every rank is a complete
+`Softbody(rank=r, world=W)` -- its own plan, tiles with ghost runs, pack / unpack kernels -- driven launch by launch
+through the sb_debug_* hooks in the order `enqueue_substeps` uses (solver.hip), the ghost buffers travelling through
+host memory in the wire layout (peers in increasing rank order, one contiguous segment per peer).
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+from softbodyunity_amd import Softbody, native
+
+
+class HostedRanks:
+    def __init__(self, mesh, world, substeps, dt=0.02, part_dims=(0, 0, 0), **kw):
+        os.environ["SB_TEST_NO_COMM"] = "1"      # world > 1 without an RCCL communicator: the host carries the halo
+        self.mesh, self.world, self.S, self.dt = mesh, world, substeps, dt
+        self.ranks = []
+        try:
+            for r in range(world):
+                self.ranks.append(Softbody(mesh, substeps=substeps, fixed_delta_time=dt, device=0, rank=r, world=world,
+                                           part_dims=part_dims, unique_id=bytes(128), **kw).Start())
+        except Exception:
+            self.close()
+            raise
+        finally:
+            os.environ.pop("SB_TEST_NO_COMM", None)
+        self.L = native.lib()
+        st = self.ranks[0].stats()
+        self.G, self.n_t2, self.tiling = st["n_global_colours"], st["n_t2_layers"], st["n_tilings"] == 2
+        plans = [sb.plan() for sb in self.ranks]
+        n_slots = plans[0].halo_slot_count()
+        # counts[slot][r][p] = (particles r sends to p, particles r receives from p)
+        self.counts = []
+        for slot in range(n_slots):
+            per_rank = []
+            for p in plans:
+                sc = np.zeros(world, np.int32); rc = np.zeros(world, np.int32)
+                native.check(self.L.sb_plan_halo_counts(p._h, slot, native.ptr(sc), native.ptr(rc)))
+                per_rank.append((sc, rc))
+            for a in range(world):
+                for b in range(world):
+                    assert per_rank[a][0][b] == per_rank[b][1][a], "send and receive counts of a halo slot differ between two ranks"
+            self.counts.append(per_rank)
+        self.exchanged_floats = 0
+
+    def close(self):
+        for sb in self.ranks:
+            sb.OnDestroy()
+        self.ranks = []
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        self.close()
+
+    def exchange(self, slot):
+        fl = 6 if slot == 1 else 3
+        W = self.world
+        sent = []
+        for r, sb in enumerate(self.ranks):
+            ns = int(self.counts[slot][r][0].sum())
+            buf = np.zeros(max(ns * fl, 1), np.float32)
+            cnt = C.c_int64()
+            native.check(self.L.sb_debug_halo_pack(sb._h, slot, native.ptr(buf), buf.size, C.byref(cnt)))
+            assert cnt.value == ns * fl
+            off = np.concatenate([[0], np.cumsum(self.counts[slot][r][0])]) * fl      # segment of peer p in r's send buffer
+            sent.append((buf, off))
+        for r, sb in enumerate(self.ranks):
+            segs = []
+            for p in range(W):
+                if self.counts[slot][r][1][p]:
+                    buf, off = sent[p]
+                    segs.append(buf[off[r]:off[r + 1]])
+            recv = np.concatenate(segs) if segs else np.zeros(0, np.float32)
+            assert recv.size == int(self.counts[slot][r][1].sum()) * fl
+            self.exchanged_floats += recv.size
+            native.check(self.L.sb_debug_halo_unpack(sb._h, slot, native.ptr(recv) if recv.size else None, recv.size))
+
+    def launch(self, it, gcolour):
+        for sb in self.ranks:
+            native.check(self.L.sb_debug_launch(sb._h, self.dt, self.S, it, gcolour))
+
+    def tick(self):
+        S = self.S
+        for it in range(S + 1):
+            if self.tiling and (it & 1):
+                self.exchange(1)
+            self.launch(it, -1)
+            if it == S:
+                break
+            for ly in range(self.n_t2):
+                self.exchange(2 + self.G + ly)
+                self.launch(it, -2 - ly)
+            for gc in range(self.G):
+                self.exchange(2 + gc)
+                self.launch(it, gc)
+
+    def merged_state(self):
+        n = self.mesh.n
+        x = np.zeros((n, 3), np.float32); v = np.zeros((n, 3), np.float32); cover = np.zeros(n, np.int32)
+        ghosts = 0
+        for r, sb in enumerate(self.ranks):
+            own = sb.owner() == r
+            xr = sb.get_positions(); vr = sb.get_velocities()
+            x[own] = xr[own]; v[own] = vr[own]; cover += own
+            st = sb.stats()
+            ghosts += st["n_particles_local"] - st["n_particles_owned"]
+        assert np.all(cover == 1), "the ranks' owned sets must partition the particles"
+        return x, v, ghosts

@@ -44,12 +44,12 @@ def test_struct_layouts_match_header():
     assert C.sizeof(native.SbDesc) == 48
     assert C.sizeof(native.SbPlanOpts) == 24
     assert C.sizeof(native.SbPhaseInfo) == 48
-    assert C.sizeof(native.SbStats) == 8 * 2 + 8 * 3 + 4 * 2 + 8 * 4 + 8 * 5 + 8 * 3
+    assert C.sizeof(native.SbStats) == 8 * 2 + 8 * 3 + 4 * 2 + 8 * 4 + 8 * 5 + 8 * 3 + 8 * 5
 
 
 def test_loads_without_gpu_and_fails_loudly():
     L = native.lib()
-    assert L.sb_abi_version() == 3
+    assert L.sb_abi_version() == 4
     d = native.SbDesc()
     L.sb_desc_default(C.byref(d))
     assert d.world == 1 and d.tile_particles == 512 and d.use_graph == 1 and abs(d.gravity[1] + 9.81) < 1e-6

@@ -27,7 +27,52 @@ def test_bench_json_line_contract():
     for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
         assert k in r, k
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    # frac is a physical fraction of the HBM peak (traffic / time / peak); the algorithmic-bytes figure lives beside it
+    assert 0.0 < r["frac"] <= 1.0 and r["frac_algorithmic"] > 0 and r["reuse_factor"] > 1.0
+    assert r["model_bytes_per_launch"] > 0 and (r["traffic"] is None or abs(r["traffic"] / r["model_bytes_per_launch"] - 1) <= 0.03)
+    p = j["config"]["parity"]
+    assert p["ticks"] == 4 and p["finite"] is True
+    assert p["small"]["bitwise"] is True and p["small"]["rel"] == 0.0 and p["small"]["ticks"] == 4
+    assert p["golden"]["expected"] is None          # no golden entry for a 32^3 cube
     c = j["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
     assert c["kind"] == "port" and c["cores"] == 1 and c["value"] > 0 and j["config"]["finite"] is True
+
+
+@pytest.mark.gpu
+def test_bench_checks_itself_against_the_golden_checksums_and_the_live_oracle():
+    # config 2 (BASELINE.json:8): the state the timed run ends with must hash to the oracle's golden checksum for that
+    # tick count, and the live leg (solver reset, oracle on the same mesh) must agree bit for bit
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "64", "--steps", "6", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.strip()][0])
+    p = j["config"]["parity"]
+    assert p["golden"]["bitwise"] is True and p["golden"]["schedule_matches"] is True and p["golden"]["n"] == 64 ** 3
+    assert p["live"]["bitwise"] is True and p["live"]["n"] == 64 ** 3 and p["live"]["ticks"] >= 2
+    assert p["small"]["bitwise"] is True
+    assert "64^3" in j["cpu_baseline"]["sample"]
+
+
+def test_traffic_file_entries_match_the_compulsory_model_of_a_host_built_plan():
+    # profiles/hbm_traffic.json must not go stale: every entry is within 3 % of 49 B per particle + the tile streams
+    # (4 B per dictionary-coded slot) + 128 B per tile of the plan the host-only planner builds for that configuration
+    import re
+    from softbodyunity_amd import native
+    from softbodyunity_amd.mesh import jelly_cube
+    tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
+    for key, ent in tj.items():
+        n, tile, gpus = (int(g) for g in re.match(r"n(\d+)_tile(-?\d+)_gpus(\d+)", key).groups())
+        if gpus != 1:
+            continue
+        mesh = jelly_cube(n)
+        plan = native.Plan.build(mesh.rest_pos, mesh.dist_ij, tile_particles=tile)
+        for slot in ("0", "1"):
+            if slot not in ent:
+                continue
+            ph = [p for p in plan.phases(int(slot)) if p["kind"] == 1][0]
+            slots = ph["order_end"] - ph["order_begin"]
+            tiles = ph["task_end"] - ph["task_begin"]
+            model = 49.0 * mesh.n + 4.0 * slots + 128.0 * tiles
+            assert abs(ent[slot] / model - 1) <= 0.03, (key, slot, ent[slot], model)

@@ -108,6 +108,22 @@ def test_changing_dt_and_substeps_between_ticks(oracle_mod):
     assert rel <= TOL and bit
 
 
+def test_graph_cache_evicts_when_the_host_varies_substeps(oracle_mod):
+    # one hipGraphExec per (substeps, tick flavour), at most 8 kept (least recently used goes): more distinct substep
+    # counts than that, revisited, must still give the oracle's bits
+    mesh = jelly_cube(10)
+    sb = Softbody(mesh).Start()
+    try:
+        o = make_oracle(oracle_mod, mesh, sb.plan())
+        for S in list(range(1, 14)) + [2, 4, 2, 13, 1, 8, 8]:
+            sb.step(0.02, S); o.step(0.02, S)
+        x = sb.get_positions(); v = sb.get_velocities()
+    finally:
+        sb.OnDestroy()
+    rel, mabs, bit = oracle_mod.parity_error(x, o.x, mesh.pos)
+    assert rel <= TOL and bit and np.array_equal(v.view(np.uint32), o.v.view(np.uint32))
+
+
 def test_state_round_trip(oracle_mod):
     # download -> upload -> step == step
     mesh = jelly_cube(12)
@@ -237,6 +253,17 @@ def test_async_readback_matches_blocking_readback():
             assert np.array_equal(got.view(np.uint32), want.view(np.uint32))
         with pytest.raises(native.SoftbodyError):
             sb.readback_end()
+        # pointer lifetime (softbody.h): a snapshot handed out by readback_end stays intact through the NEXT
+        # readback_begin even when another snapshot was pending at the time (three buffers for two pending snapshots)
+        sb.set_state(mesh.pos, mesh.vel)
+        sb.step(); sb.readback_begin()
+        sb.step(); sb.readback_begin()
+        held = sb.readback_end()                        # view of the plugin's pinned buffer, not a copy
+        sb.step(); sb.readback_begin()                  # must not land in the buffer `held` points at
+        sb.synchronize()
+        second = sb.readback_end().copy(); third = sb.readback_end().copy()
+        assert np.array_equal(held.view(np.uint32), ref[0].view(np.uint32))
+        assert np.array_equal(second.view(np.uint32), ref[1].view(np.uint32)) and np.array_equal(third.view(np.uint32), ref[2].view(np.uint32))
     finally:
         sb.OnDestroy()
 

@@ -4,7 +4,7 @@ ARGS="$1"; shift
 for round in 1 2; do
   for v in "$@"; do
     name=${v:-product}
-    SB_LIB_VARIANT=$v python bench.py $ARGS --no-cpu-baseline > gpurun_out/ab_${name}_r${round}.json 2> gpurun_out/ab_${name}_r${round}.err
+    SB_LIB_VARIANT=$v python bench.py $ARGS --no-cpu-baseline --no-parity --allow-stale-traffic > gpurun_out/ab_${name}_r${round}.json 2> gpurun_out/ab_${name}_r${round}.err
     python tools/show_bench.py gpurun_out/ab_${name}_r${round}.json | head -3
   done
 done

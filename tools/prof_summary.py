@@ -86,6 +86,14 @@ def main():
                 if k == mid[-1]: traffic["1"] = b
         tj_path = os.path.join(out_dir, "hbm_traffic.json")
         tj = json.load(open(tj_path)) if os.path.exists(tj_path) else {}
+        # which sources the counters were measured on: bench.py reports it beside the figure, and checks the figure against
+        # the compulsory-bytes model of the build it runs (a stale entry fails the bench, it does not slip through)
+        import hashlib
+        h = hashlib.sha256()
+        for f in ("softbodyunity_amd/csrc/kernels.hip.hpp", "softbodyunity_amd/csrc/solver.hip", "softbodyunity_amd/csrc/plan.cpp"):
+            h.update(open(os.path.join(ROOT, f), "rb").read())
+        traffic["meta"] = {"round": args.round, "csrc_sha16": h.hexdigest()[:16],
+                           "counters": "FETCH_SIZE, WRITE_SIZE (separate rocprofv3 --pmc passes); bytes = 2*F*1024 + W*1024"}
         tj[args.key] = traffic
         json.dump(tj, open(tj_path, "w"), indent=1, sort_keys=True)
     open(os.path.join(out_dir, f"{args.round}_{args.key}_summary.md"), "w").write("\n".join(md) + "\n")
