@@ -5,8 +5,9 @@
 //                  asyncReadback: sb_readback_begin/end + GPU vertex normals instead (one tick of latency, no stall)
 // OnDestroy()   -> sb_destroy
 //
-// `useGpu = false` runs the same tick on the CPU through SoftbodyCpuSolver (the C# restatement of
-// SPEC.md, in the schedule the plugin publishes) — the "reference C# CPU FixedUpdate path" that
+// `useGpu = false` never creates a solver handle and needs no GPU: the schedule comes from the host-only
+// planner (sb_plan_build / sb_plan_get_order / sb_plan_destroy) and the tick runs in SoftbodyCpuSolver (the C#
+// restatement of SPEC.md) — the "reference C# CPU FixedUpdate path" that
 // BASELINE.json:5 compares against. The reference repository ships no such component
 // (/root/reference/README.md:1 is its only line); names follow Unity conventions.
 //
@@ -65,6 +66,36 @@ namespace SoftbodyMI355X
             if (velocities == null) velocities = new Vector3[n];
             if (inverseMass == null) { inverseMass = new float[n]; for (int i = 0; i < n; ++i) inverseMass[i] = 1f; }
 
+            if (!useGpu)
+            {
+                // CPU path (BASELINE.json:7, "CPU C# FixedUpdate only ... no GPU"): no solver handle, no device. The schedule
+                // comes from the host-only planner entry points (sb_plan_build works on a machine without a GPU); the tick
+                // itself is SoftbodyCpuSolver walking the order that planner publishes (SPEC.md §3).
+                var opts = new SbPlanOpts { rank = 0, world = 1, tileParticles = tileParticles };
+                IntPtr plan = IntPtr.Zero;
+                Vector3[] rest = restPositions ?? positions;
+                int md = distanceRest != null ? distanceRest.Length : 0;
+                int mv = volumeRest != null ? volumeRest.Length : 0;
+                int mb = bendingRestCosSin != null ? bendingRestCosSin.Length / 2 : 0;
+                Pin(rest, r => Pin(distanceIJ ?? new int[0], dI => Pin(volumeIJKL ?? new int[0], vI => Pin(bendingIJKL ?? new int[0], bI =>
+                    SoftbodyNative.Check(SoftbodyNative.sb_plan_build(r, n, dI, md, vI, mv, bI, mb, ref opts, out plan), "sb_plan_build")))));
+                try
+                {
+                    long m = SoftbodyNative.sb_plan_order_count(plan);
+                    var type = new byte[2][]; var id = new int[2][];
+                    for (int parity = 0; parity < 2; ++parity)
+                    {
+                        type[parity] = new byte[m]; id[parity] = new int[m];
+                        int par = parity;
+                        Pin(type[par], t => Pin(id[par], i => SoftbodyNative.Check(SoftbodyNative.sb_plan_get_order(plan, par, t, i), "sb_plan_get_order")));
+                    }
+                    cpu = new SoftbodyCpuSolver(this, type, id);
+                }
+                finally { SoftbodyNative.sb_plan_destroy(plan); }
+                posPin = GCHandle.Alloc(positions, GCHandleType.Pinned);
+                return;
+            }
+
             var d = new SbDesc();
             SoftbodyNative.sb_desc_default(ref d);
             d.device = device; d.rank = 0; d.world = 1;
@@ -89,23 +120,8 @@ namespace SoftbodyMI355X
             if (groundPlane)
                 SoftbodyNative.Check(SoftbodyNative.sb_set_ground_plane(handle, groundNormal.x, groundNormal.y, groundNormal.z, groundOffset, 1), "sb_set_ground_plane");
             SoftbodyNative.Check(SoftbodyNative.sb_finalize(handle), "sb_finalize");
-
-            if (!useGpu)
-            {
-                // CPU path walks the order the plugin's planner published (SPEC.md §3)
-                SoftbodyNative.Check(SoftbodyNative.sb_get_plan(handle, out IntPtr plan), "sb_get_plan");
-                long m = SoftbodyNative.sb_plan_order_count(plan);
-                var type = new byte[2][]; var id = new int[2][];
-                for (int parity = 0; parity < 2; ++parity)
-                {
-                    type[parity] = new byte[m]; id[parity] = new int[m];
-                    int par = parity;
-                    Pin(type[par], t => Pin(id[par], i => SoftbodyNative.Check(SoftbodyNative.sb_plan_get_order(plan, par, t, i), "sb_plan_get_order")));
-                }
-                cpu = new SoftbodyCpuSolver(this, type, id);
-            }
             posPin = GCHandle.Alloc(positions, GCHandleType.Pinned);
-            if (useGpu && asyncReadback && renderTriangles != null && renderTriangles.Length >= 3)
+            if (asyncReadback && renderTriangles != null && renderTriangles.Length >= 3)
             {
                 SoftbodyNative.Check(SoftbodyNative.sb_set_render_triangles(handle, renderTriangles, renderTriangles.Length / 3), "sb_set_render_triangles");
                 normals = new Vector3[positions.Length];

@@ -203,3 +203,44 @@ def test_gpu_render_set_only_readback_is_the_compact_view_of_the_full_one(oracle
         assert sb.readback_end().shape == (mesh.n, 3)
     finally:
         sb.OnDestroy()
+
+
+def test_cfg1_cpu_component_path_needs_no_gpu(oracle_mod):
+    # BASELINE.json:7 -- 8^3 cube, 10 substeps, CPU FixedUpdate only: the component's CPU branch (csharp/Softbody.cs,
+    # useGpu = false) must not create a solver handle (sb_create fails without a gfx950); it takes the schedule from the
+    # host-only planner. Same call order through the Python mirror; the tick is the oracle (the C# solver's twin), and the
+    # result is the committed golden vector.
+    import os
+    import numpy as np
+    from softbodyunity_amd import Softbody, jelly_cube
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "cube8_s10_t5.npz"))
+    mesh = jelly_cube(8)
+    sb = Softbody(mesh, substeps=10, use_gpu=False).Start()        # works in a container without any GPU
+    try:
+        assert sb._h is None
+        sched = sb.cpu_schedule()
+        for parity in (0, 1):
+            assert np.array_equal(sched[parity][1], g[f"order_id{parity}"])
+        with pytest.raises(RuntimeError):
+            sb.FixedUpdate()
+    finally:
+        sb.OnDestroy()
+    from helpers import make_oracle
+    o = make_oracle(oracle_mod, mesh, None)
+    for parity in (0, 1):
+        o.set_order(sched[parity][0], sched[parity][1], parity=parity)
+    for _ in range(5):
+        o.step(0.02, 10)
+    assert np.array_equal(o.x.view(np.uint32), g["x"].view(np.uint32))
+
+
+def test_csharp_cpu_branch_never_creates_a_solver():
+    # source-level check of the uncompiled C# (no toolchain in the image): inside `if (!useGpu) { ... return; }` of Start()
+    # only host-only entry points may appear
+    import os
+    import re
+    cs = open(os.path.join(os.path.dirname(os.path.dirname(__file__)), "csharp", "Softbody.cs")).read()
+    start = cs.index("if (!useGpu)")
+    branch = cs[start:cs.index("return;", start)]
+    called = set(re.findall(r"SoftbodyNative\.(sb_[a-z_]+)", branch))
+    assert called == {"sb_plan_build", "sb_plan_order_count", "sb_plan_get_order", "sb_plan_destroy"}, called
