@@ -1,14 +1,20 @@
-// plan.cpp — see plan.hpp. Pure host C++; deterministic (no hashing by address, no threads).
+// plan.cpp — see plan.hpp. Pure host C++; deterministic: no hashing by address, and the host threads it uses
+// (std::thread, SB_PLAN_THREADS, default min(hardware threads, 16)) only ever split work into pieces whose results do
+// not depend on how many threads ran them -- every rank of a partitioned solver must arrive at the same plan.
 #include "plan.hpp"
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstring>
+#include <exception>
+#include <mutex>
 #include <numeric>
 #include <stdexcept>
 #include <chrono>
 #include <cstdio>
 #include <cstdlib>
+#include <thread>
 
 namespace sbp {
 namespace {
@@ -27,6 +33,56 @@ inline void set_bit(Mask128 &m, int c) {
 }
 
 const int kVerts[3] = {2, 4, 4};
+
+int plan_threads() {
+    static const int n = [] {
+        if (const char *e = std::getenv("SB_PLAN_THREADS")) return std::max(1, std::atoi(e));
+        const unsigned hw = std::thread::hardware_concurrency();
+        return (int)std::min<unsigned>(hw ? hw : 1u, 16u);
+    }();
+    return n;
+}
+
+// Runs f(chunk, begin, end) for the chunks [k*chunk_size, min(n, (k+1)*chunk_size)) of [0, n) on the planner's
+// threads. The chunking depends on n and chunk_size only, never on the thread count, so per-chunk results (partial
+// sums, output pieces) combine to the same answer on every machine. The first exception is re-thrown after the join.
+template <class F>
+void parallel_chunks(int64_t n, int64_t chunk_size, F f) {
+    if (n <= 0) return;
+    const int64_t n_chunks = (n + chunk_size - 1) / chunk_size;
+    const int nt = (int)std::min<int64_t>(plan_threads(), n_chunks);
+    if (nt <= 1) {
+        for (int64_t c = 0; c < n_chunks; ++c) f(c, c * chunk_size, std::min(n, (c + 1) * chunk_size));
+        return;
+    }
+    std::atomic<int64_t> next{0};
+    std::exception_ptr err;
+    std::mutex err_mu;
+    auto work = [&] {
+        try {
+            for (int64_t c; (c = next.fetch_add(1)) < n_chunks;) f(c, c * chunk_size, std::min(n, (c + 1) * chunk_size));
+        } catch (...) {
+            std::lock_guard<std::mutex> g(err_mu);
+            if (!err) err = std::current_exception();
+            next.store(n_chunks);
+        }
+    };
+    std::vector<std::thread> th;
+    for (int t = 1; t < nt; ++t) th.emplace_back(work);
+    work();
+    for (auto &t : th) t.join();
+    if (err) std::rethrow_exception(err);
+}
+
+// Stable counting sort of the ids 0..n-1 by key[id] in [0, n_keys): equals std::sort by (key, id).
+void counting_sort_ids(const std::vector<int64_t> &key, int64_t n_keys, std::vector<int32_t> &out) {
+    const int32_t n = (int32_t)key.size();
+    std::vector<int32_t> cnt((size_t)n_keys + 1, 0);
+    for (int32_t p = 0; p < n; ++p) ++cnt[(size_t)key[p] + 1];
+    for (int64_t k = 0; k < n_keys; ++k) cnt[(size_t)k + 1] += cnt[(size_t)k];
+    out.resize(n);
+    for (int32_t p = 0; p < n; ++p) out[(size_t)cnt[(size_t)key[p]]++] = p;
+}
 
 struct PlanTimer {      // SB_PLAN_TIMING=1: phase times of build_plan on stderr
     bool on = std::getenv("SB_PLAN_TIMING") != nullptr;
@@ -156,6 +212,10 @@ void split_group(std::vector<int32_t> &byc, int32_t b, int32_t e, int cap, bool 
 
 }  // namespace
 
+void parallel_for_chunks(int64_t n, int64_t chunk_size, const std::function<void(int64_t, int64_t, int64_t)> &f) {
+    parallel_chunks(n, chunk_size, f);
+}
+
 void build_plan(const Input &in, const Opts &opts, Plan &P) {
     P = Plan();
     P.opts = opts;
@@ -170,35 +230,65 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
     for (int t = 0; t < 3; ++t) {
         if (C.count(t) < 0) throw std::runtime_error("negative constraint count");
         if (C.count(t) > 0 && !C.idx(t, 0)) throw std::runtime_error("null constraint array");
-        for (int64_t k = 0; k < C.count(t); ++k) {
-            const int32_t *v = C.idx(t, k);
-            for (int a = 0; a < kVerts[t]; ++a) {
-                if (v[a] < 0 || v[a] >= n) throw std::runtime_error("constraint index out of range");
-                for (int b = 0; b < a; ++b)
-                    if (v[a] == v[b]) throw std::runtime_error("constraint repeats a particle");
+        parallel_chunks(C.count(t), 1 << 20, [&](int64_t, int64_t kb, int64_t ke) {
+            for (int64_t k = kb; k < ke; ++k) {
+                const int32_t *v = C.idx(t, k);
+                for (int a = 0; a < kVerts[t]; ++a) {
+                    if (v[a] < 0 || v[a] >= n) throw std::runtime_error("constraint index out of range");
+                    for (int b = 0; b < a; ++b)
+                        if (v[a] == v[b]) throw std::runtime_error("constraint repeats a particle");
+                }
             }
-        }
+        });
     }
     timer.lap("validate");
     // ---- geometry: spacing estimate, bounding box --------------------------------------------
     double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    for (int32_t p = 0; p < n; ++p)
-        for (int a = 0; a < 3; ++a) {
-            double v = in.rest[3 * (int64_t)p + a];
-            if (!(v == v) || std::fabs(v) > 1e30) throw std::runtime_error("non-finite rest position");
-            lo[a] = std::min(lo[a], v); hi[a] = std::max(hi[a], v);
-        }
+    {
+        constexpr int64_t kChunk = 1 << 20;
+        const int64_t nch = ((int64_t)n + kChunk - 1) / kChunk;
+        std::vector<double> plo((size_t)nch * 3, 1e300), phi((size_t)nch * 3, -1e300);
+        parallel_chunks(n, kChunk, [&](int64_t c, int64_t pb, int64_t pe) {
+            double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
+            for (int64_t p = pb; p < pe; ++p)
+                for (int a = 0; a < 3; ++a) {
+                    double v = in.rest[3 * p + a];
+                    if (!(v == v) || std::fabs(v) > 1e30) throw std::runtime_error("non-finite rest position");
+                    l[a] = std::min(l[a], v); h[a] = std::max(h[a], v);
+                }
+            for (int a = 0; a < 3; ++a) { plo[(size_t)c * 3 + a] = l[a]; phi[(size_t)c * 3 + a] = h[a]; }
+        });
+        for (int64_t c = 0; c < nch; ++c)
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], plo[(size_t)c * 3 + a]); hi[a] = std::max(hi[a], phi[(size_t)c * 3 + a]); }
+    }
     double ell = 0;
     {
+        // mean spring length: partial sums over fixed chunks of the constraint list, added in chunk order (the same
+        // value whatever the thread count)
         double acc = 0; int64_t cnt = 0;
-        auto edge = [&](int32_t i, int32_t j) {
-            double s = 0;
-            for (int a = 0; a < 3; ++a) { double d = (double)in.rest[3 * (int64_t)i + a] - in.rest[3 * (int64_t)j + a]; s += d * d; }
-            acc += std::sqrt(s); ++cnt;
+        auto mean_edges = [&](const int32_t *idx, int nv, int64_t m_all) {
+            // a sample of about a million evenly spaced constraints is plenty for a length scale (every one below 2^21)
+            const int64_t stride = std::max<int64_t>(1, m_all >> 20), m = (m_all + stride - 1) / stride;
+            constexpr int64_t kChunk = 1 << 16;
+            const int64_t nch = (m + kChunk - 1) / kChunk;
+            std::vector<double> part((size_t)nch, 0.0);
+            parallel_chunks(m, kChunk, [&](int64_t c, int64_t kb, int64_t ke) {
+                double a2 = 0;
+                for (int64_t ks = kb; ks < ke; ++ks) {
+                    const int64_t k = ks * stride;
+                    const int32_t i = idx[nv * k], j = idx[nv * k + 1];
+                    double s = 0;
+                    for (int a = 0; a < 3; ++a) { double d = (double)in.rest[3 * (int64_t)i + a] - in.rest[3 * (int64_t)j + a]; s += d * d; }
+                    a2 += std::sqrt(s);
+                }
+                part[(size_t)c] = a2;
+            });
+            for (double v : part) acc += v;
+            cnt += m;
         };
-        for (int64_t k = 0; k < in.m_d; ++k) edge(in.dist_ij[2 * k], in.dist_ij[2 * k + 1]);
-        if (cnt == 0) for (int64_t k = 0; k < in.m_v; ++k) edge(in.vol[4 * k], in.vol[4 * k + 1]);
-        if (cnt == 0) for (int64_t k = 0; k < in.m_b; ++k) edge(in.bend[4 * k], in.bend[4 * k + 1]);
+        mean_edges(in.dist_ij, 2, in.m_d);
+        if (cnt == 0) mean_edges(in.vol, 4, in.m_v);
+        if (cnt == 0) mean_edges(in.bend, 4, in.m_b);
         if (cnt > 0) ell = acc / cnt;
         if (!(ell > 0)) {
             double vol = 1; for (int a = 0; a < 3; ++a) vol *= std::max(hi[a] - lo[a], 1e-6);
@@ -236,18 +326,21 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
     const double shift_frac = (double)shift_units / kk;
     std::vector<int64_t> cell(n), scell(n);
     P.owner_of_old.resize(n);
-    for (int32_t p = 0; p < n; ++p) {
-        int c[3], s[3], blk[3];
-        for (int a = 0; a < 3; ++a) {
-            double r = (in.rest[3 * (int64_t)p + a] - org[a]) / cs;
-            c[a] = std::min(std::max((int)std::floor(r), 0), nc[a] - 1);
-            s[a] = std::min(std::max((int)std::floor(r - shift_frac) + 1, 0), nc[a]);
-            blk[a] = (int)((int64_t)c[a] * P.dims[a] / nc[a]);
+    parallel_chunks(n, 1 << 18, [&](int64_t, int64_t pb, int64_t pe) {
+        for (int64_t p = pb; p < pe; ++p) {
+            int c[3], s[3], blk[3];
+            for (int a = 0; a < 3; ++a) {
+                double r = (in.rest[3 * p + a] - org[a]) / cs;
+                c[a] = std::min(std::max((int)std::floor(r), 0), nc[a] - 1);
+                s[a] = std::min(std::max((int)std::floor(r - shift_frac) + 1, 0), nc[a]);
+                blk[a] = (int)((int64_t)c[a] * P.dims[a] / nc[a]);
+            }
+            cell[p] = ((int64_t)c[2] * nc[1] + c[1]) * nc[0] + c[0];
+            scell[p] = ((int64_t)s[2] * (nc[1] + 1) + s[1]) * (nc[0] + 1) + s[0];
+            P.owner_of_old[p] = (blk[2] * P.dims[1] + blk[1]) * P.dims[0] + blk[0];
         }
-        cell[p] = ((int64_t)c[2] * nc[1] + c[1]) * nc[0] + c[0];
-        scell[p] = ((int64_t)s[2] * (nc[1] + 1) + s[1]) * (nc[0] + 1) + s[0];
-        P.owner_of_old[p] = (blk[2] * P.dims[1] + blk[1]) * P.dims[0] + blk[0];
-    }
+    });
+    const int64_t n_cells = (int64_t)nc[0] * nc[1] * nc[2], n_scells = (int64_t)(nc[0] + 1) * (nc[1] + 1) * (nc[2] + 1);
     const int cap = tiling ? std::min(kMaxTileLocal, std::max(2 * target, 64)) : 512;
 
     timer.lap("geometry + cells");
@@ -255,12 +348,17 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
     std::vector<int32_t> t1_of_old(n, 0);
     int32_t n_t1 = 0;
     if (tiling) {
-        std::vector<int32_t> bys(n);
-        std::iota(bys.begin(), bys.end(), 0);
-        std::sort(bys.begin(), bys.end(), [&](int32_t a, int32_t b) {
-            if (scell[a] != scell[b]) return scell[a] < scell[b];
-            return a < b;
-        });
+        std::vector<int32_t> bys;
+        if (n_scells <= 8 * (int64_t)n + 4096) {
+            counting_sort_ids(scell, n_scells, bys);       // = sort by (shifted cell, id)
+        } else {
+            bys.resize(n);
+            std::iota(bys.begin(), bys.end(), 0);
+            std::sort(bys.begin(), bys.end(), [&](int32_t a, int32_t b) {
+                if (scell[a] != scell[b]) return scell[a] < scell[b];
+                return a < b;
+            });
+        }
         std::vector<int32_t> begins;
         for (int32_t b = 0; b < n;) {
             int32_t e = b + 1;
@@ -275,16 +373,25 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
     }
     timer.lap("tiling T1");
     // ---- tiling T0 (aligned cells, grouped by owner) ---------------------------------------------
-    std::vector<int32_t> byc(n);
-    std::iota(byc.begin(), byc.end(), 0);
-    if (tiling)
-        std::sort(byc.begin(), byc.end(), [&](int32_t a, int32_t b) {
-            if (P.owner_of_old[a] != P.owner_of_old[b]) return P.owner_of_old[a] < P.owner_of_old[b];
-            if (cell[a] != cell[b]) return cell[a] < cell[b];
-            return a < b;
+    std::vector<int32_t> byc;
+    if (tiling && (int64_t)opts.world * n_cells <= 8 * (int64_t)n + 4096) {
+        std::vector<int64_t> key(n);                       // = sort by (owner, cell, id)
+        parallel_chunks(n, 1 << 20, [&](int64_t, int64_t pb, int64_t pe) {
+            for (int64_t p = pb; p < pe; ++p) key[p] = (int64_t)P.owner_of_old[p] * n_cells + cell[p];
         });
-    else
-        std::stable_sort(byc.begin(), byc.end(), [&](int32_t a, int32_t b) { return P.owner_of_old[a] < P.owner_of_old[b]; });
+        counting_sort_ids(key, (int64_t)opts.world * n_cells, byc);
+    } else {
+        byc.resize(n);
+        std::iota(byc.begin(), byc.end(), 0);
+        if (tiling)
+            std::sort(byc.begin(), byc.end(), [&](int32_t a, int32_t b) {
+                if (P.owner_of_old[a] != P.owner_of_old[b]) return P.owner_of_old[a] < P.owner_of_old[b];
+                if (cell[a] != cell[b]) return cell[a] < cell[b];
+                return a < b;
+            });
+        else
+            std::stable_sort(byc.begin(), byc.end(), [&](int32_t a, int32_t b) { return P.owner_of_old[a] < P.owner_of_old[b]; });
+    }
     std::vector<int32_t> t0_begin;
     for (int32_t b = 0; b < n;) {
         int32_t e = b + 1;
@@ -298,20 +405,24 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
     t0_begin.push_back(n);
     const int32_t n_t0 = (int32_t)t0_begin.size() - 1;
     std::vector<int32_t> t0_of_old(n);
-    for (int32_t c = 0; c < n_t0; ++c) {
-        // final order inside a T0 tile: by T1 tile, then original id -> T0∩T1 pieces are contiguous
-        if (tiling)
-            std::sort(byc.begin() + t0_begin[c], byc.begin() + t0_begin[c + 1], [&](int32_t a, int32_t b) {
-                if (t1_of_old[a] != t1_of_old[b]) return t1_of_old[a] < t1_of_old[b];
-                return a < b;
-            });
-        else
-            std::sort(byc.begin() + t0_begin[c], byc.begin() + t0_begin[c + 1]);
-        for (int32_t q = t0_begin[c]; q < t0_begin[c + 1]; ++q) t0_of_old[byc[q]] = c;
-    }
+    parallel_chunks(n_t0, 256, [&](int64_t, int64_t cb, int64_t ce) {
+        for (int64_t c = cb; c < ce; ++c) {
+            // final order inside a T0 tile: by T1 tile, then original id -> T0∩T1 pieces are contiguous
+            if (tiling)
+                std::sort(byc.begin() + t0_begin[c], byc.begin() + t0_begin[c + 1], [&](int32_t a, int32_t b) {
+                    if (t1_of_old[a] != t1_of_old[b]) return t1_of_old[a] < t1_of_old[b];
+                    return a < b;
+                });
+            else
+                std::sort(byc.begin() + t0_begin[c], byc.begin() + t0_begin[c + 1]);
+            for (int32_t q = t0_begin[c]; q < t0_begin[c + 1]; ++q) t0_of_old[byc[q]] = (int32_t)c;
+        }
+    });
     P.old_of_new = byc;
     P.new_of_old.resize(n);
-    for (int32_t q = 0; q < n; ++q) P.new_of_old[byc[q]] = q;
+    parallel_chunks(n, 1 << 20, [&](int64_t, int64_t qb, int64_t qe) {
+        for (int64_t q = qb; q < qe; ++q) P.new_of_old[byc[q]] = (int32_t)q;
+    });
 
     timer.lap("tiling T0");
     // ---- tiles: runs and tile-local indices ------------------------------------------------------
@@ -321,16 +432,19 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         Tiling &A = P.T[0];
         A.tiles.resize(n_t0);
         lidx[0].resize(n);
-        for (int32_t c = 0; c < n_t0; ++c) {
-            Tile &t = A.tiles[c];
-            t = Tile();
-            t.owner = P.owner_of_old[byc[t0_begin[c]]];
-            t.run_begin = (int32_t)A.runs.size(); t.run_count = 1;
-            t.n_local = t0_begin[c + 1] - t0_begin[c];
-            A.runs.push_back({t0_begin[c], t.n_local});
-            for (int32_t q = t0_begin[c]; q < t0_begin[c + 1]; ++q) lidx[0][q] = q - t0_begin[c];
-            A.max_local = std::max(A.max_local, t.n_local);
-        }
+        A.runs.resize(n_t0);
+        parallel_chunks(n_t0, 1024, [&](int64_t, int64_t cb, int64_t ce) {
+            for (int64_t c = cb; c < ce; ++c) {
+                Tile &t = A.tiles[c];
+                t = Tile();
+                t.owner = P.owner_of_old[byc[t0_begin[c]]];
+                t.run_begin = (int32_t)c; t.run_count = 1;
+                t.n_local = t0_begin[c + 1] - t0_begin[c];
+                A.runs[c] = {t0_begin[c], t.n_local};
+                for (int32_t q = t0_begin[c]; q < t0_begin[c + 1]; ++q) lidx[0][q] = q - t0_begin[c];
+            }
+        });
+        for (int32_t c = 0; c < n_t0; ++c) A.max_local = std::max(A.max_local, A.tiles[c].n_local);
         A.max_runs = 1;
     }
     if (tiling) {
@@ -340,11 +454,24 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         // segments = maximal ranges of the new numbering with equal (T0 tile, T1 tile)
         struct Seg { int32_t t1, start, len; };
         std::vector<Seg> segs;
-        for (int32_t q = 0; q < n;) {
-            int32_t e = q + 1;
-            while (e < n && t1_of_old[byc[e]] == t1_of_old[byc[q]] && t0_of_old[byc[e]] == t0_of_old[byc[q]]) ++e;
-            segs.push_back({t1_of_old[byc[q]], q, e - q});
-            q = e;
+        {
+            constexpr int64_t kTilesPerChunk = 512;
+            const int64_t nch = ((int64_t)n_t0 + kTilesPerChunk - 1) / kTilesPerChunk;
+            std::vector<std::vector<Seg>> part((size_t)nch);
+            parallel_chunks(n_t0, kTilesPerChunk, [&](int64_t ch, int64_t cb, int64_t ce) {
+                std::vector<Seg> &out = part[(size_t)ch];
+                for (int64_t c = cb; c < ce; ++c)           // a segment never spans two T0 tiles
+                    for (int32_t q = t0_begin[c]; q < t0_begin[c + 1];) {
+                        int32_t e = q + 1;
+                        while (e < t0_begin[c + 1] && t1_of_old[byc[e]] == t1_of_old[byc[q]]) ++e;
+                        out.push_back({t1_of_old[byc[q]], q, e - q});
+                        q = e;
+                    }
+            });
+            size_t total = 0;
+            for (auto &v : part) total += v.size();
+            segs.reserve(total);
+            for (auto &v : part) segs.insert(segs.end(), v.begin(), v.end());
         }
         std::stable_sort(segs.begin(), segs.end(), [](const Seg &a, const Seg &b) { return a.t1 < b.t1; });
         size_t si = 0;
@@ -376,12 +503,14 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
     for (int t = 0; t < 3; ++t) {
         cls[t].assign(C.count(t), 0);
         if (!tiling) continue;
-        for (int64_t k = 0; k < C.count(t); ++k) {
-            const int32_t *v = C.idx(t, k);
-            bool s0 = true, s1 = true;
-            for (int a = 1; a < kVerts[t]; ++a) { s0 &= t0_of_old[v[a]] == t0_of_old[v[0]]; s1 &= t1_of_old[v[a]] == t1_of_old[v[0]]; }
-            cls[t][k] = (uint8_t)((s0 ? 1 : 0) | (s1 ? 2 : 0));
-        }
+        parallel_chunks(C.count(t), 1 << 20, [&](int64_t, int64_t kb, int64_t ke) {
+            for (int64_t k = kb; k < ke; ++k) {
+                const int32_t *v = C.idx(t, k);
+                bool s0 = true, s1 = true;
+                for (int a = 1; a < kVerts[t]; ++a) { s0 &= t0_of_old[v[a]] == t0_of_old[v[0]]; s1 &= t1_of_old[v[a]] == t1_of_old[v[0]]; }
+                cls[t][k] = (uint8_t)((s0 ? 1 : 0) | (s1 ? 2 : 0));
+            }
+        });
     }
 
     timer.lap("classify");
@@ -394,45 +523,53 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
     // side is a set of complete matchings; on irregular meshes it halves the constraint degree of every particle
     // per side, i.e. the number of rounds per tile.
     std::vector<uint8_t> own[3];
-    std::vector<Mask128> used((size_t)kMaxTileLocal);
-    std::vector<int> col_tmp;
-    std::vector<int32_t> lv;
-    for (int t = 0; t < 3; ++t) {
-        own[t].assign(C.count(t), 2);
-        if (!tiling) continue;
-        const int nv = kVerts[t];
-        const int64_t M = C.count(t);
-        if (M == 0) continue;
-        const int n_buckets = t == 0 ? 3 : 1;
-        std::vector<uint8_t> bucket(M, 0);
-        std::vector<int8_t> label(M, -2);        // -2: not tiled (global), -1: free, 0/1: assigned
-        for (int64_t k = 0; k < M; ++k) {
-            const uint8_t c = cls[t][k];
-            if (c == 0) continue;
-            label[k] = c == 3 ? -1 : (c == 1 ? 0 : 1);
-            if (t == 0) {
-                const int32_t *v = C.idx(t, k);
-                double best = -1; int ba = 0;
-                for (int a = 0; a < 3; ++a) {
-                    double d = std::fabs((double)in.rest[3 * (int64_t)v[0] + a] - in.rest[3 * (int64_t)v[1] + a]);
-                    if (d > best * (1 + 1e-9)) { best = d; ba = a; }
+    {
+        std::vector<std::vector<uint8_t>> bucket(3);
+        std::vector<std::vector<int8_t>> label(3);      // -2: not tiled (global), -1: free, 0/1: assigned
+        struct SplitTask { int t, b; };
+        std::vector<SplitTask> split_tasks;
+        for (int t = 0; t < 3; ++t) {
+            own[t].assign(C.count(t), 2);
+            if (!tiling) continue;
+            const int64_t M = C.count(t);
+            if (M == 0) continue;
+            bucket[t].assign(M, 0);
+            label[t].assign(M, -2);
+            parallel_chunks(M, 1 << 20, [&](int64_t, int64_t kb, int64_t ke) {
+                for (int64_t k = kb; k < ke; ++k) {
+                    const uint8_t c = cls[t][k];
+                    if (c == 0) continue;
+                    label[t][k] = c == 3 ? -1 : (c == 1 ? 0 : 1);
+                    if (t == 0) {
+                        const int32_t *v = C.idx(t, k);
+                        double best = -1; int ba = 0;
+                        for (int a = 0; a < 3; ++a) {
+                            double d = std::fabs((double)in.rest[3 * (int64_t)v[0] + a] - in.rest[3 * (int64_t)v[1] + a]);
+                            if (d > best * (1 + 1e-9)) { best = d; ba = a; }
+                        }
+                        bucket[t][k] = (uint8_t)ba;
+                    }
                 }
-                bucket[k] = (uint8_t)ba;
-            }
+            });
+            for (int b = 0; b < (t == 0 ? 3 : 1); ++b) split_tasks.push_back({t, b});
         }
-        std::vector<int64_t> inc_off((size_t)n + 1);
-        std::vector<int32_t> inc, queue;
-        for (int b = 0; b < n_buckets; ++b) {
-            std::fill(inc_off.begin(), inc_off.end(), 0);
-            for (int64_t k = 0; k < M; ++k) if (label[k] != -2 && bucket[k] == b) for (int a = 0; a < nv; ++a) ++inc_off[C.idx(t, k)[a] + 1];
+        // the (type, bucket) classes are independent of each other: each labels only its own constraints
+        parallel_chunks((int64_t)split_tasks.size(), 1, [&](int64_t ti, int64_t, int64_t) {
+            const int t = split_tasks[(size_t)ti].t, b = split_tasks[(size_t)ti].b;
+            const int nv = kVerts[t];
+            const int64_t M = C.count(t);
+            std::vector<int8_t> &lab = label[t];
+            const std::vector<uint8_t> &bk = bucket[t];
+            std::vector<int64_t> inc_off((size_t)n + 1, 0);
+            std::vector<int32_t> inc, queue;
+            for (int64_t k = 0; k < M; ++k) if (lab[k] != -2 && bk[k] == b) for (int a = 0; a < nv; ++a) ++inc_off[C.idx(t, k)[a] + 1];
             for (int32_t p = 0; p < n; ++p) inc_off[p + 1] += inc_off[p];
             inc.resize(inc_off[n]);
             {
                 std::vector<int64_t> cur(inc_off.begin(), inc_off.end() - 1);
-                for (int64_t k = 0; k < M; ++k) if (label[k] != -2 && bucket[k] == b) for (int a = 0; a < nv; ++a) inc[cur[C.idx(t, k)[a]]++] = (int32_t)k;
+                for (int64_t k = 0; k < M; ++k) if (lab[k] != -2 && bk[k] == b) for (int a = 0; a < nv; ++a) inc[cur[C.idx(t, k)[a]]++] = (int32_t)k;
             }
-            queue.clear();
-            for (int64_t k = 0; k < M; ++k) if (label[k] >= 0 && bucket[k] == b) queue.push_back((int32_t)k);
+            for (int64_t k = 0; k < M; ++k) if (lab[k] >= 0 && bk[k] == b) queue.push_back((int32_t)k);
             size_t head = 0;
             int64_t next_seed = 0;
             for (;;) {
@@ -442,17 +579,21 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
                     for (int a = 0; a < nv; ++a)
                         for (int64_t q = inc_off[v[a]]; q < inc_off[v[a] + 1]; ++q) {
                             const int32_t c2 = inc[q];
-                            if (label[c2] == -1) { label[c2] = (int8_t)(1 - label[c]); queue.push_back(c2); }
+                            if (lab[c2] == -1) { lab[c2] = (int8_t)(1 - lab[c]); queue.push_back(c2); }
                         }
                 }
                 // components without a forced member: seed the lowest unlabelled constraint with S0
-                while (next_seed < M && !(label[next_seed] == -1 && bucket[next_seed] == b)) ++next_seed;
+                while (next_seed < M && !(lab[next_seed] == -1 && bk[next_seed] == b)) ++next_seed;
                 if (next_seed == M) break;
-                label[next_seed] = 0;
+                lab[next_seed] = 0;
                 queue.push_back((int32_t)next_seed);
             }
-        }
-        for (int64_t k = 0; k < M; ++k) if (label[k] >= 0) own[t][k] = (uint8_t)label[k];
+        });
+        for (int t = 0; t < 3; ++t)
+            if (!label[t].empty())
+                parallel_chunks(C.count(t), 1 << 20, [&](int64_t, int64_t kb, int64_t ke) {
+                    for (int64_t k = kb; k < ke; ++k) if (label[t][k] >= 0) own[t][k] = (uint8_t)label[t][k];
+                });
     }
 
     timer.lap("static split");
@@ -470,86 +611,138 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         std::vector<int64_t> off[3];
         std::vector<int32_t> lst[3];
         const int32_t nt = tile_end - tile_begin;
-        for (int t = 0; t < 3; ++t) {
+        parallel_chunks(3, 1, [&](int64_t t, int64_t, int64_t) {         // bucket each type's constraints by tile
             auto &o = off[t];
             o.assign((size_t)nt + 1, 0);
-            for (int64_t k = 0; k < C.count(t); ++k) if (own[t][k] == code) ++o[tof[C.idx(t, k)[0]] - tile_begin + 1];
+            for (int64_t k = 0; k < C.count((int)t); ++k) if (own[t][k] == code) ++o[tof[C.idx((int)t, k)[0]] - tile_begin + 1];
             for (int32_t c = 0; c < nt; ++c) o[c + 1] += o[c];
             lst[t].resize(o[nt]);
             std::vector<int64_t> cur(o.begin(), o.end() - 1);
-            for (int64_t k = 0; k < C.count(t); ++k) if (own[t][k] == code) lst[t][cur[tof[C.idx(t, k)[0]] - tile_begin]++] = (int32_t)k;
-        }
-        for (int32_t c = tile_begin; c < tile_end; ++c) {
-            Tile &tile = TT.tiles[c];
-            tile.round_begin = (int32_t)TT.rounds.size();
-            tile.d_begin = (int64_t)TT.t_dist.size(); tile.q_begin = (int64_t)TT.t_quad_id.size();
-            tile.seq_begin = (int64_t)seq_id[tl].size();
-            for (int t = 0; t < 3; ++t) {
-                const int32_t *it = lst[t].data() + off[t][c - tile_begin];
-                const int64_t cnt = off[t][c - tile_begin + 1] - off[t][c - tile_begin];
-                if (cnt == 0) continue;
-                const int nv = kVerts[t];
-                lv.resize((size_t)cnt * nv);
-                for (int64_t k = 0; k < cnt; ++k) {
-                    const int32_t *v = C.idx(t, it[k]);
-                    for (int a = 0; a < nv; ++a) lv[k * nv + a] = lmap[P.new_of_old[v[a]]];
-                }
-                int ncol = greedy_colour(cnt, nv, [&](int64_t k) { return lv.data() + (size_t)k * nv; }, used, col_tmp);
-                std::vector<std::vector<int32_t>> by(ncol);
-                for (int64_t k = 0; k < cnt; ++k) by[col_tmp[k]].push_back((int32_t)k);
-                for (auto &colv : by) {
-                    if (bank_aware && colv.size() > (size_t)kLdsGroup) {
-                        // Lane order inside a colour is free (its constraints share no particle). The LDS serves a 16-byte
-                        // gather or scatter for kLdsGroup lanes per cycle, conflict-free when their float4 indices differ
-                        // modulo kLdsGroup: deal the constraints so that every aligned group of kLdsGroup lanes holds
-                        // distinct first indices and, where the choice allows, distinct second indices (bank conflicts of
-                        // the mid-tick kernel at 256^3: 21.2 M -> 9.5 M cycles per launch, SQ_LDS_BANK_CONFLICT).
-                        std::vector<std::vector<int32_t>> bucket((size_t)kLdsGroup);
-                        for (int32_t k : colv) bucket[lv[(size_t)k * nv] % kLdsGroup].push_back(k);
-                        colv.clear();
-                        for (bool any = true; any;) {
-                            any = false;
-                            uint32_t used_j = 0;
-                            for (auto &b : bucket) {
-                                if (b.empty()) continue;
-                                any = true;
-                                size_t pick = b.size() - 1;
-                                for (size_t d = 0; d < b.size(); ++d) {
-                                    const size_t q = b.size() - 1 - d;
-                                    if (!((used_j >> (lv[(size_t)b[q] * nv + 1] % kLdsGroup)) & 1u)) { pick = q; break; }
+            for (int64_t k = 0; k < C.count((int)t); ++k) if (own[t][k] == code) lst[t][cur[tof[C.idx((int)t, k)[0]] - tile_begin]++] = (int32_t)k;
+        });
+        // Tiles are independent: chunks of tiles build their pieces of the tiling's arrays side by side, the pieces are
+        // then laid end to end in tile order (the arrays come out exactly as a tile-by-tile loop would fill them).
+        struct Piece {
+            std::vector<uint32_t> rounds, t_dist, t_quad;
+            std::vector<int32_t> t_dist_id, t_quad_id, seq_id;
+            std::vector<uint8_t> t_quad_type, seq_type;
+            std::vector<int64_t> seq_groups;
+        };
+        constexpr int64_t kTilesPerChunk = 64;
+        const int64_t nch = ((int64_t)nt + kTilesPerChunk - 1) / kTilesPerChunk;
+        std::vector<Piece> pieces((size_t)nch);
+        parallel_chunks(nt, kTilesPerChunk, [&](int64_t ch, int64_t cb, int64_t ce) {
+            Piece &Q = pieces[(size_t)ch];
+            std::vector<Mask128> used((size_t)kMaxTileLocal);
+            std::vector<int> col_tmp;
+            std::vector<int32_t> lv;
+            for (int64_t ci = cb; ci < ce; ++ci) {
+                const int32_t c = tile_begin + (int32_t)ci;
+                Tile &tile = TT.tiles[c];
+                // offsets are relative to the piece until the pieces are placed
+                tile.round_begin = (int32_t)Q.rounds.size();
+                tile.d_begin = (int64_t)Q.t_dist.size(); tile.q_begin = (int64_t)Q.t_quad_id.size();
+                tile.seq_begin = (int64_t)Q.seq_id.size();
+                for (int t = 0; t < 3; ++t) {
+                    const int32_t *it = lst[t].data() + off[t][ci];
+                    const int64_t cnt = off[t][ci + 1] - off[t][ci];
+                    if (cnt == 0) continue;
+                    const int nv = kVerts[t];
+                    lv.resize((size_t)cnt * nv);
+                    for (int64_t k = 0; k < cnt; ++k) {
+                        const int32_t *v = C.idx(t, it[k]);
+                        for (int a = 0; a < nv; ++a) lv[k * nv + a] = lmap[P.new_of_old[v[a]]];
+                    }
+                    int ncol = greedy_colour(cnt, nv, [&](int64_t k) { return lv.data() + (size_t)k * nv; }, used, col_tmp);
+                    std::vector<std::vector<int32_t>> by(ncol);
+                    for (int64_t k = 0; k < cnt; ++k) by[col_tmp[k]].push_back((int32_t)k);
+                    for (auto &colv : by) {
+                        if (bank_aware && colv.size() > (size_t)kLdsGroup) {
+                            // Lane order inside a colour is free (its constraints share no particle). The LDS serves a 16-byte
+                            // gather or scatter for kLdsGroup lanes per cycle, conflict-free when their float4 indices differ
+                            // modulo kLdsGroup: deal the constraints so that every aligned group of kLdsGroup lanes holds
+                            // distinct first indices and, where the choice allows, distinct second indices (bank conflicts of
+                            // the mid-tick kernel at 256^3: 21.2 M -> 9.5 M cycles per launch, SQ_LDS_BANK_CONFLICT).
+                            std::vector<std::vector<int32_t>> bucket((size_t)kLdsGroup);
+                            for (int32_t k : colv) bucket[lv[(size_t)k * nv] % kLdsGroup].push_back(k);
+                            colv.clear();
+                            for (bool any = true; any;) {
+                                any = false;
+                                uint32_t used_j = 0;
+                                for (auto &bq : bucket) {
+                                    if (bq.empty()) continue;
+                                    any = true;
+                                    size_t pick = bq.size() - 1;
+                                    for (size_t d = 0; d < bq.size(); ++d) {
+                                        const size_t q = bq.size() - 1 - d;
+                                        if (!((used_j >> (lv[(size_t)bq[q] * nv + 1] % kLdsGroup)) & 1u)) { pick = q; break; }
+                                    }
+                                    used_j |= 1u << (lv[(size_t)bq[pick] * nv + 1] % kLdsGroup);
+                                    colv.push_back(bq[pick]);
+                                    bq.erase(bq.begin() + (std::ptrdiff_t)pick);
                                 }
-                                used_j |= 1u << (lv[(size_t)b[pick] * nv + 1] % kLdsGroup);
-                                colv.push_back(b[pick]);
-                                b.erase(b.begin() + (std::ptrdiff_t)pick);
                             }
                         }
-                    }
-                    for (size_t s0 = 0; s0 < colv.size(); s0 += kRoundThreads) {
-                        size_t s1 = std::min(colv.size(), s0 + kRoundThreads);
-                        TT.rounds.push_back((uint32_t)(s1 - s0) | ((uint32_t)t << 10));
-                        for (size_t q = s0; q < s1; ++q) {
-                            const int32_t k = colv[q];
-                            const int32_t *l = lv.data() + (size_t)k * nv;
-                            if (t == 0) {
-                                TT.t_dist.push_back((uint32_t)l[0] | ((uint32_t)l[1] << 16));
-                                TT.t_dist_id.push_back(it[k]);
-                            } else {
-                                TT.t_quad.push_back((uint32_t)l[0] | ((uint32_t)l[1] << 16));
-                                TT.t_quad.push_back((uint32_t)l[2] | ((uint32_t)l[3] << 16));
-                                TT.t_quad_id.push_back(it[k]);
-                                TT.t_quad_type.push_back((uint8_t)t);
+                        for (size_t s0 = 0; s0 < colv.size(); s0 += kRoundThreads) {
+                            size_t s1 = std::min(colv.size(), s0 + kRoundThreads);
+                            Q.rounds.push_back((uint32_t)(s1 - s0) | ((uint32_t)t << 10));
+                            for (size_t q = s0; q < s1; ++q) {
+                                const int32_t k = colv[q];
+                                const int32_t *l = lv.data() + (size_t)k * nv;
+                                if (t == 0) {
+                                    Q.t_dist.push_back((uint32_t)l[0] | ((uint32_t)l[1] << 16));
+                                    Q.t_dist_id.push_back(it[k]);
+                                } else {
+                                    Q.t_quad.push_back((uint32_t)l[0] | ((uint32_t)l[1] << 16));
+                                    Q.t_quad.push_back((uint32_t)l[2] | ((uint32_t)l[3] << 16));
+                                    Q.t_quad_id.push_back(it[k]);
+                                    Q.t_quad_type.push_back((uint8_t)t);
+                                }
+                                Q.seq_type.push_back((uint8_t)t);
+                                Q.seq_id.push_back(it[k]);
                             }
-                            seq_type[tl].push_back((uint8_t)t);
-                            seq_id[tl].push_back(it[k]);
+                            Q.seq_groups.push_back((int64_t)Q.seq_id.size());
                         }
-                        seq_groups[tl].push_back((int64_t)seq_id[tl].size());
                     }
                 }
+                tile.seq_end = (int64_t)Q.seq_id.size();
+                tile.n_rounds = (int32_t)Q.rounds.size() - tile.round_begin;
+                tile.d_end = (int64_t)Q.t_dist.size(); tile.q_end = (int64_t)Q.t_quad_id.size();
             }
-            tile.seq_end = (int64_t)seq_id[tl].size();
-            tile.n_rounds = (int32_t)TT.rounds.size() - tile.round_begin;
-            tile.d_end = (int64_t)TT.t_dist.size(); tile.q_end = (int64_t)TT.t_quad_id.size();
+        });
+        // place the pieces
+        std::vector<int64_t> r0((size_t)nch + 1), d0((size_t)nch + 1), q0((size_t)nch + 1), s0v((size_t)nch + 1), g0((size_t)nch + 1);
+        r0[0] = (int64_t)TT.rounds.size(); d0[0] = (int64_t)TT.t_dist.size(); q0[0] = (int64_t)TT.t_quad_id.size();
+        s0v[0] = (int64_t)seq_id[tl].size(); g0[0] = (int64_t)seq_groups[tl].size();
+        for (int64_t ch = 0; ch < nch; ++ch) {
+            const Piece &Q = pieces[(size_t)ch];
+            r0[ch + 1] = r0[ch] + (int64_t)Q.rounds.size(); d0[ch + 1] = d0[ch] + (int64_t)Q.t_dist.size();
+            q0[ch + 1] = q0[ch] + (int64_t)Q.t_quad_id.size(); s0v[ch + 1] = s0v[ch] + (int64_t)Q.seq_id.size();
+            g0[ch + 1] = g0[ch] + (int64_t)Q.seq_groups.size();
         }
+        if (r0[nch] > INT32_MAX) throw std::runtime_error("too many rounds");
+        TT.rounds.resize((size_t)r0[nch]); TT.t_dist.resize((size_t)d0[nch]); TT.t_dist_id.resize((size_t)d0[nch]);
+        TT.t_quad.resize((size_t)q0[nch] * 2); TT.t_quad_id.resize((size_t)q0[nch]); TT.t_quad_type.resize((size_t)q0[nch]);
+        seq_type[tl].resize((size_t)s0v[nch]); seq_id[tl].resize((size_t)s0v[nch]); seq_groups[tl].resize((size_t)g0[nch]);
+        parallel_chunks(nch, 1, [&](int64_t ch, int64_t, int64_t) {
+            const Piece &Q = pieces[(size_t)ch];
+            std::copy(Q.rounds.begin(), Q.rounds.end(), TT.rounds.begin() + r0[ch]);
+            std::copy(Q.t_dist.begin(), Q.t_dist.end(), TT.t_dist.begin() + d0[ch]);
+            std::copy(Q.t_dist_id.begin(), Q.t_dist_id.end(), TT.t_dist_id.begin() + d0[ch]);
+            std::copy(Q.t_quad.begin(), Q.t_quad.end(), TT.t_quad.begin() + 2 * q0[ch]);
+            std::copy(Q.t_quad_id.begin(), Q.t_quad_id.end(), TT.t_quad_id.begin() + q0[ch]);
+            std::copy(Q.t_quad_type.begin(), Q.t_quad_type.end(), TT.t_quad_type.begin() + q0[ch]);
+            std::copy(Q.seq_type.begin(), Q.seq_type.end(), seq_type[tl].begin() + s0v[ch]);
+            std::copy(Q.seq_id.begin(), Q.seq_id.end(), seq_id[tl].begin() + s0v[ch]);
+            for (size_t g = 0; g < Q.seq_groups.size(); ++g) seq_groups[tl][(size_t)g0[ch] + g] = Q.seq_groups[g] + s0v[ch];
+            const int64_t cb = ch * kTilesPerChunk, ce = std::min<int64_t>(nt, cb + kTilesPerChunk);
+            for (int64_t ci = cb; ci < ce; ++ci) {
+                Tile &tile = TT.tiles[tile_begin + ci];
+                tile.round_begin += (int32_t)r0[ch];
+                tile.d_begin += d0[ch]; tile.d_end += d0[ch]; tile.q_begin += q0[ch]; tile.q_end += q0[ch];
+                tile.seq_begin += s0v[ch]; tile.seq_end += s0v[ch];
+            }
+        });
     };
     if (n_tiles[0]) build_programs(0, 0, n_tiles[0], t0_of_old, lidx[0], 0);
     if (n_tiles[1]) build_programs(1, 0, n_tiles[1], t1_of_old, lidx[1], 1);
@@ -676,9 +869,17 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
     timer.lap("global colours");
     // ---- published orders per parity --------------------------------------------------------------
     // parity p: S_p on the tiles of T_p, S2 on the tiles of T2, the global colours, S_(1-p) on the tiles of T_(1-p)
-    for (int p = 0; p < 2; ++p) {
+    parallel_chunks(2, 1, [&](int64_t p64, int64_t, int64_t) {          // the two parities fill disjoint outputs
+        const int p = (int)p64;
         auto &ot = P.order_type[p]; auto &oi = P.order_id[p];
         auto &tasks = P.task_off[p]; auto &groups = P.group_off[p];
+        {
+            const size_t total = (size_t)(P.m[0] + P.m[1] + P.m[2]);
+            size_t n_tasks = 1, n_groups = 1;
+            for (int tl = 0; tl < 3; ++tl) { n_tasks += P.T[tl].tiles.size(); n_groups += seq_groups[tl].size(); }
+            for (const GColour &g : P.gcolours) { n_tasks += g.ids.size() / kRoundThreads + 1; n_groups += g.ids.size() / kRoundThreads + 1; }
+            ot.reserve(total); oi.reserve(total); tasks.reserve(n_tasks); groups.reserve(n_groups);
+        }
         tasks.push_back(0); groups.push_back(0);
         auto append_tiles = [&](int tl, int kind, int32_t tile_begin = 0, int32_t tile_end = -1, int layer = -1) {
             if (tile_end < 0) tile_end = (int32_t)P.T[tl].tiles.size();
@@ -690,7 +891,11 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
             const int64_t base = (int64_t)oi.size() - sb;
             ot.insert(ot.end(), seq_type[tl].begin() + sb, seq_type[tl].begin() + se);
             oi.insert(oi.end(), seq_id[tl].begin() + sb, seq_id[tl].begin() + se);
-            for (int64_t g : seq_groups[tl]) if (g > sb && g <= se) groups.push_back(base + g);
+            {
+                const auto &sg = seq_groups[tl];      // ascending
+                auto gb = std::upper_bound(sg.begin(), sg.end(), sb), ge = std::upper_bound(sg.begin(), sg.end(), se);
+                for (auto it = gb; it != ge; ++it) groups.push_back(base + *it);
+            }
             for (int32_t c = tile_begin; c < tile_end; ++c) {
                 Tile &tile = P.T[tl].tiles[c];
                 tile.order_begin[p] = base + tile.seq_begin; tile.order_end[p] = base + tile.seq_end;
@@ -718,7 +923,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         }
         if (tiling && !P.T[1 - p].tiles.empty()) append_tiles(1 - p, 2);
         if ((int64_t)oi.size() != P.m[0] + P.m[1] + P.m[2]) throw std::runtime_error("planner lost constraints");
-    }
+    });
     // T2 layers whose tiles span ranks need ghost positions: one halo slot per layer, after the global colours' slots
     if (opts.world > 1)
         for (size_t ly = 0; ly < P.t2_layers.size(); ++ly) {
@@ -740,6 +945,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
 }
 
 void extract_local(const Plan &P, const Input &in, int rank, LocalPlan &L) {
+    PlanTimer timer;
     L = LocalPlan();
     L.rank = rank; L.world = P.opts.world;
     const int32_t n = P.n;
@@ -882,6 +1088,7 @@ void extract_local(const Plan &P, const Input &in, int rank, LocalPlan &L) {
             LT.run_begin.push_back((int32_t)LT.runs.size());
         }
     }
+    timer.lap("extract_local: tiles + halo");
     L.gcolours.resize(P.gcolours.size());
     for (size_t gc = 0; gc < P.gcolours.size(); ++gc) {
         const GColour &g = P.gcolours[gc];

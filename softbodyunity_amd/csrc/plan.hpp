@@ -21,6 +21,7 @@
 // published per parity for the oracle.
 #pragma once
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <utility>
 #include <vector>
@@ -147,6 +148,10 @@ struct Input {
     const int32_t *vol; int64_t m_v;
     const int32_t *bend; int64_t m_b;
 };
+
+// f(chunk, begin, end) for the chunks of [0, n) of `chunk_size` elements, on the planner's host threads (SB_PLAN_THREADS,
+// default min(hardware threads, 16)). The chunking never depends on the thread count. Re-throws the first exception.
+void parallel_for_chunks(int64_t n, int64_t chunk_size, const std::function<void(int64_t, int64_t, int64_t)> &f);
 
 // Throws std::runtime_error on invalid input.
 void build_plan(const Input &in, const Opts &opts, Plan &out);

@@ -8,6 +8,8 @@
 #include <rccl/rccl.h>
 
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <climits>
 #include <cmath>
 #include <cstdio>
@@ -243,23 +245,37 @@ void build_device(sb_solver *s) {
     // particle state
     std::vector<float> hp((size_t)s->n_local * 3), hw((size_t)s->n_local);
     std::vector<float> hv((size_t)s->n_local * 3, 0.0f);
-    for (int64_t l = 0; l < s->n_local; ++l) {
-        int32_t o = L.local_to_old[l];
-        for (int c = 0; c < 3; ++c) { hp[3 * (size_t)l + c] = s->pos[3 * (size_t)o + c]; hv[3 * (size_t)l + c] = s->vel[3 * (size_t)o + c]; }
-        hw[l] = s->invm[o];
-    }
+    sbp::parallel_for_chunks(s->n_local, 1 << 18, [&](int64_t, int64_t lb, int64_t le) {
+        for (int64_t l = lb; l < le; ++l) {
+            int32_t o = L.local_to_old[l];
+            for (int c = 0; c < 3; ++c) { hp[3 * (size_t)l + c] = s->pos[3 * (size_t)o + c]; hv[3 * (size_t)l + c] = s->vel[3 * (size_t)o + c]; }
+            hw[l] = s->invm[o];
+        }
+    });
     s->d_pos3.upload(hp, s->dev_bytes);
     s->d_wf.upload(hw, s->dev_bytes);
     {   // one byte per particle instead of four when the mesh uses few distinct masses (the usual case)
         std::vector<uint32_t> vals(hw.size());
         for (size_t l = 0; l < hw.size(); ++l) std::memcpy(&vals[l], &hw[l], 4);
-        std::vector<uint32_t> uniq = vals;
-        std::sort(uniq.begin(), uniq.end());
-        uniq.erase(std::unique(uniq.begin(), uniq.end()), uniq.end());
+        std::vector<uint32_t> uniq;           // sorted distinct bit patterns, given up beyond the palette size
+        bool few = true;
+        {
+            uint32_t last = 0; bool have_last = false;
+            for (uint32_t v : vals) {
+                if (have_last && v == last) continue;
+                last = v; have_last = true;
+                auto it = std::lower_bound(uniq.begin(), uniq.end(), v);
+                if (it != uniq.end() && *it == v) continue;
+                if ((int)uniq.size() == sbk::kMaxMassPalette) { few = false; break; }
+                uniq.insert(it, v);
+            }
+        }
         std::vector<float> pal(sbk::kMaxMassPalette, 0.0f);
-        if ((int)uniq.size() <= sbk::kMaxMassPalette && !std::getenv("SB_NO_MASS_PALETTE")) {
+        if (few && !std::getenv("SB_NO_MASS_PALETTE")) {
             std::vector<uint8_t> w8(hw.size());
-            for (size_t l = 0; l < hw.size(); ++l) w8[l] = (uint8_t)(std::lower_bound(uniq.begin(), uniq.end(), vals[l]) - uniq.begin());
+            sbp::parallel_for_chunks((int64_t)hw.size(), 1 << 20, [&](int64_t, int64_t lb, int64_t le) {
+                for (int64_t l = lb; l < le; ++l) w8[(size_t)l] = (uint8_t)(std::lower_bound(uniq.begin(), uniq.end(), vals[(size_t)l]) - uniq.begin());
+            });
             for (size_t k = 0; k < uniq.size(); ++k) std::memcpy(&pal[k], &uniq[k], 4);
             s->d_w8.upload(w8, s->dev_bytes);
             s->w_palette = true;
@@ -368,18 +384,35 @@ void build_device(sb_solver *s) {
                 rg.second = (int32_t)pk + 1;
             }
         }
-        std::vector<sbk::TileDesc> tiles;
-        std::vector<int2> overflow;
-        std::vector<uint32_t> stream;
-        std::vector<int32_t> dev_gather;
-        int32_t max_local = 0;
-        uint32_t max_data = 4;
-        int32_t max_pal = 0, max_rounds = 0;
+        // Packs are independent: chunks of packs build their pieces of the tables side by side on host threads, the pieces
+        // are then laid end to end in pack order (offsets re-based), exactly as a pack-by-pack loop would fill them.
+        struct Piece {
+            std::vector<sbk::TileDesc> tiles;
+            std::vector<int2> overflow;
+            std::vector<uint32_t> stream;
+            std::vector<int32_t> dev_gather;
+            int32_t max_local = 0, max_pal = 0, max_rounds = 0;
+            uint32_t max_data = 4;
+            bool has_quads = false;
+        };
         auto fbits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
         struct Part { int32_t member, cnt; int64_t first; };             // a member's round inside a pack round
         struct PackRound { int type; int32_t cnt; std::vector<Part> parts; };
+        const bool no_palette = std::getenv("SB_NO_PALETTE") != nullptr;
+        constexpr int64_t kPacksPerChunk = 128;
+        const int64_t n_chunks = ((int64_t)packs.size() + kPacksPerChunk - 1) / kPacksPerChunk;
+        std::vector<Piece> pieces((size_t)n_chunks);
+        sbp::parallel_for_chunks((int64_t)packs.size(), kPacksPerChunk, [&](int64_t chunk, int64_t pk_begin, int64_t pk_end) {
+        Piece &Q = pieces[(size_t)chunk];
+        std::vector<sbk::TileDesc> &tiles = Q.tiles;
+        std::vector<int2> &overflow = Q.overflow;
+        std::vector<uint32_t> &stream = Q.stream;
+        std::vector<int32_t> &dev_gather = Q.dev_gather;
+        int32_t &max_local = Q.max_local, &max_pal = Q.max_pal, &max_rounds = Q.max_rounds;
+        uint32_t &max_data = Q.max_data;
         std::vector<PackRound> prog;
-        for (const std::vector<int32_t> &members : packs) {
+        for (int64_t pk = pk_begin; pk < pk_end; ++pk) {
+            const std::vector<int32_t> &members = packs[(size_t)pk];
             sbk::TileDesc td{};
             td.run_overflow = (int32_t)overflow.size();
             std::vector<int32_t> base(members.size());
@@ -450,7 +483,7 @@ void build_device(sb_solver *s) {
             const size_t s0 = stream.size();
             // dictionary-code the rest lengths of this tile's distance constraints when few values repeat
             std::vector<uint32_t> pal;
-            bool compact = !std::getenv("SB_NO_PALETTE") && n_dist > 0;
+            bool compact = !no_palette && n_dist > 0;
             if (compact) {
                 std::vector<uint32_t> vals;
                 vals.reserve((size_t)n_dist);
@@ -490,7 +523,7 @@ void build_device(sb_solver *s) {
                             }
                         }
                     } else {
-                        D.has_quads = true;
+                        Q.has_quads = true;
                         for (int64_t k = pt.first; k < pt.first + pt.cnt; ++k) {
                             stream.push_back(G.t_quad[2 * k] + b2); stream.push_back(G.t_quad[2 * k + 1] + b2);
                             const int32_t id = G.t_quad_id[k];
@@ -504,6 +537,35 @@ void build_device(sb_solver *s) {
             td.s_len = (uint32_t)(stream.size() - s0);
             max_data = std::max(max_data, td.s_len - td.s_hdr);
             tiles.push_back(td);
+        }
+        });
+        // place the pieces: stream / overflow / gather offsets of a descriptor are relative to its piece until now
+        std::vector<sbk::TileDesc> tiles;
+        std::vector<int2> overflow;
+        std::vector<uint32_t> stream;
+        std::vector<int32_t> dev_gather;
+        int32_t max_local = 0, max_pal = 0, max_rounds = 0;
+        uint32_t max_data = 4;
+        {
+            size_t nt = 0, no = 0, ns = 0, ng = 0;
+            for (const Piece &Q : pieces) { nt += Q.tiles.size(); no += Q.overflow.size(); ns += Q.stream.size(); ng += Q.dev_gather.size(); }
+            if (ns > 0xfffffff0ull) throw std::runtime_error("tile constraint stream exceeds 2^32 dwords");
+            tiles.reserve(nt); overflow.reserve(no); stream.reserve(ns); dev_gather.reserve(ng);
+            for (Piece &Q : pieces) {
+                for (sbk::TileDesc td : Q.tiles) {
+                    td.s_begin += (uint32_t)stream.size();
+                    td.run_overflow += (int32_t)overflow.size();
+                    td.gather_begin += (int32_t)dev_gather.size();
+                    tiles.push_back(td);
+                }
+                overflow.insert(overflow.end(), Q.overflow.begin(), Q.overflow.end());
+                stream.insert(stream.end(), Q.stream.begin(), Q.stream.end());
+                dev_gather.insert(dev_gather.end(), Q.dev_gather.begin(), Q.dev_gather.end());
+                max_local = std::max(max_local, Q.max_local); max_pal = std::max(max_pal, Q.max_pal);
+                max_rounds = std::max(max_rounds, Q.max_rounds); max_data = std::max(max_data, Q.max_data);
+                D.has_quads |= Q.has_quads;
+                Piece().tiles.swap(Q.tiles); std::vector<uint32_t>().swap(Q.stream);
+            }
         }
         D.n_tiles = (int32_t)tiles.size();
         D.max_local = std::max(max_local, 1);
@@ -854,8 +916,11 @@ static int set_cons(sb_solver *s, const char *who, const int32_t *idx, const flo
     if (s->n <= 0) return fail(SB_ERR_STATE, std::string(who) + " before sb_set_particles");
     if (!(compliance >= 0.0f)) return fail(SB_ERR_INVALID_ARG, std::string(who) + ": compliance must be >= 0");
     return guarded([&]() -> int {
-        for (int64_t k = 0; k < (int64_t)m * nv; ++k)
-            if (idx[k] < 0 || idx[k] >= s->n) return fail(SB_ERR_INVALID_ARG, std::string(who) + ": particle index out of range");
+        std::atomic<bool> bad{false};
+        sbp::parallel_for_chunks((int64_t)m * nv, 1 << 22, [&](int64_t, int64_t kb, int64_t ke) {
+            for (int64_t k = kb; k < ke; ++k) if (idx[k] < 0 || idx[k] >= s->n) { bad = true; return; }
+        });
+        if (bad) return fail(SB_ERR_INVALID_ARG, std::string(who) + ": particle index out of range");
         std::vector<int32_t> &I = type == 0 ? s->dist_ij : (type == 1 ? s->vol_ijkl : s->bend_ijkl);
         std::vector<float> &R = type == 0 ? s->dist_rest : (type == 1 ? s->vol_rest : s->bend_rest);
         I.assign(idx, idx + (size_t)m * nv);
@@ -933,9 +998,15 @@ int sb_finalize(sb_solver *s) {
         o.bank_aware_lanes = !std::getenv("SB_NO_BANK_ORDER");
         o.third_tiling = !std::getenv("SB_NO_T2");
         s->plan = std::make_unique<sb_plan>();
+        const bool timing = std::getenv("SB_PLAN_TIMING") != nullptr;
+        auto t0 = std::chrono::steady_clock::now();
         sbp::build_plan(in, o, s->plan->plan);
         sbp::extract_local(s->plan->plan, in, o.rank, s->plan->local);
+        auto t1 = std::chrono::steady_clock::now();
         build_device(s);
+        if (timing)
+            std::fprintf(stderr, "[finalize] plan %.1f ms, build_device + upload %.1f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
+                         std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
         // opt in to the LDS size the largest tile needs
         for (int tl = 0; tl < 3; ++tl)
             if (s->tiling[tl].lds_bytes > 64 * 1024) throw std::runtime_error("internal: tile LDS budget exceeded");

@@ -32,19 +32,31 @@ class SoftbodyMesh:
 def jelly_cube(n, spacing=1.0, perturb=0.05, seed=1234, pin_top=False, stencil="structural"):
     """n^3 lattice, index (iz*n+iy)*n+ix, structural springs x-dir then y then z (SPEC.md §7)."""
     assert n >= 2
-    lin = np.arange(n ** 3, dtype=np.int64)
-    cx = lin % n
-    cy = (lin // n) % n
-    cz = lin // (n * n)
-    rest = np.stack([cx, cy, cz], axis=1).astype(np.float32) * np.float32(spacing)
+    N = n ** 3
+    ax = np.arange(n, dtype=np.float32) * np.float32(spacing)
+    rest = np.empty((n, n, n, 3), np.float32)                # [iz, iy, ix, xyz]
+    rest[..., 0] = ax[None, None, :]; rest[..., 1] = ax[None, :, None]; rest[..., 2] = ax[:, None, None]
+    rest = rest.reshape(N, 3)
     rng = np.random.default_rng(seed)
-    jitter = rng.uniform(-perturb, perturb, size=(n ** 3, 3)) * spacing
-    pos = (rest.astype(np.float64) + jitter).astype(np.float32)
+    jitter = rng.uniform(-perturb, perturb, size=(N, 3))
+    jitter *= spacing
+    jitter += rest                                           # float64: rest + jitter, rounded once to float32
+    pos = jitter.astype(np.float32)
     del jitter
-    edges = []
-    for mask, off in ((cx < n - 1, 1), (cy < n - 1, n), (cz < n - 1, n * n)):
-        lo = lin[mask]
-        edges.append(np.stack([lo, lo + off], axis=1))
+    idx = np.arange(N, dtype=np.int32).reshape(n, n, n)
+    m1 = n * n * (n - 1)
+    # structural springs, x-direction first, then y, then z, each in particle order (SPEC.md 7)
+    n_struct = 3 * m1
+    ij_struct = np.empty((n_struct, 2), np.int32)
+    for k, (lo, off) in enumerate(((idx[:, :, :-1], 1), (idx[:, :-1, :], n), (idx[:-1, :, :], n * n))):
+        ij_struct[k * m1:(k + 1) * m1, 0] = lo.reshape(-1)
+        np.add(ij_struct[k * m1:(k + 1) * m1, 0], np.int32(off), out=ij_struct[k * m1:(k + 1) * m1, 1])
+    edges = [ij_struct]
+    if stencil == "full":
+        lin = np.arange(N, dtype=np.int64)
+        cx = lin % n
+        cy = (lin // n) % n
+        cz = lin // (n * n)
     if stencil == "full":
         # face + body diagonals (26-neighbour stencil), for colouring stress tests
         for dx in (-1, 0, 1):
@@ -57,14 +69,14 @@ def jelly_cube(n, spacing=1.0, perturb=0.05, seed=1234, pin_top=False, stencil="
                     m = ((cx + dx >= 0) & (cx + dx < n) & (cy + dy >= 0) & (cy + dy < n) & (cz + dz < n))
                     lo = lin[m]
                     edges.append(np.stack([lo, lo + dx + dy * n + dz * n * n], axis=1))
-    ij = np.concatenate(edges).astype(np.int32)
+    ij = ij_struct if len(edges) == 1 else np.concatenate(edges).astype(np.int32)
     if stencil == "full":
         rest_len = np.linalg.norm(rest[ij[:, 0]].astype(np.float64) - rest[ij[:, 1]].astype(np.float64), axis=1).astype(np.float32)
     else:
         rest_len = np.full(ij.shape[0], spacing, np.float32)   # axis springs: L0 = spacing (SPEC.md §7)
-    w = np.ones(n ** 3, np.float32)
+    w = np.ones(N, np.float32)
     if pin_top:
-        w[cy == n - 1] = 0.0
+        w.reshape(n, n, n)[:, n - 1, :] = 0.0
     return SoftbodyMesh(rest_pos=rest, pos=pos, vel=np.zeros_like(pos), inv_mass=w, dist_ij=ij,
                         dist_rest=rest_len, label=f"jelly_cube_{n}^3_{stencil}")
 
