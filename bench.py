@@ -100,6 +100,7 @@ def main():
 
     t_setup = time.time()
     mesh = jelly_cube(args.n)
+    mesh_s = time.time() - t_setup
     N = mesh.n
     M = len(mesh.dist_rest)
     uid = None
@@ -271,7 +272,8 @@ def main():
                          "tick_ms_hip_events": ev_ms / args.steps,
                          "per_slot_ms_per_tick": {names[k]: float(slot_ms[k]) for k in range(len(names))},
                          "per_slot_launches_per_tick": {names[k]: int(slot_cnt[k]) for k in range(len(names))}},
-            "setup_seconds": setup_s, "plan": stats,
+            "setup_seconds": setup_s, "setup_breakdown": {"mesh_generation": mesh_s, "Start (author + plan + upload)": setup_s - mesh_s},
+            "plan": stats,
         }
         if world == 1 and not loopback and not args.no_parity:
             parity["small"] = small_parity(total_ticks, args, device)

@@ -393,6 +393,126 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
     }
     __syncthreads();   // also covers the staging loads
 
+    // MARK step (SPEC.md §2): collide + velocity update of the substep that just finished, integrate of the next one
+    auto mark_step = [&]() {
+#pragma unroll
+        for (int m = 0; m < PPT; ++m)
+            if (g[m] >= 0) {
+                const int l = tid + m * kTileThreads;
+                float4 P = lds_pos[l];
+                if (KIND != 0 && tp.plane_on && P.w > 0.0f) {   // collide: end of the substep that just finished
+                    float a = tp.pnx * P.x, b = tp.pny * P.y, c = tp.pnz * P.z;
+                    float pen = ((a + b) + c) - tp.pd;
+                    if (pen < 0.0f) {
+                        float dx = pen * tp.pnx, dy = pen * tp.pny, dz = pen * tp.pnz;
+                        P.x = P.x - dx; P.y = P.y - dy; P.z = P.z - dz;
+                        if (KIND == 2) lds_pos[l] = P;
+                    }
+                }
+                float vx, vy, vz;
+                const size_t o = 3 * (size_t)g[m];
+                if (KIND == 0) {
+                    vx = A.vel[o + 0]; vy = A.vel[o + 1]; vz = A.vel[o + 2];
+                } else {
+                    float dx = P.x - pvx[m], dy = P.y - pvy[m], dz = P.z - pvz[m];
+                    float qx = dx * tp.inv_h, qy = dy * tp.inv_h, qz = dz * tp.inv_h;
+                    vx = qx * tp.kd; vy = qy * tp.kd; vz = qz * tp.kd;
+                }
+                if (KIND == 2) {
+                    A.vel[o + 0] = vx; A.vel[o + 1] = vy; A.vel[o + 2] = vz;
+                } else {
+                    A.prev[o + 0] = P.x; A.prev[o + 1] = P.y; A.prev[o + 2] = P.z;
+                    if (P.w > 0.0f) {
+                        vx = vx + tp.hgx; vy = vy + tp.hgy; vz = vz + tp.hgz;
+                        float hx = tp.h * vx, hy = tp.h * vy, hz = tp.h * vz;
+                        P.x = P.x + hx; P.y = P.y + hy; P.z = P.z + hz;
+                        lds_pos[l] = P;
+                    }
+                }
+            }
+    };
+
+#ifndef SB_REG_ROUNDS
+#define SB_REG_ROUNDS 4          // 256-lane workgroups (one constraint per lane and round)
+#endif
+#ifndef SB_REG_ROUNDS_NARROW
+#define SB_REG_ROUNDS_NARROW 3   // 128-lane workgroups (two per lane): the register budget of 6 waves per SIMD allows 3
+#endif
+    // Short programs of dictionary-coded distance rounds (every tile of a regular mesh: 3 rounds) keep their constraint
+    // slots and rest lengths in registers: one batch of LDS reads ahead of the first round instead of two dependent LDS
+    // round trips (slot, then palette entry) at the head of every round, in both passes. Same constraints, same order.
+    constexpr int kRegRounds = THREADS >= 256 ? SB_REG_ROUNDS : SB_REG_ROUNDS_NARROW;
+    if (kRegRounds > 0 && !QUADS && n_rounds_all <= kRegRounds && n_rounds_all > 0 && n_pal > 0 && d_hi - d_lo <= win) {
+        uint32_t rs[kRegRounds > 0 ? kRegRounds : 1][kCPL];
+        float rl[kRegRounds > 0 ? kRegRounds : 1][kCPL];
+        int rcnt[kRegRounds > 0 ? kRegRounds : 1];
+        {
+            uint32_t o = 0;
+#pragma unroll
+            for (int r = 0; r < kRegRounds; ++r) {
+                rcnt[r] = 0;
+                if (r < n_rounds_all) {
+                    rcnt[r] = (int)((uint32_t)__builtin_amdgcn_readlane((int)rwl, r) & 1023u);
+#pragma unroll
+                    for (int u = 0; u < kCPL; ++u) {
+                        const int c = tid + u * kTileThreads;
+                        rs[r][u] = cbuf[o + (c < rcnt[r] ? c : 0)];
+                    }
+                    o += ((uint32_t)rcnt[r] + 3u) & ~3u;
+                } else {
+#pragma unroll
+                    for (int u = 0; u < kCPL; ++u) rs[r][u] = 0;
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < kRegRounds; ++r)
+#pragma unroll
+                for (int u = 0; u < kCPL; ++u) rl[r][u] = s_pal[rs[r][u] >> 24];
+        }
+        auto reg_round = [&](const uint32_t (&e)[kCPL], const float (&L0)[kCPL], int cnt) {
+            if (kCPL == 1) {
+                if (tid < cnt) {
+                    const int i = e[0] & 0xfffu, k = (e[0] >> 12) & 0xfffu;
+                    float4 a = lds_pos[i], b = lds_pos[k];
+                    if (project_distance(a, b, L0[0], tp.at_d)) { lds_pos[i] = a; lds_pos[k] = b; }
+                }
+            } else {
+                int ci[kCPL], ck[kCPL];
+                bool con[kCPL];
+                f32x4 ca[kCPL], cb[kCPL];
+#pragma unroll
+                for (int u = 0; u < kCPL; ++u) {
+                    con[u] = tid + u * kTileThreads < cnt;
+                    ci[u] = e[u] & 0xfffu; ck[u] = (e[u] >> 12) & 0xfffu;
+                    ca[u] = *reinterpret_cast<const f32x4 *>(lds_pos + ci[u]);
+                    cb[u] = *reinterpret_cast<const f32x4 *>(lds_pos + ck[u]);
+                }
+#pragma unroll
+                for (int u = 0; u < kCPL; ++u) {
+                    float4 a = make_float4(ca[u].x, ca[u].y, ca[u].z, ca[u].w), b = make_float4(cb[u].x, cb[u].y, cb[u].z, cb[u].w);
+                    con[u] = project_distance_nobranch(a, b, L0[u], tp.at_d) && con[u];
+                    ca[u].x = a.x; ca[u].y = a.y; ca[u].z = a.z; cb[u].x = b.x; cb[u].y = b.y; cb[u].z = b.z;
+                }
+#pragma unroll
+                for (int u = 0; u < kCPL; ++u) {
+                    f32x3 *da = con[u] ? reinterpret_cast<f32x3 *>(lds_pos + ci[u]) : lds_spare;
+                    f32x3 *db = con[u] ? reinterpret_cast<f32x3 *>(lds_pos + ck[u]) : lds_spare;
+                    *da = (f32x3){ca[u].x, ca[u].y, ca[u].z};
+                    *db = (f32x3){cb[u].x, cb[u].y, cb[u].z};
+                }
+            }
+            lds_barrier();
+        };
+        if (KIND != 0) {
+#pragma unroll
+            for (int r = 0; r < kRegRounds; ++r) if (r < n_rounds_all) reg_round(rs[r], rl[r], rcnt[r]);
+        }
+        if (KIND != 3) { mark_step(); lds_barrier(); }
+        if (KIND == 0 || KIND == 1) {
+#pragma unroll
+            for (int r = 0; r < kRegRounds; ++r) if (r < n_rounds_all) reg_round(rs[r], rl[r], rcnt[r]);
+        }
+    } else {
     uint32_t off = d_lo;    // dword offset (from the tile's stream start) of the current round's data
 #if defined(SB_ABLATE) && SB_ABLATE == 1   // timing experiment only: memory traffic without the rounds
     for (int v = v_begin; v < v_end; v += 100000) {
@@ -409,42 +529,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
         }
         const int cnt = w & 1023u, type = (w >> 10) & 7u;
         if (type == 3) {
-            // velocity update of the substep that just finished + integrate of the next one (SPEC.md §2)
-#pragma unroll
-            for (int m = 0; m < PPT; ++m)
-                if (g[m] >= 0) {
-                    const int l = tid + m * kTileThreads;
-                    float4 P = lds_pos[l];
-                    if (KIND != 0 && tp.plane_on && P.w > 0.0f) {   // collide: end of the substep that just finished
-                        float a = tp.pnx * P.x, b = tp.pny * P.y, c = tp.pnz * P.z;
-                        float pen = ((a + b) + c) - tp.pd;
-                        if (pen < 0.0f) {
-                            float dx = pen * tp.pnx, dy = pen * tp.pny, dz = pen * tp.pnz;
-                            P.x = P.x - dx; P.y = P.y - dy; P.z = P.z - dz;
-                            if (KIND == 2) lds_pos[l] = P;
-                        }
-                    }
-                    float vx, vy, vz;
-                    const size_t o = 3 * (size_t)g[m];
-                    if (KIND == 0) {
-                        vx = A.vel[o + 0]; vy = A.vel[o + 1]; vz = A.vel[o + 2];
-                    } else {
-                        float dx = P.x - pvx[m], dy = P.y - pvy[m], dz = P.z - pvz[m];
-                        float qx = dx * tp.inv_h, qy = dy * tp.inv_h, qz = dz * tp.inv_h;
-                        vx = qx * tp.kd; vy = qy * tp.kd; vz = qz * tp.kd;
-                    }
-                    if (KIND == 2) {
-                        A.vel[o + 0] = vx; A.vel[o + 1] = vy; A.vel[o + 2] = vz;
-                    } else {
-                        A.prev[o + 0] = P.x; A.prev[o + 1] = P.y; A.prev[o + 2] = P.z;
-                        if (P.w > 0.0f) {
-                            vx = vx + tp.hgx; vy = vy + tp.hgy; vz = vz + tp.hgz;
-                            float hx = tp.h * vx, hy = tp.h * vy, hz = tp.h * vz;
-                            P.x = P.x + hx; P.y = P.y + hy; P.z = P.z + hz;
-                            lds_pos[l] = P;
-                        }
-                    }
-                }
+            mark_step();
         } else {
             const uint32_t size = type == 0 ? ((2u * cnt + 3u) & ~3u) : (type == 4 ? ((cnt + 3u) & ~3u) : 4u * cnt);
             if (off + size > win_lo + win || off < win_lo) {   // refill the window (uniform; rare for small tiles)
@@ -545,6 +630,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
 #else
         lds_barrier();
 #endif
+    }
     }
 #pragma unroll
     for (int m = 0; m < PPT; ++m)

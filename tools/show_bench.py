@@ -10,7 +10,7 @@ for f in sys.argv[1:]:
         print(f, "unreadable:", e)
         continue
     r = d["roofline"]
-    print(f"{f}: {d['value']:.3e} {d['unit']}  ms/step {d['ms_per_step']:.3f}  job_frac {r['job_frac']:.3f}")
+    print(f"{f}: {d['value']:.3e} {d['unit']}  ms/step {d['ms_per_step']:.3f}  job_frac_alg {r.get('job_frac_algorithmic', r.get('job_frac', 0)):.3f}  setup {d.get('setup_seconds', 0):.1f} s")
     print(f"   dominant: {r['kernel'][:40]} avg {r['kernel_avg_ms']:.4f} ms  achieved {r['achieved']:.0f} GB/s (frac {r['frac']:.3f})"
           f"  traffic {r.get('traffic')}")
     print("   per tick:", {k[:24]: round(v, 3) for k, v in r["per_slot_ms_per_tick"].items()})
