@@ -73,6 +73,7 @@ struct TileArgs {
     int32_t pal_dwords;       // largest rest-length dictionary of the tiling, padded to 4 (0 = none)
     int32_t win_dwords;       // constraint window held in LDS (multiple of 4, >= the largest round)
     int32_t tile_base;        // this launch covers tiles tile_base + blockIdx.x (boundary / interior split)
+    int32_t w_uniform;        // WPAL kernels: every particle has the same inverse mass -> all lanes read index 0 (one cache line, no per-particle byte)
 };
 
 // Lanes per tile (template parameter THREADS of tile_kernel). A round holds up to kRoundSlots independent constraints,
@@ -332,7 +333,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
     for (int m = 0; m < PPT; ++m) {
         const int gc = max(g[m], 0);
         X[m].x = A.pos.xyz[3 * (size_t)gc + 0]; X[m].y = A.pos.xyz[3 * (size_t)gc + 1]; X[m].z = A.pos.xyz[3 * (size_t)gc + 2];
-        if (WPAL) { wi[m] = A.w8[gc]; X[m].w = 0.0f; } else { wi[m] = 0; X[m].w = A.pos.w[gc]; }
+        if (WPAL) { wi[m] = A.w8[A.w_uniform ? 0 : gc]; X[m].w = 0.0f; } else { wi[m] = 0; X[m].w = A.pos.w[gc]; }
         pvx[m] = pvy[m] = pvz[m] = 0.0f;
         if (KIND != 0 && KIND != 3) { pvx[m] = A.prev[3 * (size_t)gc + 0]; pvy[m] = A.prev[3 * (size_t)gc + 1]; pvz[m] = A.prev[3 * (size_t)gc + 2]; }
     }

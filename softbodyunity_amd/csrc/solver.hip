@@ -133,6 +133,7 @@ struct sb_solver {
     DevBuf<uint8_t> d_w8;            // palette index of the inverse mass (when <= 64 distinct values)
     DevBuf<float> d_wpal;
     bool w_palette = false;
+    bool w_uniform = false;          // one distinct inverse mass: the tile kernels skip the per-particle index read
     sbk::PosView pos_view() const { return sbk::PosView{d_pos3.p, d_wf.p}; }
     DevBuf<float> d_prev, d_vel;
     DevBuf<sbk::TickParams> d_tp;
@@ -279,6 +280,7 @@ void build_device(sb_solver *s) {
             for (size_t k = 0; k < uniq.size(); ++k) std::memcpy(&pal[k], &uniq[k], 4);
             s->d_w8.upload(w8, s->dev_bytes);
             s->w_palette = true;
+            s->w_uniform = uniq.size() == 1 && !std::getenv("SB_NO_UNIFORM_MASS");
         }
         s->d_wpal.upload(pal, s->dev_bytes);
     }
@@ -678,6 +680,7 @@ void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = 
     A.tiles = D.tiles.p; A.runs_overflow = D.runs_overflow.p; A.stream = D.stream.p;
     A.tp = s->d_tp.p;
     A.gather = D.gather.p;
+    A.w_uniform = s->w_uniform ? 1 : 0;
     A.max_local = D.max_local; A.win_dwords = D.win_dwords; A.tile_base = tile_begin; A.pal_dwords = D.pal_dwords; A.rounds_dwords = D.rounds_dwords;
     const bool small = D.max_local <= sbk::kSmallTile;   // every tile <= 512 particles
     // narrow (2-wave) workgroups once the launch oversubscribes the chip; wide ones while every tile is resident at once
@@ -1432,7 +1435,7 @@ int sb_get_stats(sb_solver *s, sb_stats *out) {
     }
     out->device_bytes = s->dev_bytes;
     {   // compulsory bytes per launch (see softbody.h): particle state + the tables a launch reads
-        const int64_t mb = s->w_palette ? 1 : 4;     // inverse mass: palette index or float
+        const int64_t mb = s->w_uniform ? 0 : (s->w_palette ? 1 : 4);     // inverse mass: nothing (uniform), palette index, or float
         auto tables = [&](const DevTiling &D) { return D.stream_bytes + (int64_t)D.n_tiles * (int64_t)sizeof(sbk::TileDesc) + (int64_t)D.runs_overflow.count * 8; };
         for (int tl = 0; tl < 2; ++tl) {
             const DevTiling &D = s->tiling[tl];
