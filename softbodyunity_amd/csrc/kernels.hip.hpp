@@ -34,7 +34,7 @@ struct TileDesc {
     uint32_t pad3;
     int32_t run_overflow;      // runs beyond kInlineRuns live at runs_overflow[run_overflow ...]
     int32_t n_pal;             // palette entries (0 = no dictionary coding), stored after the round words
-    int32_t dep_begin, dep_count;   // fused T2 launch: this tile waits for tiles t2_deps[dep_begin .. +dep_count) (earlier layers sharing a particle)
+    int32_t pad1, pad2;
     int2 runs[10];             // {first particle (device numbering), first tile-local index}; unused entries: {0, INT_MAX}
 };
 constexpr int kInlineRuns = 10;
@@ -73,13 +73,6 @@ struct TileArgs {
     int32_t pal_dwords;       // largest rest-length dictionary of the tiling, padded to 4 (0 = none)
     int32_t win_dwords;       // constraint window held in LDS (multiple of 4, >= the largest round)
     int32_t tile_base;        // this launch covers tiles tile_base + blockIdx.x (boundary / interior split)
-    // Fused T2 launch (all layers of a substep in one launch, single-rank solvers): workgroup = tile in layer order; a
-    // tile starts once every earlier-layer tile that shares a particle with it has finished. t2_done[tile] counts the
-    // launches the tile has completed -- every tile runs once per launch, so a tile's own count tells which launch this
-    // is and no per-launch argument is needed (the launch sits in a captured hipGraph). nullptr = one launch per layer.
-    uint32_t *t2_done;
-    const int32_t *t2_deps;
-    uint32_t *t2_error;       // set to 1 when a wait gave up (never in a correct plan: the spin is bounded so a bug cannot hang the GPU)
     int32_t w_uniform;        // WPAL kernels: every particle has the same inverse mass -> all lanes read index 0 (one cache line, no per-particle byte)
 };
 
@@ -259,12 +252,10 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
     // Workgroups are dealt round-robin over the 8 XCDs (observed, MI355X_MICROARCH.md §Workgroup dispatch; speed only):
     // give each XCD a contiguous range of tiles, so that neighbouring tiles -- whose runs meet inside a 128-byte line
     // wherever a T1 tile's pieces of one T0 tile lie side by side -- read and write those lines through the same L2.
-    const bool fused_t2 = KIND == 3 && A.t2_done != nullptr;
 #ifndef SB_NO_XCD_REMAP
     const int nwg = (int)gridDim.x, wg = (int)blockIdx.x;
     const int xq = nwg >> 3, xr = nwg & 7, xcd = wg & 7;
-    // (fused T2 launch: workgroup order = layer order, so that a tile's predecessors are never dispatched after it)
-    const int tile_index = fused_t2 ? wg : (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wg >> 3);
+    const int tile_index = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wg >> 3);
 #else
     const int tile_index = (int)blockIdx.x;
 #endif
@@ -306,22 +297,6 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
             g[m] = l < n_local ? gi : -1;
         }
     }
-    // ---- fused T2 launch: wait for the earlier-layer tiles this tile shares particles with ---------------
-    uint32_t t2_target = 0;
-    if (KIND == 3 && fused_t2) {
-        const int self = A.tile_base + tile_index;
-        t2_target = __hip_atomic_load(A.t2_done + self, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;   // launches completed so far + 1
-        for (int d = tid; d < td.dep_count; d += kTileThreads) {
-            const uint32_t *flag = A.t2_done + A.t2_deps[td.dep_begin + d];
-            int spins = 0;
-            while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - t2_target) < 0) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > (1 << 22)) { __hip_atomic_store(A.t2_error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); break; }
-            }
-        }
-        __syncthreads();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    }
     // ---- the stretch of the stream this kernel needs, staged through an LDS window -----------------
     // virtual program: rounds 0..R-1 (finish the previous substep), MARK, rounds 0..R-1 again (start the next)
     const int R = n_rounds_all;
@@ -357,14 +332,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
 #pragma unroll
     for (int m = 0; m < PPT; ++m) {
         const int gc = max(g[m], 0);
-        if (KIND == 3 && fused_t2) {
-            // written by other workgroups of THIS launch (possibly behind another XCD's L2): read at agent scope
-            X[m].x = __hip_atomic_load(A.pos.xyz + 3 * (size_t)gc + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            X[m].y = __hip_atomic_load(A.pos.xyz + 3 * (size_t)gc + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            X[m].z = __hip_atomic_load(A.pos.xyz + 3 * (size_t)gc + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        } else {
-            X[m].x = A.pos.xyz[3 * (size_t)gc + 0]; X[m].y = A.pos.xyz[3 * (size_t)gc + 1]; X[m].z = A.pos.xyz[3 * (size_t)gc + 2];
-        }
+        X[m].x = A.pos.xyz[3 * (size_t)gc + 0]; X[m].y = A.pos.xyz[3 * (size_t)gc + 1]; X[m].z = A.pos.xyz[3 * (size_t)gc + 2];
         if (WPAL) { wi[m] = A.w8[A.w_uniform ? 0 : gc]; X[m].w = 0.0f; } else { wi[m] = 0; X[m].w = A.pos.w[gc]; }
         pvx[m] = pvy[m] = pvz[m] = 0.0f;
         if (KIND != 0 && KIND != 3) { pvx[m] = A.prev[3 * (size_t)gc + 0]; pvy[m] = A.prev[3 * (size_t)gc + 1]; pvz[m] = A.prev[3 * (size_t)gc + 2]; }
@@ -664,21 +632,6 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
         lds_barrier();
 #endif
     }
-    }
-    if (KIND == 3 && fused_t2) {
-#pragma unroll
-        for (int m = 0; m < PPT; ++m)
-            if (g[m] >= 0) {
-                const float4 v = lds_pos[tid + m * kTileThreads];
-                float *q = A.pos.xyz + 3 * (size_t)g[m];
-                __hip_atomic_store(q + 0, v.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(q + 1, v.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(q + 2, v.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");     // every lane: its stores are visible device-wide ...
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(A.t2_done + A.tile_base + tile_index, t2_target, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);   // ... before the tile reports
-        return;
     }
 #pragma unroll
     for (int m = 0; m < PPT; ++m)

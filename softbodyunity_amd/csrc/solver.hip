@@ -85,9 +85,6 @@ struct DevTiling {
     DevBuf<int2> runs_overflow;
     DevBuf<uint32_t> stream;     // per tile: [round words][rest-length dictionary][round data], see kernels.hip.hpp
     DevBuf<int32_t> gather;      // T2: particle lists of the tiles (local numbering)
-    DevBuf<int32_t> deps;        // T2, fused launch: predecessor tiles (device tile indices), see TileDesc::dep_begin
-    DevBuf<uint32_t> done;       // T2, fused launch: launches completed per tile; [n_tiles] = error flag
-    bool fused = false;          // T2: all layers of a substep in one launch (single rank, every tile co-resident)
 };
 
 struct DevGColour {
@@ -584,34 +581,6 @@ void build_device(sb_solver *s) {
             const sbp::Tile &T = G.tiles[LT.tile_ids[ci]];
             D.n_slots += (T.d_end - T.d_begin) + (T.q_end - T.q_begin);
         }
-        if (tl == 2 && !tiles.empty()) {
-            // Fused launch of all T2 layers: tile -> the last earlier-layer tile that touched each of its
-            // particles. Tiles of one layer share no particle, so updating `last` as we go is safe; a chain of waits
-            // per particle makes the relation transitive.
-            std::vector<int32_t> last((size_t)s->n_local, -1), deps, layer_of_tile(tiles.size(), 0);
-            for (size_t ly = 0; ly < s->t2_layer_range.size(); ++ly)
-                for (int32_t t = s->t2_layer_range[ly].first; t < s->t2_layer_range[ly].second; ++t) layer_of_tile[(size_t)t] = (int32_t)ly;
-            for (size_t t = 0; t < tiles.size(); ++t) {
-                sbk::TileDesc &td = tiles[t];
-                td.dep_begin = (int32_t)deps.size();
-                for (int32_t q = 0; q < td.n_local; ++q) {
-                    const int32_t li = dev_gather[(size_t)td.gather_begin + q];
-                    const int32_t pre = last[(size_t)li];
-                    if (pre >= 0 && layer_of_tile[(size_t)pre] != layer_of_tile[t] &&
-                        std::find(deps.begin() + td.dep_begin, deps.end(), pre) == deps.end()) deps.push_back(pre);
-                    last[(size_t)li] = (int32_t)t;
-                }
-                td.dep_count = (int32_t)deps.size() - td.dep_begin;
-            }
-            int n_cu = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDeviceProperties(&prop, s->desc.device) == hipSuccess) n_cu = prop.multiProcessorCount;
-            // every workgroup of the launch must be resident at once (a waiting tile keeps its slot): 2 wide workgroups per CU is far inside the limit
-            D.fused = s->desc.world == 1 && s->t2_layer_range.size() > 1 && (int)tiles.size() <= 2 * n_cu && !std::getenv("SB_NO_T2_FUSE");
-            D.deps.upload(deps, s->dev_bytes);
-            D.done.alloc(tiles.size() + 1, s->dev_bytes);
-            HIP_CHECK(hipMemset(D.done.p, 0, (tiles.size() + 1) * sizeof(uint32_t)));
-        }
         D.staged_particles = 0;
         for (const sbk::TileDesc &td : tiles) D.staged_particles += td.n_local;
         D.stream_bytes = (int64_t)stream.size() * 4;
@@ -703,11 +672,10 @@ void halo_exchange(sb_solver *s, int slot, hipStream_t st = nullptr) {
 }
 
 template <int KIND>
-void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = -1, bool fused_t2 = false) {
+void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = -1) {
     if (tile_end < 0) tile_end = D.n_tiles;
     if (tile_end <= tile_begin) return;
     sbk::TileArgs A{};
-    if (fused_t2) { A.t2_done = D.done.p; A.t2_deps = D.deps.p; A.t2_error = D.done.p + D.n_tiles; }
     A.pos = s->pos_view(); A.w8 = s->d_w8.p; A.wpal = s->d_wpal.p; A.prev = s->d_prev.p; A.vel = s->d_vel.p;
     A.tiles = D.tiles.p; A.runs_overflow = D.runs_overflow.p; A.stream = D.stream.p;
     A.tp = s->d_tp.p;
@@ -816,12 +784,7 @@ void enqueue_substeps(sb_solver *s, int substeps, LaunchTimer *lt = nullptr, boo
         if (it == 0 && fused_first) launch_tick_kernel(s, 2, 4, lt);   // an even, interior step index: KIND 1 on T0
         else launch_tick_kernel(s, it, substeps, lt);
         if (it == substeps) break;
-        if (s->tiling[2].fused) {      // all T2 layers in one launch, tile-level dependencies (single rank: no ghost refresh between layers)
-            if (lt) lt->begin(4 + (int)s->gcolours.size());
-            launch_tile<3>(s, s->tiling[2], 0, s->tiling[2].n_tiles, true);
-            if (lt) lt->end();
-        } else
-            for (size_t ly = 0; ly < s->t2_layer_range.size(); ++ly) launch_t2_layer(s, (int)ly, lt);
+        for (size_t ly = 0; ly < s->t2_layer_range.size(); ++ly) launch_t2_layer(s, (int)ly, lt);
         for (size_t gc = 0; gc < s->gcolours.size(); ++gc) {
             halo_exchange(s, 2 + (int)gc);
             launch_gcolour(s, (int)gc, lt);
@@ -848,16 +811,6 @@ void upload_tick_params(sb_solver *s, float dt, int substeps) {
         HIP_CHECK(hipStreamSynchronize(s->stream));
         s->tp_host = tp; s->tp_valid = true;
     }
-}
-
-// Fused T2 launch: a dependency wait that gave up (cannot happen with a correct plan) must not pass silently.
-void check_t2_error(sb_solver *s) {
-    DevTiling &D = s->tiling[2];
-    if (!D.fused || !D.done.p) return;
-    uint32_t flag = 0;
-    HIP_CHECK(hipMemcpyAsync(&flag, D.done.p + D.n_tiles, sizeof(flag), hipMemcpyDeviceToHost, s->stream));
-    HIP_CHECK(hipStreamSynchronize(s->stream));
-    if (flag) throw HipError(SB_ERR_HIP, "fused T2 launch: a tile gave up waiting for a predecessor (internal error)");
 }
 
 template <class F>
@@ -1231,7 +1184,6 @@ int sb_synchronize(sb_solver *s) {
         int rc = set_device(s); if (rc) return rc;
         flush_deferred(s);
         HIP_CHECK(hipStreamSynchronize(s->stream));
-        check_t2_error(s);
         return SB_OK;
     });
 }
@@ -1244,7 +1196,6 @@ static int get_state(sb_solver *s, float *out, int32_t n, bool velocity) {
         int rc = set_device(s); if (rc) return rc;
         const sbp::LocalPlan &L = s->plan->local;
         flush_deferred(s);
-        check_t2_error(s);
         if (s->desc.world == 1) {
             // single rank: every entry is ours, so the permutation to caller numbering runs on the GPU and one copy
             // lands in the caller's array (the host-side scatter below costs 25 ms for 16.7 M particles)

@@ -326,23 +326,6 @@ def test_tile_packing_is_invisible(oracle_mod, bunny20k, monkeypatch):
         assert np.array_equal(xa.view(np.uint32), xb.view(np.uint32)) and np.array_equal(va.view(np.uint32), vb.view(np.uint32))
 
 
-def test_fused_t2_launch_is_invisible(oracle_mod, bunny20k, monkeypatch):
-    # single-rank solvers run all T2 layers of a substep in ONE launch (a tile waits for the earlier-layer tiles it shares
-    # particles with); SB_NO_T2_FUSE launches layer by layer. Same bits either way, and the oracle's.
-    comp = (1e-7, 1e-7, 1e-5)
-    outs = []
-    for fuse in (True, False):
-        if fuse:
-            monkeypatch.delenv("SB_NO_T2_FUSE", raising=False)
-        else:
-            monkeypatch.setenv("SB_NO_T2_FUSE", "1")
-        rel, mabs, bit, x, v, o, st = _run_pair(oracle_mod, bunny20k, ticks=4, substeps=10, compliance=comp, tile_particles=128)
-        assert st["n_t2_layers"] >= 2
-        assert bit and np.array_equal(v.view(np.uint32), o.v.view(np.uint32)), (fuse, rel, mabs)
-        outs.append(x)
-    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
-
-
 @pytest.mark.parametrize("lanes", ["128", "256"])
 def test_both_workgroup_widths_match_the_oracle(oracle_mod, bunny20k, monkeypatch, lanes):
     # small tiles run as 256-lane workgroups (one constraint per lane and round) or, in launches of >= 10240 tiles,
