@@ -79,7 +79,8 @@ struct DevTiling {
     int64_t staged_particles = 0;   // sum of n_local over the device tiles
     int64_t stream_bytes = 0;    // bytes of the tile streams (round words, palettes, slots)
     int32_t max_local = 0, win_dwords = 4, pal_dwords = 0, rounds_dwords = 0;
-    int32_t n_boundary = 0;      // T0 with world > 1: the first n_boundary tiles hold every particle some peer needs
+    int32_t n_boundary = 0;      // world > 1: T0 -- the FIRST n_boundary tiles hold every particle some peer needs; T1 -- the LAST
+                                 // n_boundary tiles hold every ghost and every sent particle
     bool has_quads = false;
     DevBuf<sbk::TileDesc> tiles;
     DevBuf<int2> runs_overflow;
@@ -293,24 +294,32 @@ void build_device(sb_solver *s) {
         const sbp::Tiling &G = P.T[tl];
         sbp::LocalTiling LT = L.T[tl];     // copy: T0 is re-ordered boundary tiles first
         DevTiling &D = s->tiling[tl];
-        if (tl == 0 && L.world > 1 && L.halo.size() > 1) {
+        // world > 1: T0 launches run the tiles that hold sent particles FIRST (n_boundary of them), T1 launches run the
+        // tiles that hold a ghost or a sent particle LAST: the ghost exchange between a T0 and the following T1 kernel can
+        // then travel beside the T0 interior tiles and the T1 interior tiles, which touch none of the particles the
+        // pack kernel reads or the unpack kernel writes (enqueue_substeps, overlapped schedule).
+        std::vector<uint8_t> tile_is_b;            // per plan tile of LT after the re-ordering (tilings 0 and 1)
+        if ((tl == 0 || tl == 1) && L.world > 1 && L.halo.size() > 1) {
             std::vector<uint8_t> sent((size_t)s->n_local, 0);
             for (const auto &lst : L.halo[1].send_idx) for (int32_t li : lst) sent[li] = 1;
             std::vector<int32_t> order(LT.tile_ids.size());
             std::vector<uint8_t> is_b(LT.tile_ids.size(), 0);
             for (size_t ci = 0; ci < LT.tile_ids.size(); ++ci) {
                 order[ci] = (int32_t)ci;
-                for (int32_t r = LT.run_begin[ci]; r < LT.run_begin[ci + 1] && !is_b[ci]; ++r)
+                for (int32_t r = LT.run_begin[ci]; r < LT.run_begin[ci + 1] && !is_b[ci]; ++r) {
+                    if (tl == 1 && (int64_t)LT.runs[r].start + LT.runs[r].len > s->n_owned) { is_b[ci] = 1; break; }   // a ghost run
                     for (int32_t q = 0; q < LT.runs[r].len; ++q) if (sent[LT.runs[r].start + q]) { is_b[ci] = 1; break; }
+                }
             }
-            std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return is_b[a] > is_b[b]; });
+            if (tl == 0) std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return is_b[a] > is_b[b]; });
+            else std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return is_b[a] < is_b[b]; });
             sbp::LocalTiling R;
             R.run_begin.push_back(0);
             for (int32_t ci : order) {
                 R.tile_ids.push_back(LT.tile_ids[ci]);
                 for (int32_t r = LT.run_begin[ci]; r < LT.run_begin[ci + 1]; ++r) R.runs.push_back(LT.runs[r]);
                 R.run_begin.push_back((int32_t)R.runs.size());
-                D.n_boundary += is_b[ci];
+                tile_is_b.push_back(is_b[ci]);
             }
             LT = R;
         }
@@ -332,7 +341,7 @@ void build_device(sb_solver *s) {
                 while (ly + 1 < (int)P.t2_layers.size() && plan_tile >= P.t2_layers[ly].second) ++ly;
                 return ly;
             };
-            auto cls = [&](int32_t ci) { return tl == 2 ? layer_of(LT.tile_ids[ci]) : (ci < D.n_boundary ? 0 : 1); };
+            auto cls = [&](int32_t ci) { return tl == 2 ? layer_of(LT.tile_ids[ci]) : (tile_is_b.empty() ? 0 : (int)tile_is_b[(size_t)ci]); };
             auto size_of = [&](int32_t ci) { return G.tiles[LT.tile_ids[ci]].n_local; };
             auto runs_of = [&](int32_t ci) { return LT.run_begin[ci + 1] - LT.run_begin[ci]; };
             if (s->pack_tiles)
@@ -372,7 +381,7 @@ void build_device(sb_solver *s) {
                 if (pack_of[ci] < 0) { packs.push_back({(int32_t)ci}); }
                 else if (slot_of_bin[pack_of[ci]] < 0) { slot_of_bin[pack_of[ci]] = (int32_t)packs.size(); packs.push_back({(int32_t)ci}); }
                 else { packs[slot_of_bin[pack_of[ci]]].push_back((int32_t)ci); continue; }
-                if ((int32_t)ci < D.n_boundary) ++n_boundary_packs;
+                if (!tile_is_b.empty() && tile_is_b[ci]) ++n_boundary_packs;     // (a pack never mixes the two classes)
             }
             D.n_boundary = n_boundary_packs;
         }
@@ -756,14 +765,17 @@ void launch_gcolour(sb_solver *s, int gc, LaunchTimer *lt) {
 void enqueue_substeps(sb_solver *s, int substeps, LaunchTimer *lt = nullptr, bool fused_first = false, bool defer_last = false) {
     const bool two = s->plan->plan.tiling;
     if (s->overlap_halo) {
-        // T0 kernels run their boundary tiles first; the ghost exchange for the following T1 kernel then travels
-        // on comm_stream while the interior tiles run. T0 interior tiles touch neither the packed particles
-        // (they live in boundary tiles) nor the ghost slots the unpack writes.
-        DevTiling &T0 = s->tiling[0];
+        // Overlapped schedule (opt-in, SB_HALO_OVERLAP): a T0 kernel runs its boundary tiles first; the ghost exchange
+        // for the following T1 kernel then travels on comm_stream beside the T0 interior tiles AND the T1 interior
+        // tiles; the T1 tiles that hold a ghost or a sent particle run last, after the exchange. The interior tiles of
+        // either tiling touch none of the particles the pack kernel reads or the unpack kernel writes (build_device).
+        DevTiling &T0 = s->tiling[0], &T1 = s->tiling[1];
+        const int t1_interior = T1.n_tiles - T1.n_boundary;
         for (int it = 0; it <= substeps; ++it) {
             if (it & 1) {
+                launch_tick_kernel(s, it, substeps, lt, 0, t1_interior);
                 HIP_CHECK(hipStreamWaitEvent(s->stream, s->ev_halo, 0));
-                launch_tick_kernel(s, it, substeps, lt);
+                launch_tick_kernel(s, it, substeps, lt, t1_interior, T1.n_tiles);
             } else {
                 launch_tick_kernel(s, it, substeps, lt, 0, T0.n_boundary);
                 if (it < substeps) {
@@ -1046,7 +1058,7 @@ int sb_step(sb_solver *s, float dt, int32_t substeps) {
         if (!fuse) flush_deferred(s);
         upload_tick_params(s, dt, substeps);
         // world > 1: RCCL send/recv inside a captured graph is opt-in (SB_GRAPH_RCCL=1), see DESIGN.md §7
-        const bool graph_ok = s->desc.use_graph && !s->overlap_halo && (s->desc.world == 1 || s->graph_rccl);
+        const bool graph_ok = s->desc.use_graph && (s->desc.world == 1 || s->graph_rccl);     // the overlapped schedule forks onto comm_stream inside the capture
         if (!graph_ok) {
             enqueue_substeps(s, substeps, nullptr, fuse, can_defer);
         } else {

@@ -180,11 +180,12 @@ def test_rccl_pipeline_loopback_and_overlap_equivalence(monkeypatch):
     mesh = jelly_cube(32)
     monkeypatch.setenv("SB_TEST_LOOPBACK", "1")
     outs = []
-    for no_overlap in ("", "1"):
-        if no_overlap:
-            monkeypatch.delenv("SB_HALO_OVERLAP", raising=False)
-        else:
-            monkeypatch.setenv("SB_HALO_OVERLAP", "1")
+    for overlap, graph in (("1", ""), ("", ""), ("1", "1"), ("", "1")):      # eager / captured in a hipGraph, overlapped or serialised
+        for key, val in (("SB_HALO_OVERLAP", overlap), ("SB_GRAPH_RCCL", graph)):
+            if val:
+                monkeypatch.setenv(key, val)
+            else:
+                monkeypatch.delenv(key, raising=False)
         sb = Softbody(mesh, substeps=8, device=0, rank=0, world=2, tile_particles=64, unique_id=comm_unique_id()).Start()
         try:
             st = sb.stats()
@@ -198,4 +199,5 @@ def test_rccl_pipeline_loopback_and_overlap_equivalence(monkeypatch):
             sb.OnDestroy()
         assert np.isfinite(x[owned]).all()
         outs.append(x[owned])
-    assert np.array_equal(outs[0].view(np.uint32), outs[1].view(np.uint32))
+    for o in outs[1:]:
+        assert np.array_equal(outs[0].view(np.uint32), o.view(np.uint32))
