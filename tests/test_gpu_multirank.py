@@ -170,34 +170,16 @@ def test_multirank_device_path_with_hosted_halo(tmp_path, oracle_mod, monkeypatc
 
 # ---- the real RCCL pipeline on one GPU: loopback communicator (every peer = this rank) -----------------------
 
-def test_rccl_pipeline_loopback_and_overlap_equivalence(monkeypatch):
+def test_rccl_pipeline_loopback_and_overlap_equivalence():
     """SB_TEST_LOOPBACK makes rank 0 of a 2-rank split exchange its ghosts with ITSELF through a size-1 RCCL
     communicator: physically meaningless, but pack -> ncclSend/ncclRecv -> unpack, the comm stream and the event
-    wiring all run for real. The overlapped schedule (boundary tiles first, exchange beside the interior tiles) must
-    give bit-identical results to the serialised one."""
-    from softbodyunity_amd import Softbody, comm_unique_id
-    from softbodyunity_amd.mesh import jelly_cube
-    mesh = jelly_cube(32)
-    monkeypatch.setenv("SB_TEST_LOOPBACK", "1")
-    outs = []
-    for overlap, graph in (("1", ""), ("", ""), ("1", "1"), ("", "1")):      # eager / captured in a hipGraph, overlapped or serialised
-        for key, val in (("SB_HALO_OVERLAP", overlap), ("SB_GRAPH_RCCL", graph)):
-            if val:
-                monkeypatch.setenv(key, val)
-            else:
-                monkeypatch.delenv(key, raising=False)
-        sb = Softbody(mesh, substeps=8, device=0, rank=0, world=2, tile_particles=64, unique_id=comm_unique_id()).Start()
-        try:
-            st = sb.stats()
-            assert st["halo_particles_t1"] > 0
-            for _ in range(5):
-                sb.step()
-            sb.synchronize()
-            x = sb.get_positions().copy()
-            owned = sb.owner() == 0
-        finally:
-            sb.OnDestroy()
-        assert np.isfinite(x[owned]).all()
-        outs.append(x[owned])
-    for o in outs[1:]:
-        assert np.array_equal(outs[0].view(np.uint32), o.view(np.uint32))
+    wiring all run for real. Four schedules -- serialised or overlapped (exchange beside the T0 interior and the T1
+    interior tiles), launched eagerly or captured in the hipGraph -- must give the same bits. Each runs in its own
+    process (tools/lb_combo_test.py): several RCCL communicators with captured graphs in ONE process crashed inside
+    the runtime on this image, which has nothing to do with the schedule under test."""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lb_combo_test.py")], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-1500:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("overlap=")]
+    assert len(lines) == 4 and all("rc=0 HASH" in l and l.endswith("True") for l in lines), out.stdout[-1500:]
+    assert "all equal: True" in out.stdout, out.stdout[-1500:]
