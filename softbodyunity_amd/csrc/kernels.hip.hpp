@@ -218,6 +218,95 @@ __device__ __forceinline__ bool project_bending(float4 &pa, float4 &pb, float4 &
     return true;
 }
 
+// ---- 4-vertex constraints on FOUR lanes each (tile kernels) -------------------------------------------------------
+// A tet or hinge projection is a long serial chain (130 / 450 instructions on one lane) and a round of an irregular
+// tile holds only a few dozen of them, so the tile kernels spread one constraint over a quad of lanes: lane q = 0,1,2
+// of the quad carries component q of every 3-vector, lane 3 carries the inverse masses; dot and cross products combine
+// the lanes with DPP quad permutes (no LDS, no extra instructions once folded into the consumer), and independent scalar
+// divisions / square roots are dealt one to a lane. Every operation is the one SPEC.md §5/§6 prescribes, in the same
+// order with the same operands, so the bits equal the one-lane functions above (and the oracle).
+constexpr int qp_ctrl(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
+template <int CTRL>
+__device__ __forceinline__ float qperm(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float qb0(float v) { return qperm<qp_ctrl(0, 0, 0, 0)>(v); }
+__device__ __forceinline__ float qb1(float v) { return qperm<qp_ctrl(1, 1, 1, 1)>(v); }
+__device__ __forceinline__ float qb2(float v) { return qperm<qp_ctrl(2, 2, 2, 2)>(v); }
+__device__ __forceinline__ float qb3(float v) { return qperm<qp_ctrl(3, 3, 3, 3)>(v); }
+__device__ __forceinline__ float qrot1(float v) { return qperm<qp_ctrl(1, 2, 0, 3)>(v); }   // lane c <- component (c+1) mod 3
+__device__ __forceinline__ float qrot2(float v) { return qperm<qp_ctrl(2, 0, 1, 3)>(v); }   // lane c <- component (c+2) mod 3
+// dot3: (xx + yy) + zz, the value in every lane of the quad
+__device__ __forceinline__ float qdot(float a, float b) {
+    const float t = a * b;
+    const float xx = qb0(t), yy = qb1(t), zz = qb2(t);
+    return (xx + yy) + zz;
+}
+// cross3: lane c gets a[c+1]*b[c+2] - a[c+2]*b[c+1]
+__device__ __forceinline__ float qcross(float a, float b) {
+    const float t0 = qrot1(a) * qrot2(b), t1 = qrot2(a) * qrot1(b);
+    return t0 - t1;
+}
+
+// SPEC.md §5 on a quad. P[k]: lane q < 3 holds component q of particle k, lane 3 its inverse mass.
+__device__ __forceinline__ bool project_volume_quad(float (&P)[4], float R6, float at_v) {
+    const float W0 = qb3(P[0]), W1 = qb3(P[1]), W2 = qb3(P[2]), W3 = qb3(P[3]);
+    const float e1 = P[1] - P[0], e2 = P[2] - P[0], e3 = P[3] - P[0];
+    const float g1 = qcross(e2, e3), g2 = qcross(e3, e1), g3 = qcross(e1, e2);
+    float t = g1 + g2; t = t + g3;
+    const float g0 = -t;
+    const float C6 = qdot(e1, g1) - R6;
+    const float a0 = W0 * qdot(g0, g0), a1 = W1 * qdot(g1, g1), a2 = W2 * qdot(g2, g2), a3 = W3 * qdot(g3, g3);
+    const float den = (((a0 + a1) + a2) + a3) + at_v;
+    if (!(den > 0.0f)) return false;
+    const float s = (-C6) / den;
+    const float s0 = W0 * s, s1 = W1 * s, s2 = W2 * s, s3 = W3 * s;
+    const float d0 = s0 * g0, d1 = s1 * g1, d2 = s2 * g2, d3 = s3 * g3;
+    P[0] = P[0] + d0; P[1] = P[1] + d1; P[2] = P[2] + d2; P[3] = P[3] + d3;
+    return true;
+}
+
+// SPEC.md §6 on a quad. rest = (cos phi0, sin phi0). q = lane & 3.
+__device__ __forceinline__ bool project_bending_quad(float (&P)[4], float rest_c, float rest_s, float at_b, int q) {
+    const float xa = P[0], xb = P[1], xc = P[2], xd = P[3];
+    const float Wa = qb3(xa), Wb = qb3(xb), Wc = qb3(xc), Wd = qb3(xd);
+    const float e = xb - xa;
+    const float el2 = qdot(e, e);
+    const float el = sqrtf(el2);
+    const float ac = xa - xc, bc = xb - xc, bd = xb - xd, ad = xa - xd;
+    const float n1 = qcross(ac, bc), n2 = qcross(bd, ad);
+    const float q1 = qdot(n1, n1), q2 = qdot(n2, n2);
+    if (!(el > 0.0f) || !(q1 > 0.0f) || !(q2 > 0.0f)) return false;
+    const float m1 = n1 / q1, m2 = n2 / q2;
+    const float gc = el * m1, gd = el * m2;
+    const float cb = xc - xb, db = xd - xb;
+    // four independent scalar divisions by el: one to a lane, then broadcast
+    const float na1 = qdot(cb, e), na2 = qdot(db, e), nb1 = qdot(ac, e), nb2 = qdot(ad, e);
+    const float num = q == 0 ? na1 : (q == 1 ? na2 : (q == 2 ? nb1 : nb2));
+    const float quo = num / el;
+    const float ta1 = qb0(quo), ta2 = qb1(quo), tb1 = qb2(quo), tb2 = qb3(quo);
+    float ga, gb;
+    { const float p = ta1 * m1, r = ta2 * m2; ga = p + r; }
+    { const float p = tb1 * m1, r = tb2 * m2; gb = p + r; }
+    // two independent square roots: lane 0 takes q1, the others q2
+    const float sq = sqrtf(q == 0 ? q1 : q2);
+    const float s1 = qb0(sq), s2 = qb1(sq);
+    const float u1 = n1 / s1, u2 = n2 / s2;
+    const float cs = qdot(u1, u2);
+    const float cr = qcross(u1, u2);
+    const float sn = -(qdot(cr, e) / el);
+    const float t0 = sn * rest_c, t1 = cs * rest_s;
+    const float C = t0 - t1;
+    const float a0 = Wa * qdot(ga, ga), a1 = Wb * qdot(gb, gb), a2 = Wc * qdot(gc, gc), a3 = Wd * qdot(gd, gd);
+    const float den = (((a0 + a1) + a2) + a3) + at_b;
+    if (!(den > 0.0f)) return false;
+    const float s = (-C) / den;
+    const float sa = Wa * s, sb = Wb * s, sc = Wc * s, sd = Wd * s;
+    const float da = sa * ga, db2 = sb * gb, dc = sc * gc, dd = sd * gd;
+    P[0] = xa + da; P[1] = xb + db2; P[2] = xc + dc; P[3] = xd + dd;
+    return true;
+}
+
 // One workgroup = one tile (or one pack of under-full tiles, solver.hip build_device) of THREADS lanes; a tile owns one
 // constraint list, cut into rounds of at most kRoundSlots independent constraints (plan.hpp):
 //   KIND 0 (first kernel of a tick)  : MARK: v from the velocity array, integrate; the tile's rounds
@@ -613,6 +702,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
                     *db = (f32x3){cb[u].x, cb[u].y, cb[u].z};
                 }
             } else if (QUADS) {
+#ifdef SB_QUADS_ONE_LANE   // A/B timing builds: one lane per 4-vertex constraint
 #pragma unroll 1
                 for (int c = tid; c < cnt; c += kTileThreads) {
                     const uint4 e = *reinterpret_cast<const uint4 *>(base + 4 * c);
@@ -623,6 +713,22 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
                                         : project_bending(p0, p1, p2, p3, rest, tp.at_b);
                     if (ok) { lds_pos[i0] = p0; lds_pos[i1] = p1; lds_pos[i2] = p2; lds_pos[i3] = p3; }
                 }
+#else
+                // four lanes per constraint (see project_volume_quad): lane q of a quad reads component q of the four
+                // particles (lane 3: their inverse masses), writes component q back
+                float *lds_f = reinterpret_cast<float *>(lds_pos);
+                const int q = tid & 3;
+#pragma unroll 1
+                for (int c = tid >> 2; c < cnt; c += kTileThreads / 4) {
+                    const uint4 e = *reinterpret_cast<const uint4 *>(base + 4 * c);
+                    const int o0 = 4 * (int)(e.x & 0xffffu) + q, o1 = 4 * (int)(e.x >> 16) + q;
+                    const int o2 = 4 * (int)(e.y & 0xffffu) + q, o3 = 4 * (int)(e.y >> 16) + q;
+                    float P[4] = {lds_f[o0], lds_f[o1], lds_f[o2], lds_f[o3]};
+                    const bool ok = type == 1 ? project_volume_quad(P, __uint_as_float(e.z), tp.at_v)
+                                              : project_bending_quad(P, __uint_as_float(e.z), __uint_as_float(e.w), tp.at_b, q);
+                    if (ok && q < 3) { lds_f[o0] = P[0]; lds_f[o1] = P[1]; lds_f[o2] = P[2]; lds_f[o3] = P[3]; }
+                }
+#endif
             }
             off += size;
         }
