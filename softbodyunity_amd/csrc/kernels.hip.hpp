@@ -20,11 +20,11 @@ struct TickParams {           // SPEC.md §2 host-side scalars, uploaded once pe
 // One LDS tile (or pack of tiles) = one workgroup. 128 B, read with scalar loads.
 // The tile's constraint stream lives at stream[s_begin ...], 16-byte aligned, in dwords:
 //   [round words, padded to 4] [rest-length palette, padded to 4] [rounds' data]
-// round word: bits 0-9 count, bits 10-12 type (0 distance, 1 volume, 2 bending, 4 = distance, dictionary-coded);
-// a distance round stores count x {i | j<<16, rest length} (padded to 4 dwords); when a tile's distance
-// constraints use at most 256 distinct rest lengths (regular meshes) they are dictionary-coded instead:
-// count x {i | j<<12 | palette index<<24} (one dword each) with the values in the tile's palette;
-// a 4-vertex round stores count x {i0|i1<<16, i2|i3<<16, rest.x, rest.y}.
+// group word: bits 0-9 distance, 10-19 volume, 20-29 bending constraint count (each <= 256), bit 30 = the distance slots
+// are dictionary-coded. A group's constraints share no particle (one barrier per group). Its data: the distance slots,
+// count x {i | j<<16, rest length}, or -- when a tile's distance constraints use at most 256 distinct rest lengths
+// (regular meshes) -- count x {i | j<<12 | palette index<<24} (one dword each) with the values in the tile's palette,
+// padded to 4 dwords; then the volume slots, then the bending slots, each {i0|i1<<16, i2|i3<<16, rest.x, rest.y}.
 struct TileDesc {
     int32_t n_local, run_count, n_rounds;
     int32_t gather_begin;      // KIND 3 (T2 tiles): the tile's particles are gather[gather_begin .. +n_local) instead of runs
@@ -528,7 +528,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
 #ifndef SB_REG_ROUNDS_NARROW
 #define SB_REG_ROUNDS_NARROW 3   // 128-lane workgroups (two per lane): the register budget of 6 waves per SIMD allows 3
 #endif
-    // Short programs of dictionary-coded distance rounds (every tile of a regular mesh: 3 rounds) keep their constraint
+    // Short programs of dictionary-coded distance groups (every tile of a regular mesh: 3 groups) keep their constraint
     // slots and rest lengths in registers: one batch of LDS reads ahead of the first round instead of two dependent LDS
     // round trips (slot, then palette entry) at the head of every round, in both passes. Same constraints, same order.
     constexpr int kRegRounds = THREADS >= 256 ? SB_REG_ROUNDS : SB_REG_ROUNDS_NARROW;
@@ -603,135 +603,141 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
             for (int r = 0; r < kRegRounds; ++r) if (r < n_rounds_all) reg_round(rs[r], rl[r], rcnt[r]);
         }
     } else {
-    uint32_t off = d_lo;    // dword offset (from the tile's stream start) of the current round's data
+    uint32_t off = d_lo;    // dword offset (from the tile's stream start) of the current group's data
 #if defined(SB_ABLATE) && SB_ABLATE == 1   // timing experiment only: memory traffic without the rounds
     for (int v = v_begin; v < v_end; v += 100000) {
 #else
     for (int v = v_begin; v < v_end; ++v) {
 #endif
+        if (v == R) { mark_step(); lds_barrier(); continue; }     // (virtual) MARK step between the two passes
         const int r = v < R ? v : v - R - 1;
         if (v == R + 1) off = d_lo;          // the second pass walks the same list again
-        uint32_t w = 3u << 10;               // v == R: the MARK step
-        if (v != R) {
-            if (rounds_in_lanes) w = (uint32_t)__builtin_amdgcn_readlane((int)rwl, __builtin_amdgcn_readfirstlane(r));
-            else if (rounds_in_lds) w = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rounds[r]);
-            else w = (uint32_t)__builtin_amdgcn_readfirstlane((int)tstream[r]);
+        uint32_t w;
+        if (rounds_in_lanes) w = (uint32_t)__builtin_amdgcn_readlane((int)rwl, __builtin_amdgcn_readfirstlane(r));
+        else if (rounds_in_lds) w = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rounds[r]);
+        else w = (uint32_t)__builtin_amdgcn_readfirstlane((int)tstream[r]);
+        // group word: distance | volume << 10 | bending << 20 constraint counts, bit 30 = dictionary-coded distance slots
+        const int cnt = w & 1023u, n_vol = (w >> 10) & 1023u, n_bend = (w >> 20) & 1023u;
+        const bool compact = (w >> 30) & 1u;
+        const uint32_t dsize = compact ? ((cnt + 3u) & ~3u) : ((2u * cnt + 3u) & ~3u);
+        const uint32_t size = dsize + 4u * (uint32_t)(n_vol + n_bend);
+        if (off + size > win_lo + win || off < win_lo) {   // refill the window (uniform; rare for small tiles)
+            lds_barrier();
+            win_lo = off;
+            load_window(win_lo);
+            __syncthreads();
         }
-        const int cnt = w & 1023u, type = (w >> 10) & 7u;
-        if (type == 3) {
-            mark_step();
-        } else {
-            const uint32_t size = type == 0 ? ((2u * cnt + 3u) & ~3u) : (type == 4 ? ((cnt + 3u) & ~3u) : 4u * cnt);
-            if (off + size > win_lo + win || off < win_lo) {   // refill the window (uniform; rare for small tiles)
-                lds_barrier();
-                win_lo = off;
-                load_window(win_lo);
-                __syncthreads();
-            }
-            const uint32_t *base = cbuf + (off - win_lo);
-            if (kCPL == 1 && type == 0) {
-                if (tid < cnt) {
-                    const uint2 e = *reinterpret_cast<const uint2 *>(base + 2 * tid);
-                    const int i = e.x & 0xffffu, k = e.x >> 16;
-                    float4 a = lds_pos[i], b = lds_pos[k];
-#if defined(SB_ABLATE) && SB_ABLATE == 2   // timing experiment only: LDS traffic + barriers without the arithmetic
-                    a.x += __uint_as_float(e.y); b.x -= tp.at_d;
-                    lds_pos[i] = a; lds_pos[k] = b;
-#else
-                    if (project_distance(a, b, __uint_as_float(e.y), tp.at_d)) { lds_pos[i] = a; lds_pos[k] = b; }
-#endif
-                }
-            } else if (kCPL == 1 && type == 4) {
-                if (tid < cnt) {
-                    const uint32_t e = base[tid];
-                    const int i = e & 0xfffu, k = (e >> 12) & 0xfffu;
-                    const float L0 = s_pal[e >> 24];
-                    float4 a = lds_pos[i], b = lds_pos[k];
-#if defined(SB_ABLATE) && SB_ABLATE == 2
-                    a.x += L0; b.x -= tp.at_d;
-                    lds_pos[i] = a; lds_pos[k] = b;
-#else
-                    if (project_distance(a, b, L0, tp.at_d)) { lds_pos[i] = a; lds_pos[k] = b; }
-#endif
-                }
-            } else if (type == 0 || type == 4) {
-                // kCPL independent constraints per lane: fetch all slots, gather all operands, project, scatter. Lanes
-                // past the end of the round re-read its first slot (always present) and drop the result.
-                int ci[kCPL], ck[kCPL];
-                float cL0[kCPL];
-                bool con[kCPL];
-                f32x4 ca[kCPL], cb[kCPL];
-                if (type == 0) {
-#pragma unroll
-                    for (int u = 0; u < kCPL; ++u) {
-                        const int c = tid + u * kTileThreads;
-                        con[u] = c < cnt;
-                        const uint2 e = *reinterpret_cast<const uint2 *>(base + 2 * (con[u] ? c : 0));
-                        ci[u] = e.x & 0xffffu; ck[u] = e.x >> 16; cL0[u] = __uint_as_float(e.y);
+        const uint32_t *base = cbuf + (off - win_lo);
+        if (QUADS) {
+            // A group may hold constraints of all three types (they share no particle): its hinges, tets and springs go
+            // to different WAVES -- wave slot sw covers 16 four-lane constraints or 64 springs, hinges first (the longest
+            // projection starts first) -- so a group lasts as long as its slowest type, not the sum of the three.
+            const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+            const int n_wb = (n_bend + 15) >> 4, n_wv = (n_vol + 15) >> 4, n_wd = (cnt + 63) >> 6;
+            const uint32_t *qbase = base + dsize;                 // the group's tets, then its hinges
+            float *lds_f = reinterpret_cast<float *>(lds_pos);
+            const int q = tid & 3;
+#pragma unroll 1
+            for (int sw = wave; sw < n_wb + n_wv + n_wd; sw += kTileThreads / 64) {
+                if (sw < n_wb + n_wv) {
+                    // four lanes per constraint (see project_volume_quad): lane q of a quad reads component q of the four
+                    // particles (lane 3: their inverse masses), writes component q back
+                    const bool bend = sw < n_wb;
+                    const int c = (bend ? sw : sw - n_wb) * 16 + (lane >> 2);
+                    if (c < (bend ? n_bend : n_vol)) {
+                        const uint4 e = *reinterpret_cast<const uint4 *>(qbase + 4 * (bend ? n_vol + c : c));
+                        const int o0 = 4 * (int)(e.x & 0xffffu) + q, o1 = 4 * (int)(e.x >> 16) + q;
+                        const int o2 = 4 * (int)(e.y & 0xffffu) + q, o3 = 4 * (int)(e.y >> 16) + q;
+                        float P[4] = {lds_f[o0], lds_f[o1], lds_f[o2], lds_f[o3]};
+                        const bool ok = bend ? project_bending_quad(P, __uint_as_float(e.z), __uint_as_float(e.w), tp.at_b, q)
+                                             : project_volume_quad(P, __uint_as_float(e.z), tp.at_v);
+                        if (ok && q < 3) { lds_f[o0] = P[0]; lds_f[o1] = P[1]; lds_f[o2] = P[2]; lds_f[o3] = P[3]; }
                     }
                 } else {
-                    uint32_t ce[kCPL];
-#pragma unroll
-                    for (int u = 0; u < kCPL; ++u) {
-                        const int c = tid + u * kTileThreads;
-                        con[u] = c < cnt;
-                        ce[u] = base[con[u] ? c : 0];
+                    const int c = (sw - n_wb - n_wv) * 64 + lane;
+                    if (c < cnt) {
+                        int i, k;
+                        float L0;
+                        if (compact) {
+                            const uint32_t e = base[c];
+                            i = e & 0xfffu; k = (e >> 12) & 0xfffu; L0 = s_pal[e >> 24];
+                        } else {
+                            const uint2 e = *reinterpret_cast<const uint2 *>(base + 2 * c);
+                            i = e.x & 0xffffu; k = e.x >> 16; L0 = __uint_as_float(e.y);
+                        }
+                        float4 a = lds_pos[i], b = lds_pos[k];
+                        if (project_distance(a, b, L0, tp.at_d)) { lds_pos[i] = a; lds_pos[k] = b; }
                     }
-#pragma unroll
-                    for (int u = 0; u < kCPL; ++u) { ci[u] = ce[u] & 0xfffu; ck[u] = (ce[u] >> 12) & 0xfffu; cL0[u] = s_pal[ce[u] >> 24]; }
                 }
-#pragma unroll
-                for (int u = 0; u < kCPL; ++u) {
-                    ca[u] = *reinterpret_cast<const f32x4 *>(lds_pos + ci[u]);
-                    cb[u] = *reinterpret_cast<const f32x4 *>(lds_pos + ck[u]);
+            }
+        } else if (kCPL == 1) {
+            if (tid < cnt) {
+                int i, k;
+                float L0;
+                if (compact) {
+                    const uint32_t e = base[tid];
+                    i = e & 0xfffu; k = (e >> 12) & 0xfffu; L0 = s_pal[e >> 24];
+                } else {
+                    const uint2 e = *reinterpret_cast<const uint2 *>(base + 2 * tid);
+                    i = e.x & 0xffffu; k = e.x >> 16; L0 = __uint_as_float(e.y);
                 }
-#pragma unroll
-                for (int u = 0; u < kCPL; ++u) {
-                    float4 a = make_float4(ca[u].x, ca[u].y, ca[u].z, ca[u].w), b = make_float4(cb[u].x, cb[u].y, cb[u].z, cb[u].w);
-                    con[u] = project_distance_nobranch(a, b, cL0[u], tp.at_d) && con[u];
-                    ca[u].x = a.x; ca[u].y = a.y; ca[u].z = a.z; cb[u].x = b.x; cb[u].y = b.y; cb[u].z = b.z;
-                }
-                // Unconditional stores: an idle lane or a skipped constraint writes to a spare LDS slot instead. With the
-                // stores under `if (ok)` the compiler sinks each projection into its own branch and runs them one after
-                // the other; this way the independent chains are scheduled together.
-#pragma unroll
-                for (int u = 0; u < kCPL; ++u) {
-                    f32x3 *da = con[u] ? reinterpret_cast<f32x3 *>(lds_pos + ci[u]) : lds_spare;
-                    f32x3 *db = con[u] ? reinterpret_cast<f32x3 *>(lds_pos + ck[u]) : lds_spare;
-                    *da = (f32x3){ca[u].x, ca[u].y, ca[u].z};
-                    *db = (f32x3){cb[u].x, cb[u].y, cb[u].z};
-                }
-            } else if (QUADS) {
-#ifdef SB_QUADS_ONE_LANE   // A/B timing builds: one lane per 4-vertex constraint
-#pragma unroll 1
-                for (int c = tid; c < cnt; c += kTileThreads) {
-                    const uint4 e = *reinterpret_cast<const uint4 *>(base + 4 * c);
-                    const int i0 = e.x & 0xffffu, i1 = e.x >> 16, i2 = e.y & 0xffffu, i3 = e.y >> 16;
-                    const float2 rest = make_float2(__uint_as_float(e.z), __uint_as_float(e.w));
-                    float4 p0 = lds_pos[i0], p1 = lds_pos[i1], p2 = lds_pos[i2], p3 = lds_pos[i3];
-                    bool ok = type == 1 ? project_volume(p0, p1, p2, p3, rest.x, tp.at_v)
-                                        : project_bending(p0, p1, p2, p3, rest, tp.at_b);
-                    if (ok) { lds_pos[i0] = p0; lds_pos[i1] = p1; lds_pos[i2] = p2; lds_pos[i3] = p3; }
-                }
+                float4 a = lds_pos[i], b = lds_pos[k];
+#if defined(SB_ABLATE) && SB_ABLATE == 2   // timing experiment only: LDS traffic + barriers without the arithmetic
+                a.x += L0; b.x -= tp.at_d;
+                lds_pos[i] = a; lds_pos[k] = b;
 #else
-                // four lanes per constraint (see project_volume_quad): lane q of a quad reads component q of the four
-                // particles (lane 3: their inverse masses), writes component q back
-                float *lds_f = reinterpret_cast<float *>(lds_pos);
-                const int q = tid & 3;
-#pragma unroll 1
-                for (int c = tid >> 2; c < cnt; c += kTileThreads / 4) {
-                    const uint4 e = *reinterpret_cast<const uint4 *>(base + 4 * c);
-                    const int o0 = 4 * (int)(e.x & 0xffffu) + q, o1 = 4 * (int)(e.x >> 16) + q;
-                    const int o2 = 4 * (int)(e.y & 0xffffu) + q, o3 = 4 * (int)(e.y >> 16) + q;
-                    float P[4] = {lds_f[o0], lds_f[o1], lds_f[o2], lds_f[o3]};
-                    const bool ok = type == 1 ? project_volume_quad(P, __uint_as_float(e.z), tp.at_v)
-                                              : project_bending_quad(P, __uint_as_float(e.z), __uint_as_float(e.w), tp.at_b, q);
-                    if (ok && q < 3) { lds_f[o0] = P[0]; lds_f[o1] = P[1]; lds_f[o2] = P[2]; lds_f[o3] = P[3]; }
-                }
+                if (project_distance(a, b, L0, tp.at_d)) { lds_pos[i] = a; lds_pos[k] = b; }
 #endif
             }
-            off += size;
+        } else {
+            // kCPL independent constraints per lane: fetch all slots, gather all operands, project, scatter. Lanes
+            // past the end of the round re-read its first slot (always present) and drop the result.
+            int ci[kCPL], ck[kCPL];
+            float cL0[kCPL];
+            bool con[kCPL];
+            f32x4 ca[kCPL], cb[kCPL];
+            if (!compact) {
+#pragma unroll
+                for (int u = 0; u < kCPL; ++u) {
+                    const int c = tid + u * kTileThreads;
+                    con[u] = c < cnt;
+                    const uint2 e = *reinterpret_cast<const uint2 *>(base + 2 * (con[u] ? c : 0));
+                    ci[u] = e.x & 0xffffu; ck[u] = e.x >> 16; cL0[u] = __uint_as_float(e.y);
+                }
+            } else {
+                uint32_t ce[kCPL];
+#pragma unroll
+                for (int u = 0; u < kCPL; ++u) {
+                    const int c = tid + u * kTileThreads;
+                    con[u] = c < cnt;
+                    ce[u] = base[con[u] ? c : 0];
+                }
+#pragma unroll
+                for (int u = 0; u < kCPL; ++u) { ci[u] = ce[u] & 0xfffu; ck[u] = (ce[u] >> 12) & 0xfffu; cL0[u] = s_pal[ce[u] >> 24]; }
+            }
+#pragma unroll
+            for (int u = 0; u < kCPL; ++u) {
+                ca[u] = *reinterpret_cast<const f32x4 *>(lds_pos + ci[u]);
+                cb[u] = *reinterpret_cast<const f32x4 *>(lds_pos + ck[u]);
+            }
+#pragma unroll
+            for (int u = 0; u < kCPL; ++u) {
+                float4 a = make_float4(ca[u].x, ca[u].y, ca[u].z, ca[u].w), b = make_float4(cb[u].x, cb[u].y, cb[u].z, cb[u].w);
+                con[u] = project_distance_nobranch(a, b, cL0[u], tp.at_d) && con[u];
+                ca[u].x = a.x; ca[u].y = a.y; ca[u].z = a.z; cb[u].x = b.x; cb[u].y = b.y; cb[u].z = b.z;
+            }
+            // Unconditional stores: an idle lane or a skipped constraint writes to a spare LDS slot instead. With the
+            // stores under `if (ok)` the compiler sinks each projection into its own branch and runs them one after
+            // the other; this way the independent chains are scheduled together.
+#pragma unroll
+            for (int u = 0; u < kCPL; ++u) {
+                f32x3 *da = con[u] ? reinterpret_cast<f32x3 *>(lds_pos + ci[u]) : lds_spare;
+                f32x3 *db = con[u] ? reinterpret_cast<f32x3 *>(lds_pos + ck[u]) : lds_spare;
+                *da = (f32x3){ca[u].x, ca[u].y, ca[u].z};
+                *db = (f32x3){cb[u].x, cb[u].y, cb[u].z};
+            }
         }
+        off += size;
 #if defined(SB_ABLATE) && SB_ABLATE == 3   // timing experiment only (WRONG results): rounds without the workgroup barrier
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #else

@@ -127,13 +127,14 @@ void resolve_dims(int world, const float ext[3], const int want[3], int dims[3])
 // the general routine below with masks as wide as it takes -- same rule (lowest colour free at every endpoint,
 // constraints in the given order), so the result for <= 128 colours is the same either way.
 template <class GetVerts>
-int greedy_colour_wide(int64_t count, int nverts, GetVerts get, size_t index_space, std::vector<int> &colour_out) {
+int greedy_colour_wide(int64_t count, GetVerts get, size_t index_space, std::vector<int> &colour_out) {
     colour_out.assign(count, 0);
     std::vector<std::vector<uint64_t>> used(index_space);     // only touched indices ever grow
     std::vector<uint64_t> m;
     int ncol = 0;
     for (int64_t k = 0; k < count; ++k) {
-        const int32_t *v = get(k);
+        int nverts;
+        const int32_t *v = get(k, nverts);
         m.clear();
         for (int a = 0; a < nverts; ++a) {
             const std::vector<uint64_t> &u = used[v[a]];
@@ -154,12 +155,15 @@ int greedy_colour_wide(int64_t count, int nverts, GetVerts get, size_t index_spa
     return ncol;
 }
 
+// get(k, nverts) returns the index list of constraint k and its length (2 or 4): constraints of different types may be
+// coloured together.
 template <class GetVerts>
-int greedy_colour(int64_t count, int nverts, GetVerts get, std::vector<Mask128> &used, std::vector<int> &colour_out) {
+int greedy_colour(int64_t count, GetVerts get, std::vector<Mask128> &used, std::vector<int> &colour_out) {
     colour_out.resize(count);
     int ncol = 0;
     for (int64_t k = 0; k < count; ++k) {
-        const int32_t *v = get(k);
+        int nverts;
+        const int32_t *v = get(k, nverts);
         Mask128 m;
         for (int a = 0; a < nverts; ++a) m = m | used[v[a]];
         int c = first_free(m);
@@ -169,10 +173,11 @@ int greedy_colour(int64_t count, int nverts, GetVerts get, std::vector<Mask128> 
         ncol = std::max(ncol, c + 1);
     }
     for (int64_t k = 0; k < count; ++k) {
-        const int32_t *v = get(k);
+        int nverts;
+        const int32_t *v = get(k, nverts);
         for (int a = 0; a < nverts; ++a) used[v[a]] = Mask128();
     }
-    if (ncol < 0) ncol = greedy_colour_wide(count, nverts, get, used.size(), colour_out);
+    if (ncol < 0) ncol = greedy_colour_wide(count, get, used.size(), colour_out);
     return ncol;
 }
 
@@ -224,6 +229,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
     if (opts.world < 1 || opts.rank < 0 || opts.rank >= opts.world) throw std::runtime_error("bad rank/world");
     PlanTimer timer;
     const bool bank_aware = opts.bank_aware_lanes;
+    const bool mixed_groups = opts.mixed_groups;
     Cons C{&in};
     P.n = n;
     P.m[0] = in.m_d; P.m[1] = in.m_v; P.m[2] = in.m_b;
@@ -634,8 +640,9 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         parallel_chunks(nt, kTilesPerChunk, [&](int64_t ch, int64_t cb, int64_t ce) {
             Piece &Q = pieces[(size_t)ch];
             std::vector<Mask128> used((size_t)kMaxTileLocal);
-            std::vector<int> col_tmp;
-            std::vector<int32_t> lv;
+            std::vector<int> col_all, col_t[3];
+            std::vector<int32_t> lv[3];
+            std::vector<std::vector<int32_t>> by[3];
             for (int64_t ci = cb; ci < ce; ++ci) {
                 const int32_t c = tile_begin + (int32_t)ci;
                 Tile &tile = TT.tiles[c];
@@ -643,20 +650,55 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
                 tile.round_begin = (int32_t)Q.rounds.size();
                 tile.d_begin = (int64_t)Q.t_dist.size(); tile.q_begin = (int64_t)Q.t_quad_id.size();
                 tile.seq_begin = (int64_t)Q.seq_id.size();
+                // the tile's constraints of every type, tile-local particle indices
+                const int32_t *it[3];
+                int64_t cnt[3];
                 for (int t = 0; t < 3; ++t) {
-                    const int32_t *it = lst[t].data() + off[t][ci];
-                    const int64_t cnt = off[t][ci + 1] - off[t][ci];
-                    if (cnt == 0) continue;
+                    it[t] = lst[t].data() + off[t][ci];
+                    cnt[t] = off[t][ci + 1] - off[t][ci];
                     const int nv = kVerts[t];
-                    lv.resize((size_t)cnt * nv);
-                    for (int64_t k = 0; k < cnt; ++k) {
-                        const int32_t *v = C.idx(t, it[k]);
-                        for (int a = 0; a < nv; ++a) lv[k * nv + a] = lmap[P.new_of_old[v[a]]];
+                    lv[t].resize((size_t)cnt[t] * nv);
+                    for (int64_t k = 0; k < cnt[t]; ++k) {
+                        const int32_t *v = C.idx(t, it[t][k]);
+                        for (int a = 0; a < nv; ++a) lv[t][k * nv + a] = lmap[P.new_of_old[v[a]]];
                     }
-                    int ncol = greedy_colour(cnt, nv, [&](int64_t k) { return lv.data() + (size_t)k * nv; }, used, col_tmp);
-                    std::vector<std::vector<int32_t>> by(ncol);
-                    for (int64_t k = 0; k < cnt; ++k) by[col_tmp[k]].push_back((int32_t)k);
-                    for (auto &colv : by) {
+                }
+                // Colours -> groups. A group is a set of constraints of the tile that share no particle: the kernel
+                // projects a group's constraints concurrently, one barrier per group. With mixed groups the three types
+                // are coloured TOGETHER (hinges first, then tets, then springs: the long projections get the low
+                // colours), so a tile needs about as many groups as its busiest particle has constraints instead of the
+                // sum of the per-type colour counts; otherwise each type is coloured on its own, springs first.
+                // Either way a mesh with springs only gets the same groups.
+                int ncol_t[3] = {0, 0, 0}, col_base[3] = {0, 0, 0}, ncol = 0;
+                if (mixed_groups && (cnt[1] > 0 || cnt[2] > 0)) {
+                    const int64_t total = cnt[0] + cnt[1] + cnt[2];
+                    const int64_t b1 = cnt[2], b0 = cnt[2] + cnt[1];        // sequence: bending, volume, distance
+                    ncol = greedy_colour(total, [&](int64_t k, int &nvo) {
+                        if (k < b1) { nvo = 4; return (const int32_t *)lv[2].data() + (size_t)k * 4; }
+                        if (k < b0) { nvo = 4; return (const int32_t *)lv[1].data() + (size_t)(k - b1) * 4; }
+                        nvo = 2; return (const int32_t *)lv[0].data() + (size_t)(k - b0) * 2;
+                    }, used, col_all);
+                    col_t[2].assign(col_all.begin(), col_all.begin() + b1);
+                    col_t[1].assign(col_all.begin() + b1, col_all.begin() + b0);
+                    col_t[0].assign(col_all.begin() + b0, col_all.end());
+                } else {
+                    for (int t = 0; t < 3; ++t) {
+                        if (cnt[t] == 0) continue;
+                        const int nv = kVerts[t];
+                        ncol_t[t] = greedy_colour(cnt[t], [&](int64_t k, int &nvo) { nvo = nv; return (const int32_t *)lv[t].data() + (size_t)k * nv; }, used, col_t[t]);
+                    }
+                    col_base[1] = ncol_t[0]; col_base[2] = ncol_t[0] + ncol_t[1];
+                    ncol = ncol_t[0] + ncol_t[1] + ncol_t[2];
+                }
+                for (int t = 0; t < 3; ++t) {
+                    by[t].assign((size_t)ncol, {});
+                    for (int64_t k = 0; k < cnt[t]; ++k) by[t][(size_t)(col_base[t] + col_t[t][k])].push_back((int32_t)k);
+                }
+                for (int c = 0; c < ncol; ++c) {
+                    size_t pieces = 0;
+                    for (int t = 0; t < 3; ++t) {
+                        std::vector<int32_t> &colv = by[t][(size_t)c];
+                        const int nv = kVerts[t];
                         if (bank_aware && colv.size() > (size_t)kLdsGroup) {
                             // Lane order inside a colour is free (its constraints share no particle). The LDS serves a 16-byte
                             // gather or scatter for kLdsGroup lanes per cycle, conflict-free when their float4 indices differ
@@ -664,7 +706,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
                             // distinct first indices and, where the choice allows, distinct second indices (bank conflicts of
                             // the mid-tick kernel at 256^3: 21.2 M -> 9.5 M cycles per launch, SQ_LDS_BANK_CONFLICT).
                             std::vector<std::vector<int32_t>> bucket((size_t)kLdsGroup);
-                            for (int32_t k : colv) bucket[lv[(size_t)k * nv] % kLdsGroup].push_back(k);
+                            for (int32_t k : colv) bucket[lv[t][(size_t)k * nv] % kLdsGroup].push_back(k);
                             colv.clear();
                             for (bool any = true; any;) {
                                 any = false;
@@ -675,34 +717,41 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
                                     size_t pick = bq.size() - 1;
                                     for (size_t d = 0; d < bq.size(); ++d) {
                                         const size_t q = bq.size() - 1 - d;
-                                        if (!((used_j >> (lv[(size_t)bq[q] * nv + 1] % kLdsGroup)) & 1u)) { pick = q; break; }
+                                        if (!((used_j >> (lv[t][(size_t)bq[q] * nv + 1] % kLdsGroup)) & 1u)) { pick = q; break; }
                                     }
-                                    used_j |= 1u << (lv[(size_t)bq[pick] * nv + 1] % kLdsGroup);
+                                    used_j |= 1u << (lv[t][(size_t)bq[pick] * nv + 1] % kLdsGroup);
                                     colv.push_back(bq[pick]);
                                     bq.erase(bq.begin() + (std::ptrdiff_t)pick);
                                 }
                             }
                         }
-                        for (size_t s0 = 0; s0 < colv.size(); s0 += kRoundThreads) {
-                            size_t s1 = std::min(colv.size(), s0 + kRoundThreads);
-                            Q.rounds.push_back((uint32_t)(s1 - s0) | ((uint32_t)t << 10));
+                        pieces = std::max(pieces, (colv.size() + kRoundThreads - 1) / kRoundThreads);
+                    }
+                    // a colour with more than kRoundThreads constraints of a type is cut into several groups
+                    for (size_t piece = 0; piece < pieces; ++piece) {
+                        uint32_t word = 0;
+                        for (int t = 0; t < 3; ++t) {
+                            const std::vector<int32_t> &colv = by[t][(size_t)c];
+                            const size_t s0 = std::min(colv.size(), piece * kRoundThreads), s1 = std::min(colv.size(), s0 + kRoundThreads);
+                            word |= (uint32_t)(s1 - s0) << (10 * t);
                             for (size_t q = s0; q < s1; ++q) {
                                 const int32_t k = colv[q];
-                                const int32_t *l = lv.data() + (size_t)k * nv;
+                                const int32_t *l = lv[t].data() + (size_t)k * kVerts[t];
                                 if (t == 0) {
                                     Q.t_dist.push_back((uint32_t)l[0] | ((uint32_t)l[1] << 16));
-                                    Q.t_dist_id.push_back(it[k]);
+                                    Q.t_dist_id.push_back(it[t][k]);
                                 } else {
                                     Q.t_quad.push_back((uint32_t)l[0] | ((uint32_t)l[1] << 16));
                                     Q.t_quad.push_back((uint32_t)l[2] | ((uint32_t)l[3] << 16));
-                                    Q.t_quad_id.push_back(it[k]);
+                                    Q.t_quad_id.push_back(it[t][k]);
                                     Q.t_quad_type.push_back((uint8_t)t);
                                 }
                                 Q.seq_type.push_back((uint8_t)t);
-                                Q.seq_id.push_back(it[k]);
+                                Q.seq_id.push_back(it[t][k]);
                             }
-                            Q.seq_groups.push_back((int64_t)Q.seq_id.size());
                         }
+                        Q.rounds.push_back(word);
+                        Q.seq_groups.push_back((int64_t)Q.seq_id.size());
                     }
                 }
                 tile.seq_end = (int64_t)Q.seq_id.size();
@@ -851,7 +900,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
             if (left.empty()) continue;
             if (gused.empty()) gused.assign(n, Mask128());
             const int nv = kVerts[t];
-            int ncol = greedy_colour((int64_t)left.size(), nv, [&](int64_t k) { return C.idx(t, left[k]); }, gused, colr);
+            int ncol = greedy_colour((int64_t)left.size(), [&](int64_t k, int &nvo) { nvo = nv; return C.idx(t, left[k]); }, gused, colr);
             size_t base = P.gcolours.size();
             P.gcolours.resize(base + ncol);
             for (int c = 0; c < ncol; ++c) P.gcolours[base + c].type = t;

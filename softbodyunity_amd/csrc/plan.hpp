@@ -33,6 +33,7 @@ struct Opts {
     int dims[3] = {0, 0, 0};
     int tile_particles = 512;  // -1: no tiling
     bool third_tiling = true;       // constraints inside neither T0 nor T1 get LDS tiles of their own (T2) where they can (SB_NO_T2: A/B runs)
+    bool mixed_groups = true;       // colour the constraint types of a tile together (SB_NO_MIXED_GROUPS: one type per group, A/B runs)
     bool bank_aware_lanes = true;   // order the constraints of a round for conflict-free LDS gathers (SB_NO_BANK_ORDER: A/B runs)
 };
 
@@ -41,7 +42,7 @@ struct Run {            // a contiguous range of particles
     int32_t len;
 };
 
-constexpr int kRoundThreads = 256;          // constraints per round (one per lane of a 256-thread workgroup)
+constexpr int kRoundThreads = 256;          // constraints of one type per group (round)
 constexpr int kMaxTileLocal = 1024;         // particles staged per tile (4 per lane)
 constexpr int kMaxTileRuns = 64;
 constexpr int kMaxT2Layers = 6;             // shifted grids tried in turn for the constraints inside neither T0 nor T1
@@ -63,7 +64,7 @@ struct Tile {
 struct Tiling {
     std::vector<Tile> tiles;
     std::vector<Run> runs;
-    std::vector<uint32_t> rounds;
+    std::vector<uint32_t> rounds;       // one word per group of a tile: distance | volume << 10 | bending << 20 constraint counts (each <= kRoundThreads)
     // tile constraints in execution order, tile-local particle indices (16 bit each)
     std::vector<uint32_t> t_dist;       // lo16 = i, hi16 = j
     std::vector<int32_t> t_dist_id;     // original constraint id (for rest values)

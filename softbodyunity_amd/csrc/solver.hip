@@ -407,8 +407,8 @@ void build_device(sb_solver *s) {
             bool has_quads = false;
         };
         auto fbits = [](float f) { uint32_t u; std::memcpy(&u, &f, 4); return u; };
-        struct Part { int32_t member, cnt; int64_t first; };             // a member's round inside a pack round
-        struct PackRound { int type; int32_t cnt; std::vector<Part> parts; };
+        struct Part { int32_t member; int32_t cnt[3]; int64_t first_d, first_q; };   // a member's group inside a pack group
+        struct PackRound { int32_t cnt[3]; std::vector<Part> parts; };                 // constraints per type (distance, volume, bending)
         const bool no_palette = std::getenv("SB_NO_PALETTE") != nullptr;
         constexpr int64_t kPacksPerChunk = 128;
         const int64_t n_chunks = ((int64_t)packs.size() + kPacksPerChunk - 1) / kPacksPerChunk;
@@ -462,24 +462,20 @@ void build_device(sb_solver *s) {
                     const sbp::Tile &T = G.tiles[LT.tile_ids[members[m]]];
                     dk[m] = T.d_begin; qk[m] = T.q_begin;
                 }
-                for (;;) {
-                    int type = 4;     // every member lists its distance rounds first, then volume, then bending: lowest type first
-                    for (size_t m = 0; m < members.size(); ++m) {
-                        const sbp::Tile &T = G.tiles[LT.tile_ids[members[m]]];
-                        if (next[m] < T.n_rounds) type = std::min(type, (int)((G.rounds[T.round_begin + next[m]] >> 10) & 3u));
-                    }
-                    if (type == 4) break;
-                    PackRound R{type, 0, {}};
+                for (;;) {       // group r of the pack = the members' next groups, as many as fit (<= 256 constraints per type)
+                    PackRound R{{0, 0, 0}, {}};
                     for (size_t m = 0; m < members.size(); ++m) {
                         const sbp::Tile &T = G.tiles[LT.tile_ids[members[m]]];
                         if (next[m] >= T.n_rounds) continue;
                         const uint32_t w = G.rounds[T.round_begin + next[m]];
-                        const int32_t cnt = (int32_t)(w & 1023u);
-                        if ((int)((w >> 10) & 3u) != type || R.cnt + cnt > sbp::kRoundThreads) continue;
-                        int64_t &k = type == 0 ? dk[m] : qk[m];
-                        R.parts.push_back({(int32_t)m, cnt, k});
-                        k += cnt; R.cnt += cnt; ++next[m];
+                        const int32_t c[3] = {(int32_t)(w & 1023u), (int32_t)((w >> 10) & 1023u), (int32_t)((w >> 20) & 1023u)};
+                        if (R.cnt[0] + c[0] > sbp::kRoundThreads || R.cnt[1] + c[1] > sbp::kRoundThreads || R.cnt[2] + c[2] > sbp::kRoundThreads) continue;
+                        R.parts.push_back({(int32_t)m, {c[0], c[1], c[2]}, dk[m], qk[m]});
+                        dk[m] += c[0]; qk[m] += c[1] + c[2];
+                        for (int t = 0; t < 3; ++t) R.cnt[t] += c[t];
+                        ++next[m];
                     }
+                    if (R.parts.empty()) break;
                     prog.push_back(std::move(R));
                 }
                 for (size_t m = 0; m < members.size(); ++m) {
@@ -506,11 +502,8 @@ void build_device(sb_solver *s) {
                 vals.erase(std::unique(vals.begin(), vals.end()), vals.end());
                 if ((int)vals.size() <= sbk::kMaxPalette && td.n_local <= 4096) pal = vals; else compact = false;
             }
-            for (const PackRound &R : prog) {
-                uint32_t w = (uint32_t)R.cnt | ((uint32_t)R.type << 10);
-                if (compact && R.type == 0) w |= 4u << 10;     // distance -> dictionary-coded distance
-                stream.push_back(w);
-            }
+            for (const PackRound &R : prog)      // group word: counts per type, bit 30 = dictionary-coded distance slots
+                stream.push_back((uint32_t)R.cnt[0] | ((uint32_t)R.cnt[1] << 10) | ((uint32_t)R.cnt[2] << 20) | (compact ? 1u << 30 : 0u));
             while ((stream.size() - s0) & 3) stream.push_back(0);
             if (stream.size() == s0) stream.insert(stream.end(), 4, 0u);   // empty program: keep 16 readable bytes
             td.n_pal = (int32_t)pal.size();
@@ -520,30 +513,34 @@ void build_device(sb_solver *s) {
             max_rounds = std::max(max_rounds, td.n_rounds);
             td.s_hdr = (uint32_t)(stream.size() - s0);
             for (const PackRound &R : prog) {
+                // a group's data: its distance slots (padded to 4 dwords), then its volume slots, then its bending slots
                 for (const Part &pt : R.parts) {
                     const uint32_t b = (uint32_t)base[pt.member], b2 = b | (b << 16);   // added to both 16-bit local indices
-                    if (R.type == 0) {
-                        for (int64_t k = pt.first; k < pt.first + pt.cnt; ++k) {
-                            const uint32_t idx = G.t_dist[k] + b2, rb = fbits(s->dist_rest[G.t_dist_id[k]]);
-                            if (compact) {
-                                const uint32_t pi = (uint32_t)(std::lower_bound(pal.begin(), pal.end(), rb) - pal.begin());
-                                stream.push_back((idx & 0xffffu) | ((idx >> 16) << 12) | (pi << 24));
-                            } else {
-                                stream.push_back(idx);
-                                stream.push_back(rb);
-                            }
-                        }
-                    } else {
-                        Q.has_quads = true;
-                        for (int64_t k = pt.first; k < pt.first + pt.cnt; ++k) {
-                            stream.push_back(G.t_quad[2 * k] + b2); stream.push_back(G.t_quad[2 * k + 1] + b2);
-                            const int32_t id = G.t_quad_id[k];
-                            if (G.t_quad_type[k] == 1) { volatile float r6 = 6.0f * s->vol_rest[id]; stream.push_back(fbits(r6)); stream.push_back(0); }
-                            else { stream.push_back(fbits(s->bend_rest[2 * (size_t)id])); stream.push_back(fbits(s->bend_rest[2 * (size_t)id + 1])); }
+                    for (int64_t k = pt.first_d; k < pt.first_d + pt.cnt[0]; ++k) {
+                        const uint32_t idx = G.t_dist[k] + b2, rb = fbits(s->dist_rest[G.t_dist_id[k]]);
+                        if (compact) {
+                            const uint32_t pi = (uint32_t)(std::lower_bound(pal.begin(), pal.end(), rb) - pal.begin());
+                            stream.push_back((idx & 0xffffu) | ((idx >> 16) << 12) | (pi << 24));
+                        } else {
+                            stream.push_back(idx);
+                            stream.push_back(rb);
                         }
                     }
                 }
-                if (R.type == 0) while ((stream.size() - s0) & 3) stream.push_back(0);
+                while ((stream.size() - s0) & 3) stream.push_back(0);
+                for (int t = 1; t < 3; ++t)
+                    for (const Part &pt : R.parts) {
+                        const uint32_t b = (uint32_t)base[pt.member], b2 = b | (b << 16);
+                        const int64_t kb = pt.first_q + (t == 2 ? pt.cnt[1] : 0);      // a member's group lists its tets, then its hinges
+                        for (int64_t k = kb; k < kb + pt.cnt[t]; ++k) {
+                            if (G.t_quad_type[k] != t) throw std::runtime_error("internal: group layout");
+                            Q.has_quads = true;
+                            stream.push_back(G.t_quad[2 * k] + b2); stream.push_back(G.t_quad[2 * k + 1] + b2);
+                            const int32_t id = G.t_quad_id[k];
+                            if (t == 1) { volatile float r6 = 6.0f * s->vol_rest[id]; stream.push_back(fbits(r6)); stream.push_back(0); }
+                            else { stream.push_back(fbits(s->bend_rest[2 * (size_t)id])); stream.push_back(fbits(s->bend_rest[2 * (size_t)id + 1])); }
+                        }
+                    }
             }
             td.s_len = (uint32_t)(stream.size() - s0);
             max_data = std::max(max_data, td.s_len - td.s_hdr);
@@ -1012,6 +1009,7 @@ int sb_finalize(sb_solver *s) {
         o.tile_particles = s->desc.tile_particles;
         o.bank_aware_lanes = !std::getenv("SB_NO_BANK_ORDER");
         o.third_tiling = !std::getenv("SB_NO_T2");
+        o.mixed_groups = !std::getenv("SB_NO_MIXED_GROUPS");
         s->plan = std::make_unique<sb_plan>();
         const bool timing = std::getenv("SB_PLAN_TIMING") != nullptr;
         auto t0 = std::chrono::steady_clock::now();
@@ -1480,6 +1478,7 @@ int sb_plan_build(const float *rest, int32_t n, const int32_t *dist_ij, int32_t 
         }
         o.bank_aware_lanes = !std::getenv("SB_NO_BANK_ORDER");
         o.third_tiling = !std::getenv("SB_NO_T2");
+        o.mixed_groups = !std::getenv("SB_NO_MIXED_GROUPS");
         sbp::Input in = make_input(rest, n, dist_ij, m_d, vol, m_v, bend, m_b);
         auto p = std::make_unique<sb_plan>();
         sbp::build_plan(in, o, p->plan);
