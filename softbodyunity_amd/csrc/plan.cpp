@@ -807,7 +807,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
     if (tiling && opts.third_tiling) {
         struct Cand { int64_t key; uint8_t type; int32_t id; };
         std::vector<Cand> cand;
-        std::vector<int32_t> t2_of_old, lidx2, members;
+        std::vector<int32_t> t2_of_old, lidx2, members, uf_parent, uf_size, uf_tile, uf_ptile;
         // layer shifts (fractions of a cell): first the middle of the widest gap between the T0 and T1 planes, then a
         // golden-ratio walk, skipping positions within 6 % of a cell of any plane already in use
         std::vector<double> planes = {0.0, shift_frac, 1.0};
@@ -833,16 +833,75 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
             cand.clear();
             int64_t left = 0;
             for (int t = 0; t < 3; ++t)
-                for (int64_t k = 0; k < C.count(t); ++k) {
-                    if (own[t][k] != 2) continue;
-                    ++left;
-                    const int32_t *v = C.idx(t, k);
-                    const int64_t c0 = cell2(v[0]);
-                    bool same = true;
-                    for (int a = 1; a < kVerts[t]; ++a) same &= cell2(v[a]) == c0;
-                    if (same) cand.push_back({c0, (uint8_t)t, (int32_t)k});
-                }
+                for (int64_t k = 0; k < C.count(t); ++k) left += own[t][k] == 2;
             if (left == 0) break;
+            // Few constraints left (they sit where the planes of the grids already tried cross): another grid would catch
+            // only part of them and every further layer is one more launch per substep. Cluster layer instead: the
+            // connected components of what is left become the sparse tiles -- a component shares no particle with any
+            // other, so they all fit ONE layer; only a component of more than kMaxTileLocal particles is cut, and the
+            // constraints across the cut wait for the next layer.
+            const bool cluster = opts.cluster_layers && layer > 0 && left <= std::max<int64_t>(4096, (P.m[0] + P.m[1] + P.m[2]) / 50);
+            if (cluster) {
+                std::vector<int32_t> &parent = uf_parent;
+                if (parent.empty()) parent.assign((size_t)n, -1);        // -1: not touched in this layer
+                std::vector<int32_t> touched;
+                auto find = [&](int32_t x) {
+                    while (parent[x] != x) { parent[x] = parent[parent[x]]; x = parent[x]; }
+                    return x;
+                };
+                for (int t = 0; t < 3; ++t)
+                    for (int64_t k = 0; k < C.count(t); ++k) {
+                        if (own[t][k] != 2) continue;
+                        const int32_t *v = C.idx(t, k);
+                        for (int a = 0; a < kVerts[t]; ++a) if (parent[v[a]] < 0) { parent[v[a]] = v[a]; touched.push_back(v[a]); }
+                        int32_t r0 = find(v[0]);
+                        for (int a = 1; a < kVerts[t]; ++a) {
+                            const int32_t ra = find(v[a]);
+                            if (ra != r0) { const int32_t lo = std::min(ra, r0), hi = std::max(ra, r0); parent[hi] = lo; r0 = lo; }
+                        }
+                    }
+                // particles per component, and a tile per component (or per piece of an over-full one), in constraint order
+                std::vector<int32_t> &csize = uf_size, &ctile = uf_tile, &ptile = uf_ptile;
+                if (csize.empty()) { csize.assign((size_t)n, 0); ctile.assign((size_t)n, -1); ptile.assign((size_t)n, -1); }
+                for (int32_t p : touched) ++csize[find(p)];
+                int32_t n_new = 0;
+                std::vector<int32_t> fill;                                  // particles in each new tile
+                for (int t = 0; t < 3; ++t)
+                    for (int64_t k = 0; k < C.count(t); ++k) {
+                        if (own[t][k] != 2) continue;
+                        const int32_t *v = C.idx(t, k);
+                        const int32_t root = find(v[0]);
+                        const int nv = kVerts[t];
+                        int32_t tile = -1;
+                        if (csize[root] <= kMaxTileLocal) {                 // the whole component is one tile
+                            if (ctile[root] < 0) { ctile[root] = n_new++; fill.push_back(csize[root]); }
+                            tile = ctile[root];
+                        } else {                                            // over-full component: fill tiles greedily
+                            int32_t seen = -1, fresh = 0; bool two = false;
+                            for (int a = 0; a < nv; ++a) {
+                                const int32_t pt = ptile[v[a]];
+                                if (pt < 0) ++fresh; else if (seen < 0) seen = pt; else if (pt != seen) two = true;
+                            }
+                            if (two) continue;                              // bridges two tiles of this layer: next layer
+                            if (seen < 0) { seen = ctile[root]; if (seen < 0 || fill[(size_t)seen] + fresh > kMaxTileLocal) { seen = n_new++; fill.push_back(0); ctile[root] = seen; } }
+                            else if (fill[(size_t)seen] + fresh > kMaxTileLocal) continue;
+                            tile = seen;
+                            for (int a = 0; a < nv; ++a) if (ptile[v[a]] < 0) { ptile[v[a]] = tile; ++fill[(size_t)tile]; }
+                        }
+                        cand.push_back({(int64_t)tile, (uint8_t)t, (int32_t)k});
+                    }
+                for (int32_t p : touched) { csize[p] = 0; ctile[p] = -1; ptile[p] = -1; parent[p] = -1; }
+            } else {
+                for (int t = 0; t < 3; ++t)
+                    for (int64_t k = 0; k < C.count(t); ++k) {
+                        if (own[t][k] != 2) continue;
+                        const int32_t *v = C.idx(t, k);
+                        const int64_t c0 = cell2(v[0]);
+                        bool same = true;
+                        for (int a = 1; a < kVerts[t]; ++a) same &= cell2(v[a]) == c0;
+                        if (same) cand.push_back({c0, (uint8_t)t, (int32_t)k});
+                    }
+            }
             if (cand.empty()) continue;
             std::stable_sort(cand.begin(), cand.end(), [](const Cand &x, const Cand &y) { return x.key < y.key; });
             t2_of_old.assign(n, -1);
