@@ -79,7 +79,12 @@ def test_ragged_cells_non_cubic_block_and_duplicate_springs(oracle_mod):
         _pair(oracle_mod, m, tile_particles=tile)
 
 
-def test_long_range_springs_go_to_global_colours(oracle_mod):
+@pytest.mark.parametrize("cluster_layers", [True, False])
+def test_long_range_springs_go_to_cluster_tiles_or_global_colours(oracle_mod, monkeypatch, cluster_layers):
+    # springs between random far-apart particles fit no grid cell of any tiling: their connected components become sparse
+    # cluster tiles (one T2 layer); with SB_NO_CLUSTER_LAYERS they fall through to the global-colour kernels
+    if not cluster_layers:
+        monkeypatch.setenv("SB_NO_CLUSTER_LAYERS", "1")
     m = jelly_cube(10)
     rng = np.random.default_rng(2)
     extra = rng.integers(0, m.n, (300, 2)).astype(np.int32)
@@ -88,7 +93,11 @@ def test_long_range_springs_go_to_global_colours(oracle_mod):
     m.dist_rest = np.concatenate([m.dist_rest, np.linalg.norm(m.rest_pos[extra[:, 0]] - m.rest_pos[extra[:, 1]], axis=1).astype(f32)])
     sb = Softbody(m, substeps=5, tile_particles=64).Start()
     try:
-        assert sb.stats()["n_global_colours"] > 0
+        st = sb.stats()
+        if cluster_layers:
+            assert st["n_global_colours"] == 0 and st["t2_constraints"] >= 250
+        else:
+            assert st["n_global_colours"] > 0
     finally:
         sb.OnDestroy()
     _pair(oracle_mod, m, S=5, tile_particles=64)
