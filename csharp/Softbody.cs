@@ -35,7 +35,8 @@ namespace SoftbodyMI355X
         [Header("Device")]
         [SerializeField] bool useGpu = true;
         [SerializeField] int device = 0;
-        [SerializeField] int tileParticles = 512;
+        [Tooltip("Target particles per LDS tile; 0 = automatic (512, or 256 when the mesh has volume or bending constraints).")]
+        [SerializeField] int tileParticles = 0;
         [Tooltip("Render from the previous tick's snapshot: the D2H copy and the normals (computed on the GPU) overlap the next tick.")]
         [SerializeField] bool asyncReadback = false;
         [Tooltip("With asyncReadback: copy only the particles the render triangles use (a volumetric body renders its surface only); the MeshFilter's mesh is rebuilt over that set.")]

@@ -54,7 +54,8 @@ typedef struct {
     int32_t part_dims[3];    /* blocks per axis, product == world; {0,0,0} = auto (2x2x2 for 8, ...) */
     float   gravity[3];
     float   damping;
-    int32_t tile_particles;  /* target particles per LDS tile; 0 = default (512); -1 = no tiling:
+    int32_t tile_particles;  /* target particles per LDS tile; 0 = automatic (512; 256 when the mesh has volume or
+                                bending constraints); -1 = no tiling:
                                 every constraint goes through the global-colour kernels */
     int32_t use_graph;       /* 1 = replay the substep loop as a hipGraph (default 1 via sb_desc_default) */
 } sb_desc;

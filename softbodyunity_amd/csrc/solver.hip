@@ -853,7 +853,7 @@ void sb_desc_default(sb_desc *d) {
     std::memset(d, 0, sizeof(*d));
     d->world = 1;
     d->gravity[1] = -9.81f;
-    d->tile_particles = 512;
+    d->tile_particles = 0;         // automatic: 512, or 256 when the mesh has 4-vertex constraints (sb_finalize)
     d->use_graph = 1;
 }
 
@@ -865,7 +865,6 @@ int sb_create(const sb_desc *desc, sb_solver **out) {
         if (d.world <= 0) d.world = 1;
         if (d.rank < 0 || d.rank >= d.world) return fail(SB_ERR_INVALID_ARG, "sb_create: rank out of range");
         if (!(d.damping >= 0.0f)) return fail(SB_ERR_INVALID_ARG, "sb_create: damping must be >= 0");
-        if (d.tile_particles == 0) d.tile_particles = 512;
         if (d.tile_particles > sbp::kMaxTileLocal) return fail(SB_ERR_INVALID_ARG, "sb_create: tile_particles too large");
         int ndev = 0;
         hipError_t e = hipGetDeviceCount(&ndev);
@@ -1006,7 +1005,9 @@ int sb_finalize(sb_solver *s) {
         sbp::Opts o;
         o.rank = s->desc.rank; o.world = s->desc.world;
         for (int a = 0; a < 3; ++a) o.dims[a] = s->desc.part_dims[a];
-        o.tile_particles = s->desc.tile_particles;
+        // automatic tile size: 512 particles for spring meshes (bandwidth-bound: the fewest rim tiles that still fill the chip),
+        // 256 when tets or hinges are present (latency-bound: shorter programs per tile, more tiles in flight)
+        o.tile_particles = s->desc.tile_particles != 0 ? s->desc.tile_particles : (s->vol_rest.empty() && s->bend_rest.empty() ? 512 : 256);
         o.bank_aware_lanes = !std::getenv("SB_NO_BANK_ORDER");
         o.third_tiling = !std::getenv("SB_NO_T2");
         o.mixed_groups = !std::getenv("SB_NO_MIXED_GROUPS");
@@ -1475,7 +1476,7 @@ int sb_plan_build(const float *rest, int32_t n, const int32_t *dist_ij, int32_t 
         if (opts) {
             o.rank = opts->rank; o.world = opts->world <= 0 ? 1 : opts->world;
             for (int a = 0; a < 3; ++a) o.dims[a] = opts->part_dims[a];
-            o.tile_particles = opts->tile_particles == 0 ? 512 : opts->tile_particles;
+            o.tile_particles = opts->tile_particles == 0 ? (m_v + m_b > 0 ? 256 : 512) : opts->tile_particles;
         }
         o.bank_aware_lanes = !std::getenv("SB_NO_BANK_ORDER");
         o.third_tiling = !std::getenv("SB_NO_T2");

@@ -164,7 +164,7 @@ class Plan:
 
     @classmethod
     def build(cls, rest_pos, dist_ij=None, vol_ijkl=None, bend_ijkl=None, rank=0, world=1, part_dims=(0, 0, 0),
-              tile_particles=512):
+              tile_particles=0):
         L = lib()
         rest = f32(rest_pos, (-1, 3))
         d = i32(dist_ij if dist_ij is not None else np.zeros((0, 2)), (-1, 2))

@@ -18,7 +18,7 @@ class Softbody:
     # [SerializeField] block of csharp/Softbody.cs
     def __init__(self, mesh, substeps=20, fixed_delta_time=0.02, gravity=(0.0, -9.81, 0.0), damping=0.0,
                  distance_compliance=0.0, volume_compliance=0.0, bending_compliance=0.0, device=0, rank=0, world=1,
-                 part_dims=(0, 0, 0), tile_particles=512, use_graph=True, unique_id=None, ground_plane=None, use_gpu=True):
+                 part_dims=(0, 0, 0), tile_particles=0, use_graph=True, unique_id=None, ground_plane=None, use_gpu=True):
         self.mesh = mesh
         self.substeps = int(substeps)
         self.fixed_delta_time = float(fixed_delta_time)

@@ -33,7 +33,7 @@ int main(int argc, char **argv) {
         }
     CHECK(sb_abi_version() == SB_ABI_VERSION, "sb_abi_version matches the header");
     sb_desc d; sb_desc_default(&d);
-    CHECK(d.world == 1 && d.tile_particles == 512 && d.use_graph == 1, "sb_desc_default");
+    CHECK(d.world == 1 && d.tile_particles == 0 && d.use_graph == 1, "sb_desc_default");
     /* planner: pure host code */
     sb_plan_opts o; memset(&o, 0, sizeof o); o.world = 1; o.tile_particles = 64;
     sb_plan *plan = NULL;

@@ -52,7 +52,7 @@ def test_loads_without_gpu_and_fails_loudly():
     assert L.sb_abi_version() == 4
     d = native.SbDesc()
     L.sb_desc_default(C.byref(d))
-    assert d.world == 1 and d.tile_particles == 512 and d.use_graph == 1 and abs(d.gravity[1] + 9.81) < 1e-6
+    assert d.world == 1 and d.tile_particles == 0 and d.use_graph == 1 and abs(d.gravity[1] + 9.81) < 1e-6
     h = C.c_void_p()
     rc = L.sb_create(C.byref(d), C.byref(h))
     if rc == native.SB_OK:               # a gfx950 device is present (GPU box): nothing to fail on
