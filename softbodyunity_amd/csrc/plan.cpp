@@ -559,7 +559,8 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
             });
             for (int b = 0; b < (t == 0 ? 3 : 1); ++b) split_tasks.push_back({t, b});
         }
-        // the (type, bucket) classes are independent of each other: each labels only its own constraints
+        // the (type, bucket) classes are independent of each other: each reads and writes the labels of its own constraints only
+        // (the bucket is tested before the label is touched)
         parallel_chunks((int64_t)split_tasks.size(), 1, [&](int64_t ti, int64_t, int64_t) {
             const int t = split_tasks[(size_t)ti].t, b = split_tasks[(size_t)ti].b;
             const int nv = kVerts[t];
@@ -568,14 +569,14 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
             const std::vector<uint8_t> &bk = bucket[t];
             std::vector<int64_t> inc_off((size_t)n + 1, 0);
             std::vector<int32_t> inc, queue;
-            for (int64_t k = 0; k < M; ++k) if (lab[k] != -2 && bk[k] == b) for (int a = 0; a < nv; ++a) ++inc_off[C.idx(t, k)[a] + 1];
+            for (int64_t k = 0; k < M; ++k) if (bk[k] == b && lab[k] != -2) for (int a = 0; a < nv; ++a) ++inc_off[C.idx(t, k)[a] + 1];
             for (int32_t p = 0; p < n; ++p) inc_off[p + 1] += inc_off[p];
             inc.resize(inc_off[n]);
             {
                 std::vector<int64_t> cur(inc_off.begin(), inc_off.end() - 1);
-                for (int64_t k = 0; k < M; ++k) if (lab[k] != -2 && bk[k] == b) for (int a = 0; a < nv; ++a) inc[cur[C.idx(t, k)[a]]++] = (int32_t)k;
+                for (int64_t k = 0; k < M; ++k) if (bk[k] == b && lab[k] != -2) for (int a = 0; a < nv; ++a) inc[cur[C.idx(t, k)[a]]++] = (int32_t)k;
             }
-            for (int64_t k = 0; k < M; ++k) if (lab[k] >= 0 && bk[k] == b) queue.push_back((int32_t)k);
+            for (int64_t k = 0; k < M; ++k) if (bk[k] == b && lab[k] >= 0) queue.push_back((int32_t)k);
             size_t head = 0;
             int64_t next_seed = 0;
             for (;;) {
@@ -589,7 +590,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
                         }
                 }
                 // components without a forced member: seed the lowest unlabelled constraint with S0
-                while (next_seed < M && !(lab[next_seed] == -1 && bk[next_seed] == b)) ++next_seed;
+                while (next_seed < M && !(bk[next_seed] == b && lab[next_seed] == -1)) ++next_seed;
                 if (next_seed == M) break;
                 lab[next_seed] = 0;
                 queue.push_back((int32_t)next_seed);
