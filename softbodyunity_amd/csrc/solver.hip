@@ -1227,10 +1227,12 @@ static int get_state(sb_solver *s, float *out, int32_t n, bool velocity) {
         s->h_stage.resize((size_t)s->n_owned * 3);
         const float *src = velocity ? s->d_vel.p : s->d_pos3.p;
         if (s->n_owned) HIP_CHECK(hipMemcpy(s->h_stage.data(), src, (size_t)s->n_owned * 3 * sizeof(float), hipMemcpyDeviceToHost));
-        for (int64_t l = 0; l < s->n_owned; ++l) {
-            int32_t o = L.local_to_old[l];
-            for (int c = 0; c < 3; ++c) out[3 * (size_t)o + c] = s->h_stage[3 * (size_t)l + c];
-        }
+        sbp::parallel_for_chunks(s->n_owned, 1 << 18, [&](int64_t, int64_t lb, int64_t le) {     // owned particles have distinct caller ids
+            for (int64_t l = lb; l < le; ++l) {
+                int32_t o = L.local_to_old[l];
+                for (int c = 0; c < 3; ++c) out[3 * (size_t)o + c] = s->h_stage[3 * (size_t)l + c];
+            }
+        });
         return SB_OK;
     });
 }
