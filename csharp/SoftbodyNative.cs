@@ -91,6 +91,9 @@ namespace SoftbodyMI355X
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_debug_halo_pack(IntPtr s, int slot, IntPtr hostOut, long capacityFloats, out long countFloats);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_debug_halo_unpack(IntPtr s, int slot, IntPtr hostIn, long countFloats);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_get_stats(IntPtr s, out SbStats stats);
+        // opt-in peer-store halo transport (SB_HALO_TRANSPORT=peer): see softbody.h
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_peer_mailbox_handle(IntPtr s, byte[] handle64);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_peer_connect(IntPtr s, int rank, byte[] handle64, IntPtr sameProcessPeer);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_build(IntPtr restXyz, int n, IntPtr distIj, int mD, IntPtr volIjkl, int mV, IntPtr bendIjkl, int mB, ref SbPlanOpts opts, out IntPtr plan);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_destroy(IntPtr plan);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_get_plan(IntPtr s, out IntPtr plan);

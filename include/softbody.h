@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SB_ABI_VERSION 4
+#define SB_ABI_VERSION 5
 
 typedef enum {
     SB_OK = 0,
@@ -87,6 +87,18 @@ int sb_finalize(sb_solver *s);
 #define SB_UNIQUE_ID_BYTES 128
 int sb_comm_unique_id(uint8_t out_id[SB_UNIQUE_ID_BYTES]);
 int sb_comm_init(sb_solver *s, const uint8_t id[SB_UNIQUE_ID_BYTES]);
+
+/* Opt-in peer-store halo transport (environment SB_HALO_TRANSPORT=peer, read by sb_create): instead of pack -> ncclSend /
+ * ncclRecv -> unpack, a rank stores its neighbours' ghosts straight into their mailboxes (one device allocation per rank,
+ * mapped by IPC handle, or by plain pointer inside one process) and raises a flag there; the neighbour's unpack kernel
+ * waits for the flags, copies and acknowledges. With an RCCL communicator present sb_finalize exchanges the handles by
+ * itself (one ncclAllGather at setup). Without one the host connects the mailboxes after sb_finalize: every rank
+ * exports its handle, every rank connects each neighbour's (ranks it shares no halo with may be skipped). A rank that
+ * lives in the SAME process is connected by passing its solver (handle may then be NULL): hipIpcOpenMemHandle refuses
+ * handles of the opening process. Unverified between two devices (1-GPU box); RCCL stays the default. */
+#define SB_IPC_HANDLE_BYTES 64
+int sb_peer_mailbox_handle(sb_solver *s, uint8_t out_handle[SB_IPC_HANDLE_BYTES]);
+int sb_peer_connect(sb_solver *s, int32_t rank, const uint8_t handle[SB_IPC_HANDLE_BYTES], sb_solver *same_process_peer /* or NULL */);
 
 /* ---- the hot path (FixedUpdate) -------------------------------------------------------------- */
 /* One tick of `substeps` substeps (SPEC.md §2). Asynchronous: work is enqueued on the solver's stream. The last

@@ -855,4 +855,101 @@ __global__ __launch_bounds__(256) void halo_unpack_kernel(PosView pos, float *pr
     *reinterpret_cast<f32x3 *>(pos.xyz + o) = x;
 }
 
+// ---- peer-store halo transport (opt-in, SB_HALO_TRANSPORT=peer; solver.hip) ---------------------------------------
+// Instead of pack -> ncclSend/ncclRecv -> unpack, the pack kernel stores every peer's ghosts STRAIGHT into that peer's
+// mailbox (one fine-grained device allocation per rank, mapped into the senders by IPC handle or, inside one process, by
+// plain pointer) and raises a flag there; the receiver's unpack kernel waits for the flags of its senders, copies the
+// ghosts into its arrays and acknowledges, which lets the senders reuse the mailbox. Epochs count the exchanges of a
+// halo slot, live in device memory and are advanced by the kernels themselves, so the launches sit in a captured
+// hipGraph unchanged. Every wait is bounded: a flag that never arrives sets an error word instead of hanging the GPU.
+constexpr int kMaxPeers = 8;
+struct PeerSlot {
+    int32_t n_send, n_recv;                 // peers this rank sends to / receives from on this halo slot
+    int32_t send_off[kMaxPeers + 1];        // particles per send peer (prefix sums), order of the send peers
+    int32_t send_cap[kMaxPeers];            // particles the peer's segment holds (a loopback self-exchange may send fewer than it packs)
+    float *remote_data[kMaxPeers];          // per send peer: where this rank's segment starts inside the peer's mailbox
+    uint32_t *remote_data_flag[kMaxPeers];  // per send peer: the peer's "data from this rank arrived" word
+    uint32_t *my_ack_flag[kMaxPeers];       // per send peer: local word the peer writes when it has consumed the segment
+    uint32_t *my_data_flag[kMaxPeers];      // per recv peer: local word the peer writes when its data is in the mailbox
+    uint32_t *remote_ack_flag[kMaxPeers];   // per recv peer: the peer's "consumed" word for this rank
+    uint32_t *epoch;                        // exchanges of this slot completed so far (advanced by the unpack kernel)
+    uint32_t *counters;                     // [0] push, [1] unpack: workgroups finished (last-workgroup detection)
+    uint32_t *error;                        // set to 1 when a wait gave up
+};
+constexpr int kPeerSpinLimit = 1 << 24;
+
+__device__ __forceinline__ void peer_wait_at_least(const uint32_t *flag, uint32_t want, uint32_t *error) {
+    int spins = 0;
+    while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++spins > kPeerSpinLimit) { __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+    }
+}
+
+template <bool WITH_PREV>
+__global__ __launch_bounds__(256) void peer_push_kernel(PosView pos, const float *prev, const int32_t *idx, int count, PeerSlot P) {
+    __shared__ uint32_t s_last;
+    const int tid = threadIdx.x;
+    const uint32_t e = __hip_atomic_load(P.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (tid < P.n_send) peer_wait_at_least(P.my_ack_flag[tid], e - 1u, P.error);      // the peer has consumed the previous segment
+    __syncthreads();
+    const int k = blockIdx.x * 256 + tid;
+    if (k < count) {
+        int j = 0;
+#pragma unroll
+        for (int q = 1; q < kMaxPeers; ++q) j = (q < P.n_send && k >= P.send_off[q]) ? q : j;
+        constexpr int F = WITH_PREV ? 6 : 3;
+        if (k - P.send_off[j] < P.send_cap[j]) {
+            float *b = P.remote_data[j] + (size_t)F * (k - P.send_off[j]);
+            const size_t o = 3 * (size_t)idx[k];
+            const f32x3 x = *reinterpret_cast<const f32x3 *>(pos.xyz + o);
+            if (WITH_PREV) {
+                const f32x3 pv = *reinterpret_cast<const f32x3 *>(prev + o);
+                *reinterpret_cast<f32x3 *>(b + 3) = pv;
+            }
+            *reinterpret_cast<f32x3 *>(b) = x;
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");         // system scope: this lane's stores are visible to the peers ...
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(P.counters + 0, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_last) {                                          // ... before the last workgroup raises the flags
+        if (tid == 0) __hip_atomic_store(P.counters + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid < P.n_send) __hip_atomic_store(P.remote_data_flag[tid], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
+template <bool WITH_PREV>
+__global__ __launch_bounds__(256) void peer_unpack_kernel(PosView pos, float *prev, const int32_t *idx, const float *mailbox, int count, PeerSlot P) {
+    __shared__ uint32_t s_last;
+    const int tid = threadIdx.x;
+    const uint32_t e = __hip_atomic_load(P.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    if (tid < P.n_recv) peer_wait_at_least(P.my_data_flag[tid], e, P.error);
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    const int k = blockIdx.x * 256 + tid;
+    if (k < count) {
+        constexpr int F = WITH_PREV ? 6 : 3;
+        const float *b = mailbox + (size_t)F * k;
+        const size_t o = 3 * (size_t)idx[k];
+        // written by another agent: read at system scope
+        float v[F];
+#pragma unroll
+        for (int c = 0; c < F; ++c) v[c] = __hip_atomic_load(b + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        pos.xyz[o] = v[0]; pos.xyz[o + 1] = v[1]; pos.xyz[o + 2] = v[2];
+        if (WITH_PREV) { prev[o] = v[3]; prev[o + 1] = v[4]; prev[o + 2] = v[5]; }
+    }
+    __syncthreads();
+    if (tid == 0) s_last = atomicAdd(P.counters + 1, 1u) == gridDim.x - 1 ? 1u : 0u;
+    __syncthreads();
+    if (s_last) {        // every workgroup has read its part of the mailbox: acknowledge, advance the slot's epoch
+        if (tid == 0) {
+            __hip_atomic_store(P.counters + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(P.epoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid < P.n_recv) __hip_atomic_store(P.remote_ack_flag[tid], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}
+
 }  // namespace sbk

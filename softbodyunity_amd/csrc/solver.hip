@@ -161,6 +161,18 @@ struct sb_solver {
     bool pack_tiles = true;          // SB_NO_PACK unset: under-full tiles share a workgroup (build_device)
     bool graph_rccl = false;         // SB_GRAPH_RCCL set: capture the RCCL calls of a multi-rank tick in the hipGraph
     std::vector<float> h_stage;
+    // peer-store halo transport (SB_HALO_TRANSPORT=peer; kernels.hip.hpp): one mailbox per rank = [header words | ghost segments]
+    struct PeerState {
+        bool enabled = false, linked = false, fine_grained = false;
+        uint32_t *mailbox = nullptr;            // header: word 0 = error; per slot: data flags[world], ack flags[world], epoch, 2 counters; then the offset table
+        size_t bytes = 0, data_off_words = 0, off_table = 0;
+        int n_slots = 0;
+        std::vector<uint32_t *> remote;         // [world]: the ranks' mailboxes as this process sees them (own pointer for itself)
+        std::vector<uint8_t> opened;            // remote[r] was mapped with hipIpcOpenMemHandle
+        std::vector<std::vector<uint32_t>> my_off;   // [slot][rank]: first word (from the mailbox start) of rank's segment in MY mailbox
+        std::vector<sbk::PeerSlot> slots;
+        size_t slot_base(int slot, int world) const { return 1 + (size_t)slot * (2 * (size_t)world + 3); }
+    } peer;
     // asynchronous render readback (sb_readback_begin / sb_readback_end): two snapshot slots
     hipStream_t copy_stream = nullptr;
     DevBuf<int32_t> d_local_to_old;
@@ -189,6 +201,8 @@ struct sb_solver {
     ~sb_solver() {
         for (auto &g : graphs) (void)hipGraphExecDestroy(g.second.exec);
         if (comm) (void)ncclCommDestroy(comm);
+        for (size_t r = 0; r < peer.remote.size(); ++r) if (peer.opened[r] && peer.remote[r]) (void)hipIpcCloseMemHandle(peer.remote[r]);
+        if (peer.mailbox) (void)hipFree(peer.mailbox);
         if (ev_boundary) (void)hipEventDestroy(ev_boundary);
         if (ev_halo) (void)hipEventDestroy(ev_halo);
         if (comm_stream) (void)hipStreamDestroy(comm_stream);
@@ -633,6 +647,84 @@ void build_device(sb_solver *s) {
     }
     s->d_sendbuf.alloc(max_send, s->dev_bytes);
     s->d_recvbuf.alloc(max_recv, s->dev_bytes);
+    if (s->peer.enabled && L.world > 1) {
+        // the mailbox: header words, then one segment per (halo slot, sending rank) in slot order, ranks increasing
+        auto &PS = s->peer;
+        const int W = L.world;
+        if (W > sbk::kMaxPeers + 1) throw std::runtime_error("peer transport: at most 9 ranks");
+        PS.n_slots = (int)s->halos.size();
+        PS.off_table = PS.slot_base(PS.n_slots, W);
+        const size_t hdr_words = PS.off_table + (size_t)PS.n_slots * W;
+        PS.data_off_words = (hdr_words + 63) & ~(size_t)63;
+        std::vector<uint32_t> header(PS.data_off_words, 0u);
+        PS.my_off.assign((size_t)PS.n_slots, std::vector<uint32_t>((size_t)W, 0u));
+        size_t words = PS.data_off_words;
+        for (int slot = 0; slot < PS.n_slots; ++slot) {
+            const DevHalo &D = *s->halos[(size_t)slot];
+            const size_t fl = slot == 1 ? 6 : 3;
+            for (size_t k = 0; k < D.peers.size(); ++k) {
+                PS.my_off[(size_t)slot][(size_t)D.peers[k]] = (uint32_t)(words + fl * (size_t)D.recv_off[k]);
+                header[PS.off_table + (size_t)slot * W + (size_t)D.peers[k]] = (uint32_t)(words + fl * (size_t)D.recv_off[k]);
+            }
+            words += fl * (size_t)D.recv_off.back();
+            words = (words + 63) & ~(size_t)63;
+        }
+        PS.bytes = words * 4;
+        void *mb = nullptr;
+        if (hipExtMallocWithFlags(&mb, PS.bytes, hipDeviceMallocFinegrained) == hipSuccess) PS.fine_grained = true;
+        else { (void)hipGetLastError(); HIP_CHECK(hipMalloc(&mb, PS.bytes)); }
+        PS.mailbox = (uint32_t *)mb;
+        s->dev_bytes += (int64_t)PS.bytes;
+        HIP_CHECK(hipMemset(PS.mailbox, 0, PS.bytes));
+        HIP_CHECK(hipMemcpy(PS.mailbox, header.data(), header.size() * 4, hipMemcpyHostToDevice));
+        PS.remote.assign((size_t)W, nullptr);
+        PS.opened.assign((size_t)W, 0);
+        PS.remote[(size_t)L.rank] = PS.mailbox;
+    }
+}
+
+// Peer transport: once every sending / receiving neighbour's mailbox is mapped, fill the per-slot tables the kernels take.
+void peer_link(sb_solver *s) {
+    auto &PS = s->peer;
+    const int W = s->desc.world, me = s->desc.rank;
+    PS.slots.assign((size_t)PS.n_slots, sbk::PeerSlot{});
+    for (int slot = 0; slot < PS.n_slots; ++slot) {
+        const DevHalo &D = *s->halos[(size_t)slot];
+        sbk::PeerSlot &P = PS.slots[(size_t)slot];
+        const size_t base = PS.slot_base(slot, W);
+        P.epoch = PS.mailbox + base + 2 * (size_t)W;
+        P.counters = PS.mailbox + base + 2 * (size_t)W + 1;
+        P.error = PS.mailbox;
+        for (size_t k = 0; k < D.peers.size(); ++k) {
+            const int r = s->loopback ? me : D.peers[k];
+            int cs = D.send_off[k + 1] - D.send_off[k], cr = D.recv_off[k + 1] - D.recv_off[k];
+            if (s->loopback && (cs == 0 || cr == 0)) cs = cr = 0;       // a self-exchange needs both directions
+            uint32_t *rm = PS.remote[(size_t)r];
+            if ((cs || cr) && !rm) throw HipError(SB_ERR_STATE, "peer transport: the mailbox of rank " + std::to_string(r) + " is not connected (sb_peer_connect)");
+            if (cs) {
+                if (P.n_send >= sbk::kMaxPeers) throw std::runtime_error("peer transport: too many neighbours");
+                // where my segment starts inside the peer's mailbox: the peer's own offset table says
+                uint32_t off = 0;
+                if (s->loopback) off = PS.my_off[(size_t)slot][(size_t)D.peers[k]];
+                else HIP_CHECK(hipMemcpy(&off, rm + PS.off_table + (size_t)slot * W + (size_t)me, 4, hipMemcpyDeviceToHost));
+                if (off == 0) throw std::runtime_error("peer transport: a neighbour's mailbox has no segment for this rank");
+                P.send_off[P.n_send] = D.send_off[k];
+                P.send_cap[P.n_send] = s->loopback ? std::min(cs, cr) : INT32_MAX;
+                P.remote_data[P.n_send] = reinterpret_cast<float *>(rm + off);
+                P.remote_data_flag[P.n_send] = rm + base + (size_t)(s->loopback ? D.peers[k] : me);
+                P.my_ack_flag[P.n_send] = PS.mailbox + base + (size_t)W + (size_t)D.peers[k];
+                ++P.n_send;
+                P.send_off[P.n_send] = D.send_off[k + 1];
+            }
+            if (cr) {
+                P.my_data_flag[P.n_recv] = PS.mailbox + base + (size_t)D.peers[k];
+                P.remote_ack_flag[P.n_recv] = rm + base + (size_t)W + (size_t)(s->loopback ? D.peers[k] : me);
+                ++P.n_recv;
+            }
+        }
+        for (int q = P.n_send + 1; q <= sbk::kMaxPeers; ++q) P.send_off[q] = INT32_MAX;
+    }
+    PS.linked = true;
 }
 
 // Ghost refresh for one halo slot. Buffers hold every peer's particles back to back (3 floats each, slot 1: 6 with the
@@ -642,9 +734,32 @@ void halo_exchange(sb_solver *s, int slot, hipStream_t st = nullptr) {
     if (slot < 0 || slot >= (int)s->halos.size()) return;
     DevHalo &D = *s->halos[slot];
     if (!D.active()) return;
-    if (!s->comm) throw HipError(SB_ERR_STATE, "world > 1 needs sb_comm_init before sb_finalize");
     const bool with_prev = slot == 1;
     const int ns = D.send_off.back(), nr = D.recv_off.back();
+    if (s->peer.enabled) {
+        if (!s->peer.linked) peer_link(s);
+        const sbk::PeerSlot &P = s->peer.slots[(size_t)slot];
+        if (ns) {
+            if (with_prev)
+                hipLaunchKernelGGL(sbk::peer_push_kernel<true>, dim3((ns + 255) / 256), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.send_idx.p, ns, P);
+            else
+                hipLaunchKernelGGL(sbk::peer_push_kernel<false>, dim3((ns + 255) / 256), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.send_idx.p, ns, P);
+        }
+        // (always launched for an active slot: it also advances the slot's epoch)
+        const float *mb = reinterpret_cast<const float *>(s->peer.mailbox + s->peer.my_off[(size_t)slot][(size_t)D.peers[0]]);
+        // the segments of a slot are contiguous in rank order, the first receiving peer's segment starts the slot's region
+        {
+            size_t first = SIZE_MAX;
+            for (size_t k = 0; k < D.peers.size(); ++k) if (D.recv_off[k + 1] > D.recv_off[k]) { first = k; break; }
+            if (first != SIZE_MAX) mb = reinterpret_cast<const float *>(s->peer.mailbox + s->peer.my_off[(size_t)slot][(size_t)D.peers[first]]);
+        }
+        if (with_prev)
+            hipLaunchKernelGGL(sbk::peer_unpack_kernel<true>, dim3(std::max(1, (nr + 255) / 256)), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.recv_idx.p, mb, nr, P);
+        else
+            hipLaunchKernelGGL(sbk::peer_unpack_kernel<false>, dim3(std::max(1, (nr + 255) / 256)), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.recv_idx.p, mb, nr, P);
+        return;
+    }
+    if (!s->comm) throw HipError(SB_ERR_STATE, "world > 1 needs sb_comm_init before sb_finalize");
     if (ns) {
         if (with_prev)
             hipLaunchKernelGGL(sbk::halo_pack_kernel<true>, dim3((ns + 255) / 256), dim3(256), 0, st, s->pos_view(),
@@ -822,6 +937,15 @@ void upload_tick_params(sb_solver *s, float dt, int substeps) {
     }
 }
 
+// Peer transport: a wait that gave up (a neighbour never delivered / never acknowledged) must not pass silently.
+void check_peer_error(sb_solver *s) {
+    if (!s->peer.enabled || !s->peer.mailbox) return;
+    uint32_t flag = 0;
+    HIP_CHECK(hipMemcpyAsync(&flag, s->peer.mailbox, sizeof(flag), hipMemcpyDeviceToHost, s->stream));
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (flag) throw HipError(SB_ERR_RCCL, "peer transport: a halo wait gave up (a neighbour never delivered or never acknowledged)");
+}
+
 template <class F>
 int guarded(F &&f) {
     try {
@@ -880,6 +1004,7 @@ int sb_create(const sb_desc *desc, sb_solver **out) {
         s->desc = d;
         s->lazy_tick = !std::getenv("SB_NO_LAZY_TICK");
         s->graph_rccl = std::getenv("SB_GRAPH_RCCL") != nullptr;
+        if (const char *e = std::getenv("SB_HALO_TRANSPORT")) s->peer.enabled = std::strcmp(e, "peer") == 0;
         s->pack_tiles = !std::getenv("SB_NO_PACK");
         if (const char *e = std::getenv("SB_LDS_PAD")) s->lds_pad = (size_t)std::max(0, std::atoi(e));
         if (const char *e = std::getenv("SB_TILE_LANES")) s->tile_lanes = std::atoi(e) == 128 ? 128 : (std::atoi(e) == 256 ? 256 : 0);
@@ -990,13 +1115,49 @@ int sb_comm_init(sb_solver *s, const uint8_t id_bytes[SB_UNIQUE_ID_BYTES]) {
     });
 }
 
+int sb_peer_mailbox_handle(sb_solver *s, uint8_t out_handle[SB_IPC_HANDLE_BYTES]) {
+    if (!s || !out_handle) return fail(SB_ERR_INVALID_ARG, "sb_peer_mailbox_handle: null argument");
+    if (!s->finalized || !s->peer.mailbox) return fail(SB_ERR_STATE, "sb_peer_mailbox_handle: needs a finalized world > 1 solver with SB_HALO_TRANSPORT=peer");
+    static_assert(sizeof(hipIpcMemHandle_t) <= SB_IPC_HANDLE_BYTES, "ipc handle size");
+    return guarded([&]() -> int {
+        int rc = set_device(s); if (rc) return rc;
+        hipIpcMemHandle_t h;
+        HIP_CHECK(hipIpcGetMemHandle(&h, s->peer.mailbox));
+        std::memset(out_handle, 0, SB_IPC_HANDLE_BYTES);
+        std::memcpy(out_handle, &h, sizeof(h));
+        return SB_OK;
+    });
+}
+
+int sb_peer_connect(sb_solver *s, int32_t rank, const uint8_t handle[SB_IPC_HANDLE_BYTES], sb_solver *same_process_peer) {
+    if (!s || (!handle && !same_process_peer)) return fail(SB_ERR_INVALID_ARG, "sb_peer_connect: null argument");
+    if (!s->finalized || !s->peer.mailbox) return fail(SB_ERR_STATE, "sb_peer_connect: needs a finalized world > 1 solver with SB_HALO_TRANSPORT=peer");
+    if (rank < 0 || rank >= s->desc.world || rank == s->desc.rank) return fail(SB_ERR_INVALID_ARG, "sb_peer_connect: bad rank");
+    if (s->peer.remote[(size_t)rank]) return fail(SB_ERR_STATE, "sb_peer_connect: rank already connected");
+    return guarded([&]() -> int {
+        int rc = set_device(s); if (rc) return rc;
+        if (same_process_peer) {             // the peer's handle lives in this process: its pointer is directly usable
+            if (!same_process_peer->peer.mailbox || same_process_peer->desc.rank != rank) return fail(SB_ERR_INVALID_ARG, "sb_peer_connect: the given solver is not that rank");
+            s->peer.remote[(size_t)rank] = same_process_peer->peer.mailbox;
+        } else {
+            hipIpcMemHandle_t h;
+            std::memcpy(&h, handle, sizeof(h));
+            void *p = nullptr;
+            HIP_CHECK(hipIpcOpenMemHandle(&p, h, hipIpcMemLazyEnablePeerAccess));
+            s->peer.remote[(size_t)rank] = (uint32_t *)p; s->peer.opened[(size_t)rank] = 1;
+        }
+        s->peer.linked = false;
+        return SB_OK;
+    });
+}
+
 int sb_finalize(sb_solver *s) {
     if (!s) return fail(SB_ERR_INVALID_ARG, "sb_finalize: null handle");
     if (s->finalized) return fail(SB_ERR_STATE, "sb_finalize called twice");
     if (s->n <= 0) return fail(SB_ERR_STATE, "sb_finalize before sb_set_particles");
     // SB_TEST_NO_COMM: the hosted-halo test hooks (sb_debug_*) drive world > 1 without an RCCL communicator
-    if (s->desc.world > 1 && !s->comm && !std::getenv("SB_TEST_NO_COMM"))
-        return fail(SB_ERR_STATE, "sb_finalize: world > 1 needs sb_comm_init first");
+    if (s->desc.world > 1 && !s->comm && !s->peer.enabled && !std::getenv("SB_TEST_NO_COMM"))
+        return fail(SB_ERR_STATE, "sb_finalize: world > 1 needs sb_comm_init first (or SB_HALO_TRANSPORT=peer with sb_peer_connect)");
     return guarded([&]() -> int {
         int rc = set_device(s); if (rc) return rc;
         const std::vector<float> &rest = s->rest.empty() ? s->pos : s->rest;
@@ -1033,6 +1194,34 @@ int sb_finalize(sb_solver *s) {
             HIP_CHECK(hipEventCreateWithFlags(&s->ev_boundary, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&s->ev_halo, hipEventDisableTiming));
             s->overlap_halo = true;
+        }
+        if (s->peer.enabled && s->desc.world > 1) {
+            if (s->loopback) {
+                peer_link(s);                      // every neighbour is this rank itself
+            } else if (s->comm) {
+                // exchange the mailbox handles over the communicator the host already set up (setup time only)
+                const int W = s->desc.world;
+                hipIpcMemHandle_t mine;
+                HIP_CHECK(hipIpcGetMemHandle(&mine, s->peer.mailbox));
+                DevBuf<uint8_t> d_all; int64_t acct = 0;
+                d_all.alloc((size_t)W * sizeof(mine), acct);
+                HIP_CHECK(hipMemcpy(d_all.p + (size_t)s->desc.rank * sizeof(mine), &mine, sizeof(mine), hipMemcpyHostToDevice));
+                NCCL_CHECK(ncclAllGather(d_all.p + (size_t)s->desc.rank * sizeof(mine), d_all.p, sizeof(mine), ncclUint8, s->comm, s->stream));
+                HIP_CHECK(hipStreamSynchronize(s->stream));
+                std::vector<hipIpcMemHandle_t> all((size_t)W);
+                HIP_CHECK(hipMemcpy(all.data(), d_all.p, (size_t)W * sizeof(mine), hipMemcpyDeviceToHost));
+                for (int r = 0; r < W; ++r) {
+                    if (r == s->desc.rank) continue;
+                    bool needed = false;
+                    for (const auto &H : s->halos) for (int pr : H->peers) needed |= pr == r;
+                    if (!needed) continue;
+                    void *p = nullptr;
+                    HIP_CHECK(hipIpcOpenMemHandle(&p, all[(size_t)r], hipIpcMemLazyEnablePeerAccess));
+                    s->peer.remote[(size_t)r] = (uint32_t *)p; s->peer.opened[(size_t)r] = 1;
+                }
+                peer_link(s);
+            }
+            // otherwise (test mode without a communicator) the host connects the mailboxes: sb_peer_mailbox_handle / sb_peer_connect
         }
         HIP_CHECK(hipDeviceSynchronize());
         // authoring copies are no longer needed (keep rest values out of memory for 50M-constraint meshes)
@@ -1196,6 +1385,7 @@ int sb_synchronize(sb_solver *s) {
         int rc = set_device(s); if (rc) return rc;
         flush_deferred(s);
         HIP_CHECK(hipStreamSynchronize(s->stream));
+        check_peer_error(s);
         return SB_OK;
     });
 }
@@ -1208,6 +1398,7 @@ static int get_state(sb_solver *s, float *out, int32_t n, bool velocity) {
         int rc = set_device(s); if (rc) return rc;
         const sbp::LocalPlan &L = s->plan->local;
         flush_deferred(s);
+        check_peer_error(s);
         if (s->desc.world == 1) {
             // single rank: every entry is ours, so the permutation to caller numbering runs on the GPU and one copy
             // lands in the caller's array (the host-side scatter below costs 25 ms for 16.7 M particles)

@@ -16,6 +16,7 @@ _VARIANT = os.environ.get("SB_LIB_VARIANT", "")
 LIB_PATH = os.path.join(_HERE, f"libsoftbody_mi355x{'_' + _VARIANT if _VARIANT else ''}.so")
 
 SB_UNIQUE_ID_BYTES = 128
+SB_IPC_HANDLE_BYTES = 64
 SB_OK = 0
 SB_ERR_INVALID_ARG, SB_ERR_STATE, SB_ERR_NO_DEVICE, SB_ERR_HIP, SB_ERR_RCCL, SB_ERR_NOMEM, SB_ERR_UNSUPPORTED = \
     -1, -2, -3, -4, -5, -6, -7
@@ -68,6 +69,8 @@ SIGNATURES = {
     "sb_finalize": (C.c_int, [_P]),
     "sb_comm_unique_id": (C.c_int, [_P]),
     "sb_comm_init": (C.c_int, [_P, _P]),
+    "sb_peer_mailbox_handle": (C.c_int, [_P, _P]),
+    "sb_peer_connect": (C.c_int, [_P, C.c_int32, _P, _P]),
     "sb_step": (C.c_int, [_P, C.c_float, C.c_int32]),
     "sb_get_positions": (C.c_int, [_P, _P, C.c_int32]),
     "sb_get_velocities": (C.c_int, [_P, _P, C.c_int32]),

@@ -86,7 +86,8 @@ class Softbody:
         if len(m.bend_rest):
             q = i32(m.bend_ijkl, (-1, 4)); r = f32(m.bend_rest, (-1, 2))
             check(L.sb_set_bending_constraints(h, ptr(q), ptr(r), r.shape[0], self.compliance[2]))
-        if self.world > 1 and not os.environ.get("SB_TEST_NO_COMM"):
+        peer_only = os.environ.get("SB_HALO_TRANSPORT") == "peer" and self.unique_id is None    # the host connects the mailboxes itself
+        if self.world > 1 and not os.environ.get("SB_TEST_NO_COMM") and not peer_only:
             assert self.unique_id is not None and len(self.unique_id) == native.SB_UNIQUE_ID_BYTES
             buf = (C.c_uint8 * native.SB_UNIQUE_ID_BYTES)(*self.unique_id)
             check(L.sb_comm_init(h, buf))

@@ -49,7 +49,7 @@ def test_struct_layouts_match_header():
 
 def test_loads_without_gpu_and_fails_loudly():
     L = native.lib()
-    assert L.sb_abi_version() == 4
+    assert L.sb_abi_version() == 5
     d = native.SbDesc()
     L.sb_desc_default(C.byref(d))
     assert d.world == 1 and d.tile_particles == 0 and d.use_graph == 1 and abs(d.gravity[1] + 9.81) < 1e-6

@@ -180,6 +180,6 @@ def test_rccl_pipeline_loopback_and_overlap_equivalence():
     import subprocess
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lb_combo_test.py")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-1500:]
-    lines = [l for l in out.stdout.splitlines() if l.startswith("overlap=")]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("rccl overlap=")]
     assert len(lines) == 4 and all("rc=0 HASH" in l and l.endswith("True") for l in lines), out.stdout[-1500:]
-    assert "all equal: True" in out.stdout, out.stdout[-1500:]
+    assert "rccl all equal: True" in out.stdout, out.stdout[-1500:]

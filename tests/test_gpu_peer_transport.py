@@ -1,0 +1,81 @@
+"""The opt-in peer-store halo transport (SB_HALO_TRANSPORT=peer): ghosts stored straight into the neighbours' mailboxes,
+flags instead of ncclSend/ncclRecv. Unlike RCCL it CAN run between several ranks on one GPU -- the mailboxes of the other
+processes are mapped through hipIpc handles -- so this is the one multi-rank test that goes through the real sb_step path
+(eager launches and the captured hipGraph), ranks as separate processes, and still reproduces the oracle bit for bit.
+Between two DEVICES it has never run (1-GPU box): DESIGN.md 7."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, mesh_kind, graph, out_dir):
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    os.environ["SB_HALO_TRANSPORT"] = "peer"
+    if graph:
+        os.environ["SB_GRAPH_RCCL"] = "1"          # capture the tick (exchange kernels included) in the hipGraph
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from softbodyunity_amd import Softbody, native
+    from softbodyunity_amd.mesh import bunny_surrogate, jelly_cube
+    mesh = jelly_cube(24, pin_top=True) if mesh_kind == "cube" else bunny_surrogate(target_verts=3000, seed=9)
+    comp = (0.0, 0.0, 0.0) if mesh_kind == "cube" else (1e-7, 1e-7, 1e-4)
+    sb = Softbody(mesh, substeps=6, device=0, rank=rank, world=world, tile_particles=64 if mesh_kind == "cube" else 128,
+                  distance_compliance=comp[0], volume_compliance=comp[1], bending_compliance=comp[2]).Start()   # no communicator: the host connects
+    L = native.lib()
+    mine = np.zeros(native.SB_IPC_HANDLE_BYTES, np.uint8)
+    native.check(L.sb_peer_mailbox_handle(sb._h, native.ptr(mine)))
+    handles = [torch.zeros(native.SB_IPC_HANDLE_BYTES, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(handles, torch.from_numpy(mine))
+    for r in range(world):
+        if r != rank:
+            h = handles[r].numpy().copy()
+            native.check(L.sb_peer_connect(sb._h, r, native.ptr(h), None))
+    dist.barrier()
+    for _ in range(3):
+        sb.step()
+    x = sb.get_positions(); v = sb.get_velocities()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=x, v=v, owned=sb.owner() == rank,
+             ghosts=np.array(sb.stats()["n_particles_local"] - sb.stats()["n_particles_owned"]))
+    dist.barrier()              # nobody unmaps a mailbox a neighbour may still be writing to
+    sb.OnDestroy()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,mesh_kind,graph", [(2, "cube", False), (4, "cube", True), (3, "bunny", False), (2, "bunny", True)])
+def test_ranks_as_processes_through_the_peer_transport(tmp_path, oracle_mod, world, mesh_kind, graph):
+    from softbodyunity_amd.mesh import bunny_surrogate, jelly_cube
+    from helpers import build_plan, make_oracle
+    port = 29300 + (os.getpid() % 1500) + world * 11 + (5 if graph else 0)
+    mp.spawn(_worker, args=(world, port, mesh_kind, graph, str(tmp_path)), nprocs=world, join=True)
+    mesh = jelly_cube(24, pin_top=True) if mesh_kind == "cube" else bunny_surrogate(target_verts=3000, seed=9)
+    comp = (0.0, 0.0, 0.0) if mesh_kind == "cube" else (1e-7, 1e-7, 1e-4)
+    ref = make_oracle(oracle_mod, mesh, build_plan(mesh, tile_particles=64 if mesh_kind == "cube" else 128), compliance=comp)
+    for _ in range(3):
+        ref.step(0.02, 6)
+    x = np.zeros_like(ref.x); v = np.zeros_like(ref.v); cover = np.zeros(mesh.n, int); ghosts = 0
+    for r in range(world):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        x[d["owned"]] = d["x"][d["owned"]]; v[d["owned"]] = d["v"][d["owned"]]; cover += d["owned"]; ghosts += int(d["ghosts"])
+    assert np.all(cover == 1) and ghosts > 0
+    assert np.array_equal(x.view(np.uint32), ref.x.view(np.uint32))
+    assert np.array_equal(v.view(np.uint32), ref.v.view(np.uint32))
+
+
+def test_peer_transport_loopback_schedules_agree():
+    # rank 0's share with every neighbour replaced by itself: serialised / overlapped x eager / captured, one process each
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lb_combo_test.py"), "peer"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-1500:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("peer overlap=")]
+    assert len(lines) == 4 and all("rc=0 HASH" in l and l.endswith("True") for l in lines), out.stdout[-1500:]
+    assert "peer all equal: True" in out.stdout, out.stdout[-1500:]
