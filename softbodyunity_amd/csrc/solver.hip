@@ -1239,6 +1239,7 @@ int sb_step(sb_solver *s, float dt, int32_t substeps) {
     if (!(dt > 0.0f) || substeps <= 0) return fail(SB_ERR_INVALID_ARG, "sb_step: dt and substeps must be positive");
     return guarded([&]() -> int {
         int rc = set_device(s); if (rc) return rc;
+        if (s->peer.enabled && s->desc.world > 1 && !s->peer.linked) peer_link(s);     // (reads the neighbours' offset tables: not inside a capture)
         // lazy tick boundary: fuse with the previous tick's deferred last kernel when nothing changed
         const sbk::TickParams tp_new = tick_params(s, dt, substeps);
         const bool can_defer = !s->overlap_halo && s->lazy_tick && (!s->plan->plan.tiling || (substeps & 1) == 0);
@@ -1293,6 +1294,7 @@ int sb_step_profiled(sb_solver *s, float dt, int32_t substeps, float *slot_ms, i
     if (n_slots != (int32_t)s->gcolours.size() + 5) return fail(SB_ERR_INVALID_ARG, "sb_step_profiled: n_slots must be 5 + n_global_colours");
     return guarded([&]() -> int {
         int rc = set_device(s); if (rc) return rc;
+        if (s->peer.enabled && s->desc.world > 1 && !s->peer.linked) peer_link(s);
         flush_deferred(s);
         upload_tick_params(s, dt, substeps);
         LaunchTimer lt; lt.stream = s->stream;
