@@ -6,7 +6,7 @@ import subprocess
 import sys
 
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-TICKS = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+TICKS = int(sys.argv[1]) if len(sys.argv) > 1 else 100     # both transports: RCCL send/recv and the peer-store mailboxes
 CHILD = r'''
 import os, sys, time, hashlib
 sys.path.insert(0, %r)
@@ -28,12 +28,13 @@ print("RESULT %%.4f ms/tick hash %%s finite %%s" %% (ms, hashlib.sha256(x.tobyte
 sb.OnDestroy()
 ''' % (ROOT, TICKS, TICKS)
 
-for overlap, graph in (("", ""), ("", "1"), ("1", ""), ("1", "1")):
-    env = dict(os.environ, SB_TEST_LOOPBACK="1")
-    for k, v in (("SB_HALO_OVERLAP", overlap), ("SB_GRAPH_RCCL", graph)):
-        env.pop(k, None)
-        if v:
-            env[k] = v
-    r = subprocess.run([sys.executable, "-X", "faulthandler", "-c", CHILD], env=env, capture_output=True, text=True, timeout=400)
-    line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
-    print(f"overlap={overlap or 0} graph={graph or 0}: rc={r.returncode} {line[0] if line else r.stderr[-300:]}", flush=True)
+for transport in ("rccl", "peer"):
+    for overlap, graph in (("", ""), ("", "1"), ("1", ""), ("1", "1")):
+        env = dict(os.environ, SB_TEST_LOOPBACK="1")
+        for k, v in (("SB_HALO_OVERLAP", overlap), ("SB_GRAPH_RCCL", graph), ("SB_HALO_TRANSPORT", "peer" if transport == "peer" else "")):
+            env.pop(k, None)
+            if v:
+                env[k] = v
+        r = subprocess.run([sys.executable, "-X", "faulthandler", "-c", CHILD], env=env, capture_output=True, text=True, timeout=400)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
+        print(f"{transport} overlap={overlap or 0} graph={graph or 0}: rc={r.returncode} {line[0] if line else r.stderr[-300:]}", flush=True)
