@@ -872,8 +872,8 @@ struct PeerSlot {
     uint32_t *my_ack_flag[kMaxPeers];       // per send peer: local word the peer writes when it has consumed the segment
     uint32_t *my_data_flag[kMaxPeers];      // per recv peer: local word the peer writes when its data is in the mailbox
     uint32_t *remote_ack_flag[kMaxPeers];   // per recv peer: the peer's "consumed" word for this rank
-    uint32_t *epoch;                        // exchanges of this slot completed so far (advanced by the unpack kernel)
-    uint32_t *counters;                     // [0] push, [1] unpack: workgroups finished (last-workgroup detection)
+    uint32_t *local;                        // this rank's own (ordinary, cached) words for the slot: [0] exchanges completed so far,
+                                            // [1] push / [2] unpack workgroups finished, [3] push / [4] unpack "go" (epoch the waits have passed)
     uint32_t *error;                        // set to 1 when a wait gave up
 };
 constexpr int kPeerSpinLimit = 1 << 24;
@@ -886,13 +886,31 @@ __device__ __forceinline__ void peer_wait_at_least(const uint32_t *flag, uint32_
     }
 }
 
+// Workgroup 0 polls the (uncached) flags in the mailbox; everybody else waits for its "go" word in ordinary memory.
+__device__ __forceinline__ void peer_gate(const PeerSlot &P, int which, uint32_t e, uint32_t *const *flags, int n_flags, uint32_t want) {
+    uint32_t *go = P.local + 3 + which;
+    if (blockIdx.x == 0) {
+        if ((int)threadIdx.x < n_flags) peer_wait_at_least(flags[threadIdx.x], want, P.error);
+        __syncthreads();
+        if (threadIdx.x == 0) __hip_atomic_store(go, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+        if (threadIdx.x == 0) {
+            int spins = 0;
+            while ((int32_t)(__hip_atomic_load(go, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - e) < 0) {
+                __builtin_amdgcn_s_sleep(2);
+                if (++spins > kPeerSpinLimit) { __hip_atomic_store(P.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
+            }
+        }
+        __syncthreads();
+    }
+}
+
 template <bool WITH_PREV>
 __global__ __launch_bounds__(256) void peer_push_kernel(PosView pos, const float *prev, const int32_t *idx, int count, PeerSlot P) {
     __shared__ uint32_t s_last;
     const int tid = threadIdx.x;
-    const uint32_t e = __hip_atomic_load(P.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    if (tid < P.n_send) peer_wait_at_least(P.my_ack_flag[tid], e - 1u, P.error);      // the peer has consumed the previous segment
-    __syncthreads();
+    const uint32_t e = __hip_atomic_load(P.local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    peer_gate(P, 0, e, P.my_ack_flag, P.n_send, e - 1u);        // the peers have consumed the previous segments
     const int k = blockIdx.x * 256 + tid;
     if (k < count) {
         int j = 0;
@@ -912,10 +930,10 @@ __global__ __launch_bounds__(256) void peer_push_kernel(PosView pos, const float
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");         // system scope: this lane's stores are visible to the peers ...
     __syncthreads();
-    if (tid == 0) s_last = atomicAdd(P.counters + 0, 1u) == gridDim.x - 1 ? 1u : 0u;
+    if (tid == 0) s_last = atomicAdd(P.local + 1, 1u) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
     if (s_last) {                                          // ... before the last workgroup raises the flags
-        if (tid == 0) __hip_atomic_store(P.counters + 0, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (tid == 0) __hip_atomic_store(P.local + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid < P.n_send) __hip_atomic_store(P.remote_data_flag[tid], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
@@ -924,29 +942,28 @@ template <bool WITH_PREV>
 __global__ __launch_bounds__(256) void peer_unpack_kernel(PosView pos, float *prev, const int32_t *idx, const float *mailbox, int count, PeerSlot P) {
     __shared__ uint32_t s_last;
     const int tid = threadIdx.x;
-    const uint32_t e = __hip_atomic_load(P.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    if (tid < P.n_recv) peer_wait_at_least(P.my_data_flag[tid], e, P.error);
-    __syncthreads();
+    const uint32_t e = __hip_atomic_load(P.local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    peer_gate(P, 1, e, P.my_data_flag, P.n_recv, e);            // every sender's segment has arrived
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
     const int k = blockIdx.x * 256 + tid;
     if (k < count) {
         constexpr int F = WITH_PREV ? 6 : 3;
-        const float *b = mailbox + (size_t)F * k;
+        const float *b = mailbox + (size_t)F * k;              // fine-grained (uncached) memory written by the peers
         const size_t o = 3 * (size_t)idx[k];
-        // written by another agent: read at system scope
-        float v[F];
-#pragma unroll
-        for (int c = 0; c < F; ++c) v[c] = __hip_atomic_load(b + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-        pos.xyz[o] = v[0]; pos.xyz[o + 1] = v[1]; pos.xyz[o + 2] = v[2];
-        if (WITH_PREV) { prev[o] = v[3]; prev[o + 1] = v[4]; prev[o + 2] = v[5]; }
+        const f32x3 x = *reinterpret_cast<const f32x3 *>(b);
+        if (WITH_PREV) {
+            const f32x3 pv = *reinterpret_cast<const f32x3 *>(b + 3);
+            *reinterpret_cast<f32x3 *>(prev + o) = pv;
+        }
+        *reinterpret_cast<f32x3 *>(pos.xyz + o) = x;
     }
     __syncthreads();
-    if (tid == 0) s_last = atomicAdd(P.counters + 1, 1u) == gridDim.x - 1 ? 1u : 0u;
+    if (tid == 0) s_last = atomicAdd(P.local + 2, 1u) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
     if (s_last) {        // every workgroup has read its part of the mailbox: acknowledge, advance the slot's epoch
         if (tid == 0) {
-            __hip_atomic_store(P.counters + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_store(P.epoch, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(P.local + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(P.local, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
         if (tid < P.n_recv) __hip_atomic_store(P.remote_ack_flag[tid], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }

@@ -171,6 +171,7 @@ struct sb_solver {
         std::vector<uint8_t> opened;            // remote[r] was mapped with hipIpcOpenMemHandle
         std::vector<std::vector<uint32_t>> my_off;   // [slot][rank]: first word (from the mailbox start) of rank's segment in MY mailbox
         std::vector<sbk::PeerSlot> slots;
+        uint32_t *local = nullptr;              // 8 ordinary (cached) words per slot: epoch, workgroup counters, go words
         size_t slot_base(int slot, int world) const { return 1 + (size_t)slot * (2 * (size_t)world + 3); }
     } peer;
     // asynchronous render readback (sb_readback_begin / sb_readback_end): two snapshot slots
@@ -203,6 +204,7 @@ struct sb_solver {
         if (comm) (void)ncclCommDestroy(comm);
         for (size_t r = 0; r < peer.remote.size(); ++r) if (peer.opened[r] && peer.remote[r]) (void)hipIpcCloseMemHandle(peer.remote[r]);
         if (peer.mailbox) (void)hipFree(peer.mailbox);
+        if (peer.local) (void)hipFree(peer.local);
         if (ev_boundary) (void)hipEventDestroy(ev_boundary);
         if (ev_halo) (void)hipEventDestroy(ev_halo);
         if (comm_stream) (void)hipStreamDestroy(comm_stream);
@@ -677,6 +679,8 @@ void build_device(sb_solver *s) {
         s->dev_bytes += (int64_t)PS.bytes;
         HIP_CHECK(hipMemset(PS.mailbox, 0, PS.bytes));
         HIP_CHECK(hipMemcpy(PS.mailbox, header.data(), header.size() * 4, hipMemcpyHostToDevice));
+        HIP_CHECK(hipMalloc((void **)&PS.local, (size_t)PS.n_slots * 8 * sizeof(uint32_t)));
+        HIP_CHECK(hipMemset(PS.local, 0, (size_t)PS.n_slots * 8 * sizeof(uint32_t)));
         PS.remote.assign((size_t)W, nullptr);
         PS.opened.assign((size_t)W, 0);
         PS.remote[(size_t)L.rank] = PS.mailbox;
@@ -692,8 +696,7 @@ void peer_link(sb_solver *s) {
         const DevHalo &D = *s->halos[(size_t)slot];
         sbk::PeerSlot &P = PS.slots[(size_t)slot];
         const size_t base = PS.slot_base(slot, W);
-        P.epoch = PS.mailbox + base + 2 * (size_t)W;
-        P.counters = PS.mailbox + base + 2 * (size_t)W + 1;
+        P.local = PS.local + (size_t)slot * 8;
         P.error = PS.mailbox;
         for (size_t k = 0; k < D.peers.size(); ++k) {
             const int r = s->loopback ? me : D.peers[k];
