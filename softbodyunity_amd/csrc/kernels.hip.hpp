@@ -868,6 +868,10 @@ struct PeerSlot {
     int32_t send_off[kMaxPeers + 1];        // particles per send peer (prefix sums), order of the send peers
     int32_t send_cap[kMaxPeers];            // particles the peer's segment holds (a loopback self-exchange may send fewer than it packs)
     float *remote_data[kMaxPeers];          // per send peer: where this rank's segment starts inside the peer's mailbox
+    int32_t send_chunk[kMaxPeers + 1];      // 16-byte chunks per send segment (prefix sums): the mailboxes are read and written 16 bytes per lane
+    int32_t recv_off[kMaxPeers + 1];        // particles per recv peer (prefix sums), order of the recv peers
+    int32_t recv_chunk[kMaxPeers + 1];      // 16-byte chunks per recv segment (prefix sums)
+    const float *my_data[kMaxPeers];        // per recv peer: its segment in this rank's mailbox (16-byte aligned)
     uint32_t *remote_data_flag[kMaxPeers];  // per send peer: the peer's "data from this rank arrived" word
     uint32_t *my_ack_flag[kMaxPeers];       // per send peer: local word the peer writes when it has consumed the segment
     uint32_t *my_data_flag[kMaxPeers];      // per recv peer: local word the peer writes when its data is in the mailbox
@@ -905,28 +909,35 @@ __device__ __forceinline__ void peer_gate(const PeerSlot &P, int which, uint32_t
     }
 }
 
+// The mailboxes are fine-grained (uncached) memory: they are written and read 16 contiguous bytes per lane -- lane t moves
+// dwords 4t..4t+3 of a segment, i.e. parts of one or two ghosts -- while the gathers / scatters on the rank's own arrays
+// stay in its caches. A segment holds F floats per ghost (x y z [xprev yprev zprev]), ghosts back to back.
 template <bool WITH_PREV>
-__global__ __launch_bounds__(256) void peer_push_kernel(PosView pos, const float *prev, const int32_t *idx, int count, PeerSlot P) {
+__global__ __launch_bounds__(256) void peer_push_kernel(PosView pos, const float *prev, const int32_t *idx, int n_chunks, PeerSlot P) {
     __shared__ uint32_t s_last;
     const int tid = threadIdx.x;
     const uint32_t e = __hip_atomic_load(P.local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     peer_gate(P, 0, e, P.my_ack_flag, P.n_send, e - 1u);        // the peers have consumed the previous segments
-    const int k = blockIdx.x * 256 + tid;
-    if (k < count) {
+    const int t = blockIdx.x * 256 + tid;
+    if (t < n_chunks) {
         int j = 0;
 #pragma unroll
-        for (int q = 1; q < kMaxPeers; ++q) j = (q < P.n_send && k >= P.send_off[q]) ? q : j;
+        for (int q = 1; q < kMaxPeers; ++q) j = (q < P.n_send && t >= P.send_chunk[q]) ? q : j;
         constexpr int F = WITH_PREV ? 6 : 3;
-        if (k - P.send_off[j] < P.send_cap[j]) {
-            float *b = P.remote_data[j] + (size_t)F * (k - P.send_off[j]);
-            const size_t o = 3 * (size_t)idx[k];
-            const f32x3 x = *reinterpret_cast<const f32x3 *>(pos.xyz + o);
-            if (WITH_PREV) {
-                const f32x3 pv = *reinterpret_cast<const f32x3 *>(prev + o);
-                *reinterpret_cast<f32x3 *>(b + 3) = pv;
+        const int lc = t - P.send_chunk[j];
+        const int n_dw = F * min(P.send_off[j + 1] - P.send_off[j], P.send_cap[j]);     // dwords of the segment
+        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int d = 4 * lc + q;
+            if (d < n_dw) {
+                const int p = d / F, c = d - F * p;
+                const size_t o = 3 * (size_t)idx[P.send_off[j] + p];
+                const float val = (WITH_PREV && c >= 3) ? prev[o + c - 3] : pos.xyz[o + c];
+                if (q == 0) v.x = val; else if (q == 1) v.y = val; else if (q == 2) v.z = val; else v.w = val;
             }
-            *reinterpret_cast<f32x3 *>(b) = x;
         }
+        if (4 * lc < n_dw) *reinterpret_cast<f32x4 *>(P.remote_data[j] + 4 * (size_t)lc) = v;
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");         // system scope: this lane's stores are visible to the peers ...
     __syncthreads();
@@ -939,23 +950,33 @@ __global__ __launch_bounds__(256) void peer_push_kernel(PosView pos, const float
 }
 
 template <bool WITH_PREV>
-__global__ __launch_bounds__(256) void peer_unpack_kernel(PosView pos, float *prev, const int32_t *idx, const float *mailbox, int count, PeerSlot P) {
+__global__ __launch_bounds__(256) void peer_unpack_kernel(PosView pos, float *prev, const int32_t *idx, int n_chunks, PeerSlot P) {
     __shared__ uint32_t s_last;
     const int tid = threadIdx.x;
     const uint32_t e = __hip_atomic_load(P.local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     peer_gate(P, 1, e, P.my_data_flag, P.n_recv, e);            // every sender's segment has arrived
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
-    const int k = blockIdx.x * 256 + tid;
-    if (k < count) {
+    const int t = blockIdx.x * 256 + tid;
+    if (t < n_chunks) {
+        int j = 0;
+#pragma unroll
+        for (int q = 1; q < kMaxPeers; ++q) j = (q < P.n_recv && t >= P.recv_chunk[q]) ? q : j;
         constexpr int F = WITH_PREV ? 6 : 3;
-        const float *b = mailbox + (size_t)F * k;              // fine-grained (uncached) memory written by the peers
-        const size_t o = 3 * (size_t)idx[k];
-        const f32x3 x = *reinterpret_cast<const f32x3 *>(b);
-        if (WITH_PREV) {
-            const f32x3 pv = *reinterpret_cast<const f32x3 *>(b + 3);
-            *reinterpret_cast<f32x3 *>(prev + o) = pv;
+        const int lc = t - P.recv_chunk[j];
+        const int n_dw = F * (P.recv_off[j + 1] - P.recv_off[j]);
+        if (4 * lc < n_dw) {
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(P.my_data[j] + 4 * (size_t)lc);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int d = 4 * lc + q;
+                if (d < n_dw) {
+                    const int p = d / F, c = d - F * p;
+                    const size_t o = 3 * (size_t)idx[P.recv_off[j] + p];
+                    const float val = q == 0 ? v.x : (q == 1 ? v.y : (q == 2 ? v.z : v.w));
+                    if (WITH_PREV && c >= 3) prev[o + c - 3] = val; else pos.xyz[o + c] = val;
+                }
+            }
         }
-        *reinterpret_cast<f32x3 *>(pos.xyz + o) = x;
     }
     __syncthreads();
     if (tid == 0) s_last = atomicAdd(P.local + 2, 1u) == gridDim.x - 1 ? 1u : 0u;

@@ -664,11 +664,11 @@ void build_device(sb_solver *s) {
         for (int slot = 0; slot < PS.n_slots; ++slot) {
             const DevHalo &D = *s->halos[(size_t)slot];
             const size_t fl = slot == 1 ? 6 : 3;
-            for (size_t k = 0; k < D.peers.size(); ++k) {
-                PS.my_off[(size_t)slot][(size_t)D.peers[k]] = (uint32_t)(words + fl * (size_t)D.recv_off[k]);
-                header[PS.off_table + (size_t)slot * W + (size_t)D.peers[k]] = (uint32_t)(words + fl * (size_t)D.recv_off[k]);
+            for (size_t k = 0; k < D.peers.size(); ++k) {          // one 16-byte aligned segment per sending neighbour
+                PS.my_off[(size_t)slot][(size_t)D.peers[k]] = (uint32_t)words;
+                header[PS.off_table + (size_t)slot * W + (size_t)D.peers[k]] = (uint32_t)words;
+                words += (fl * (size_t)(D.recv_off[k + 1] - D.recv_off[k]) + 3) & ~(size_t)3;
             }
-            words += fl * (size_t)D.recv_off.back();
             words = (words + 63) & ~(size_t)63;
         }
         PS.bytes = words * 4;
@@ -696,6 +696,7 @@ void peer_link(sb_solver *s) {
         const DevHalo &D = *s->halos[(size_t)slot];
         sbk::PeerSlot &P = PS.slots[(size_t)slot];
         const size_t base = PS.slot_base(slot, W);
+        const size_t fl = slot == 1 ? 6 : 3;
         P.local = PS.local + (size_t)slot * 8;
         P.error = PS.mailbox;
         for (size_t k = 0; k < D.peers.size(); ++k) {
@@ -713,6 +714,7 @@ void peer_link(sb_solver *s) {
                 if (off == 0) throw std::runtime_error("peer transport: a neighbour's mailbox has no segment for this rank");
                 P.send_off[P.n_send] = D.send_off[k];
                 P.send_cap[P.n_send] = s->loopback ? std::min(cs, cr) : INT32_MAX;
+                P.send_chunk[P.n_send + 1] = P.send_chunk[P.n_send] + (int32_t)((fl * (size_t)std::min(cs, P.send_cap[P.n_send]) + 3) / 4);
                 P.remote_data[P.n_send] = reinterpret_cast<float *>(rm + off);
                 P.remote_data_flag[P.n_send] = rm + base + (size_t)(s->loopback ? D.peers[k] : me);
                 P.my_ack_flag[P.n_send] = PS.mailbox + base + (size_t)W + (size_t)D.peers[k];
@@ -720,12 +722,17 @@ void peer_link(sb_solver *s) {
                 P.send_off[P.n_send] = D.send_off[k + 1];
             }
             if (cr) {
+                P.recv_off[P.n_recv] = D.recv_off[k];
+                P.recv_off[P.n_recv + 1] = D.recv_off[k + 1];
+                P.recv_chunk[P.n_recv + 1] = P.recv_chunk[P.n_recv] + (int32_t)((fl * (size_t)cr + 3) / 4);
+                P.my_data[P.n_recv] = reinterpret_cast<const float *>(PS.mailbox + PS.my_off[(size_t)slot][(size_t)D.peers[k]]);
                 P.my_data_flag[P.n_recv] = PS.mailbox + base + (size_t)D.peers[k];
                 P.remote_ack_flag[P.n_recv] = rm + base + (size_t)W + (size_t)(s->loopback ? D.peers[k] : me);
                 ++P.n_recv;
             }
         }
-        for (int q = P.n_send + 1; q <= sbk::kMaxPeers; ++q) P.send_off[q] = INT32_MAX;
+        for (int q = P.n_send + 1; q <= sbk::kMaxPeers; ++q) { P.send_off[q] = INT32_MAX; P.send_chunk[q] = INT32_MAX; }
+        for (int q = P.n_recv + 1; q <= sbk::kMaxPeers; ++q) P.recv_chunk[q] = INT32_MAX;
     }
     PS.linked = true;
 }
@@ -742,24 +749,18 @@ void halo_exchange(sb_solver *s, int slot, hipStream_t st = nullptr) {
     if (s->peer.enabled) {
         if (!s->peer.linked) peer_link(s);
         const sbk::PeerSlot &P = s->peer.slots[(size_t)slot];
-        if (ns) {
+        const int push_chunks = P.n_send ? P.send_chunk[P.n_send] : 0, unpack_chunks = P.n_recv ? P.recv_chunk[P.n_recv] : 0;
+        if (push_chunks) {
             if (with_prev)
-                hipLaunchKernelGGL(sbk::peer_push_kernel<true>, dim3((ns + 255) / 256), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.send_idx.p, ns, P);
+                hipLaunchKernelGGL(sbk::peer_push_kernel<true>, dim3((push_chunks + 255) / 256), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.send_idx.p, push_chunks, P);
             else
-                hipLaunchKernelGGL(sbk::peer_push_kernel<false>, dim3((ns + 255) / 256), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.send_idx.p, ns, P);
+                hipLaunchKernelGGL(sbk::peer_push_kernel<false>, dim3((push_chunks + 255) / 256), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.send_idx.p, push_chunks, P);
         }
         // (always launched for an active slot: it also advances the slot's epoch)
-        const float *mb = reinterpret_cast<const float *>(s->peer.mailbox + s->peer.my_off[(size_t)slot][(size_t)D.peers[0]]);
-        // the segments of a slot are contiguous in rank order, the first receiving peer's segment starts the slot's region
-        {
-            size_t first = SIZE_MAX;
-            for (size_t k = 0; k < D.peers.size(); ++k) if (D.recv_off[k + 1] > D.recv_off[k]) { first = k; break; }
-            if (first != SIZE_MAX) mb = reinterpret_cast<const float *>(s->peer.mailbox + s->peer.my_off[(size_t)slot][(size_t)D.peers[first]]);
-        }
         if (with_prev)
-            hipLaunchKernelGGL(sbk::peer_unpack_kernel<true>, dim3(std::max(1, (nr + 255) / 256)), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.recv_idx.p, mb, nr, P);
+            hipLaunchKernelGGL(sbk::peer_unpack_kernel<true>, dim3(std::max(1, (unpack_chunks + 255) / 256)), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.recv_idx.p, unpack_chunks, P);
         else
-            hipLaunchKernelGGL(sbk::peer_unpack_kernel<false>, dim3(std::max(1, (nr + 255) / 256)), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.recv_idx.p, mb, nr, P);
+            hipLaunchKernelGGL(sbk::peer_unpack_kernel<false>, dim3(std::max(1, (unpack_chunks + 255) / 256)), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.recv_idx.p, unpack_chunks, P);
         return;
     }
     if (!s->comm) throw HipError(SB_ERR_STATE, "world > 1 needs sb_comm_init before sb_finalize");
