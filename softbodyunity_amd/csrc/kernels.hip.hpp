@@ -884,7 +884,7 @@ constexpr int kPeerSpinLimit = 1 << 24;
 
 __device__ __forceinline__ void peer_wait_at_least(const uint32_t *flag, uint32_t want, uint32_t *error) {
     int spins = 0;
-    while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
+    while ((int32_t)(__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {     // (uncached word: no cache maintenance)
         __builtin_amdgcn_s_sleep(8);
         if (++spins > kPeerSpinLimit) { __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
     }
@@ -896,11 +896,11 @@ __device__ __forceinline__ void peer_gate(const PeerSlot &P, int which, uint32_t
     if (blockIdx.x == 0) {
         if ((int)threadIdx.x < n_flags) peer_wait_at_least(flags[threadIdx.x], want, P.error);
         __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(go, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        if (threadIdx.x == 0) __hip_atomic_store(go, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     } else {
         if (threadIdx.x == 0) {
             int spins = 0;
-            while ((int32_t)(__hip_atomic_load(go, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) - e) < 0) {
+            while ((int32_t)(__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - e) < 0) {
                 __builtin_amdgcn_s_sleep(2);
                 if (++spins > kPeerSpinLimit) { __hip_atomic_store(P.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
             }
@@ -939,13 +939,16 @@ __global__ __launch_bounds__(256) void peer_push_kernel(PosView pos, const float
         }
         if (4 * lc < n_dw) *reinterpret_cast<f32x4 *>(P.remote_data[j] + 4 * (size_t)lc) = v;
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");         // system scope: this lane's stores are visible to the peers ...
+    // The mailbox is uncached memory: a store is visible to every agent once the memory system has acknowledged it, so
+    // waiting for this wave's stores (vmcnt 0) orders them before the flag -- a release FENCE at system scope would write
+    // back the whole L2 (the tile kernels' dirty lines), once per wave.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (tid == 0) s_last = atomicAdd(P.local + 1, 1u) == gridDim.x - 1 ? 1u : 0u;
+    if (tid == 0) s_last = __hip_atomic_fetch_add(P.local + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
-    if (s_last) {                                          // ... before the last workgroup raises the flags
+    if (s_last) {                                          // every workgroup's stores have landed: raise the flags
         if (tid == 0) __hip_atomic_store(P.local + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (tid < P.n_send) __hip_atomic_store(P.remote_data_flag[tid], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid < P.n_send) __hip_atomic_store(P.remote_data_flag[tid], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -955,7 +958,7 @@ __global__ __launch_bounds__(256) void peer_unpack_kernel(PosView pos, float *pr
     const int tid = threadIdx.x;
     const uint32_t e = __hip_atomic_load(P.local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     peer_gate(P, 1, e, P.my_data_flag, P.n_recv, e);            // every sender's segment has arrived
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+    asm volatile("" ::: "memory");                              // (the mailbox is uncached: nothing to invalidate)
     const int t = blockIdx.x * 256 + tid;
     if (t < n_chunks) {
         int j = 0;
@@ -978,15 +981,16 @@ __global__ __launch_bounds__(256) void peer_unpack_kernel(PosView pos, float *pr
             }
         }
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's mailbox reads are done
     __syncthreads();
-    if (tid == 0) s_last = atomicAdd(P.local + 2, 1u) == gridDim.x - 1 ? 1u : 0u;
+    if (tid == 0) s_last = __hip_atomic_fetch_add(P.local + 2, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
     __syncthreads();
     if (s_last) {        // every workgroup has read its part of the mailbox: acknowledge, advance the slot's epoch
         if (tid == 0) {
             __hip_atomic_store(P.local + 2, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             __hip_atomic_store(P.local, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        if (tid < P.n_recv) __hip_atomic_store(P.remote_ack_flag[tid], e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid < P.n_recv) __hip_atomic_store(P.remote_ack_flag[tid], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
