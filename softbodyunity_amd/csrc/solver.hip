@@ -673,7 +673,9 @@ void build_device(sb_solver *s) {
         }
         PS.bytes = words * 4;
         void *mb = nullptr;
-        if (hipExtMallocWithFlags(&mb, PS.bytes, hipDeviceMallocFinegrained) == hipSuccess) PS.fine_grained = true;
+        // (SB_PEER_COARSE: an ordinary cached allocation -- timing experiments on ONE device only; between devices the flags and
+        // segments must be uncached for the stores of one agent to reach the loads of another without cache maintenance)
+        if (!std::getenv("SB_PEER_COARSE") && hipExtMallocWithFlags(&mb, PS.bytes, hipDeviceMallocFinegrained) == hipSuccess) PS.fine_grained = true;
         else { (void)hipGetLastError(); HIP_CHECK(hipMalloc(&mb, PS.bytes)); }
         PS.mailbox = (uint32_t *)mb;
         s->dev_bytes += (int64_t)PS.bytes;
