@@ -877,7 +877,7 @@ struct PeerSlot {
     uint32_t *my_data_flag[kMaxPeers];      // per recv peer: local word the peer writes when its data is in the mailbox
     uint32_t *remote_ack_flag[kMaxPeers];   // per recv peer: the peer's "consumed" word for this rank
     uint32_t *local;                        // this rank's own (ordinary, cached) words for the slot: [0] exchanges completed so far,
-                                            // [1] push / [2] unpack workgroups finished, [3] push / [4] unpack "go" (epoch the waits have passed)
+                                            // [1] push / [2] unpack workgroups finished
     uint32_t *error;                        // set to 1 when a wait gave up
 };
 constexpr int kPeerSpinLimit = 1 << 24;
@@ -890,23 +890,15 @@ __device__ __forceinline__ void peer_wait_at_least(const uint32_t *flag, uint32_
     }
 }
 
-// Workgroup 0 polls the (uncached) flags in the mailbox; everybody else waits for its "go" word in ordinary memory.
-__device__ __forceinline__ void peer_gate(const PeerSlot &P, int which, uint32_t e, uint32_t *const *flags, int n_flags, uint32_t want) {
-    uint32_t *go = P.local + 3 + which;
-    if (blockIdx.x == 0) {
-        if ((int)threadIdx.x < n_flags) peer_wait_at_least(flags[threadIdx.x], want, P.error);
-        __syncthreads();
-        if (threadIdx.x == 0) __hip_atomic_store(go, e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {
-        if (threadIdx.x == 0) {
-            int spins = 0;
-            while ((int32_t)(__hip_atomic_load(go, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - e) < 0) {
-                __builtin_amdgcn_s_sleep(2);
-                if (++spins > kPeerSpinLimit) { __hip_atomic_store(P.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
-            }
-        }
-        __syncthreads();
-    }
+// The waits run in a ONE-workgroup kernel of their own ahead of the bulk kernel (stream order does the rest): a bulk kernel
+// whose every workgroup waited would fill the GPU with waiting workgroups, and on a device shared by several ranks (the
+// multi-process tests) the neighbour's kernels could then never start.
+// which = 0: before a push -- the neighbours have consumed the previous segments (their acknowledgements >= epoch);
+// which = 1: before an unpack -- every sender's segment of this exchange has arrived (data flags >= epoch + 1).
+__global__ __launch_bounds__(64) void peer_gate_kernel(PeerSlot P, int which) {
+    const uint32_t done = __hip_atomic_load(P.local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int n = which == 0 ? P.n_send : P.n_recv;
+    if ((int)threadIdx.x < n) peer_wait_at_least(which == 0 ? P.my_ack_flag[threadIdx.x] : P.my_data_flag[threadIdx.x], which == 0 ? done : done + 1u, P.error);
 }
 
 // The mailboxes are fine-grained (uncached) memory: they are written and read 16 contiguous bytes per lane -- lane t moves
@@ -917,7 +909,6 @@ __global__ __launch_bounds__(256) void peer_push_kernel(PosView pos, const float
     __shared__ uint32_t s_last;
     const int tid = threadIdx.x;
     const uint32_t e = __hip_atomic_load(P.local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    peer_gate(P, 0, e, P.my_ack_flag, P.n_send, e - 1u);        // the peers have consumed the previous segments
     const int t = blockIdx.x * 256 + tid;
     if (t < n_chunks) {
         int j = 0;
@@ -957,8 +948,6 @@ __global__ __launch_bounds__(256) void peer_unpack_kernel(PosView pos, float *pr
     __shared__ uint32_t s_last;
     const int tid = threadIdx.x;
     const uint32_t e = __hip_atomic_load(P.local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    peer_gate(P, 1, e, P.my_data_flag, P.n_recv, e);            // every sender's segment has arrived
-    asm volatile("" ::: "memory");                              // (the mailbox is uncached: nothing to invalidate)
     const int t = blockIdx.x * 256 + tid;
     if (t < n_chunks) {
         int j = 0;

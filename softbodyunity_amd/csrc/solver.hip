@@ -753,12 +753,14 @@ void halo_exchange(sb_solver *s, int slot, hipStream_t st = nullptr) {
         const sbk::PeerSlot &P = s->peer.slots[(size_t)slot];
         const int push_chunks = P.n_send ? P.send_chunk[P.n_send] : 0, unpack_chunks = P.n_recv ? P.recv_chunk[P.n_recv] : 0;
         if (push_chunks) {
+            hipLaunchKernelGGL(sbk::peer_gate_kernel, dim3(1), dim3(64), 0, st, P, 0);
             if (with_prev)
                 hipLaunchKernelGGL(sbk::peer_push_kernel<true>, dim3((push_chunks + 255) / 256), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.send_idx.p, push_chunks, P);
             else
                 hipLaunchKernelGGL(sbk::peer_push_kernel<false>, dim3((push_chunks + 255) / 256), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.send_idx.p, push_chunks, P);
         }
         // (always launched for an active slot: it also advances the slot's epoch)
+        if (unpack_chunks) hipLaunchKernelGGL(sbk::peer_gate_kernel, dim3(1), dim3(64), 0, st, P, 1);
         if (with_prev)
             hipLaunchKernelGGL(sbk::peer_unpack_kernel<true>, dim3(std::max(1, (unpack_chunks + 255) / 256)), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.recv_idx.p, unpack_chunks, P);
         else
