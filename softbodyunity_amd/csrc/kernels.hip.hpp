@@ -856,18 +856,22 @@ __global__ __launch_bounds__(256) void halo_unpack_kernel(PosView pos, float *pr
 }
 
 // ---- peer-store halo transport (opt-in, SB_HALO_TRANSPORT=peer; solver.hip) ---------------------------------------
-// Instead of pack -> ncclSend/ncclRecv -> unpack, the pack kernel stores every peer's ghosts STRAIGHT into that peer's
+// Instead of pack -> ncclSend/ncclRecv -> unpack, the push kernel stores every peer's ghosts STRAIGHT into that peer's
 // mailbox (one fine-grained device allocation per rank, mapped into the senders by IPC handle or, inside one process, by
-// plain pointer) and raises a flag there; the receiver's unpack kernel waits for the flags of its senders, copies the
-// ghosts into its arrays and acknowledges, which lets the senders reuse the mailbox. Epochs count the exchanges of a
-// halo slot, live in device memory and are advanced by the kernels themselves, so the launches sit in a captured
-// hipGraph unchanged. Every wait is bounded: a flag that never arrives sets an error word instead of hanging the GPU.
+// plain pointer) and raises a flag there; its last workgroup then waits until the flags of this rank's own senders have
+// arrived, so the unpack kernel behind it in the stream can copy the ghosts into the arrays and acknowledge. A segment
+// has two buffers used alternately (epoch & 1): exchange e writes the buffer exchange e-2 used, and a rank finishes
+// exchange e only after its receivers acknowledged e-1, so no sender ever waits before writing. Epochs count the
+// exchanges of a halo slot, live in device memory and are advanced by the kernels themselves: the launches sit in a
+// captured hipGraph unchanged. Every wait is bounded: a flag that never arrives sets an error word instead of hanging.
 constexpr int kMaxPeers = 8;
 struct PeerSlot {
     int32_t n_send, n_recv;                 // peers this rank sends to / receives from on this halo slot
     int32_t send_off[kMaxPeers + 1];        // particles per send peer (prefix sums), order of the send peers
     int32_t send_cap[kMaxPeers];            // particles the peer's segment holds (a loopback self-exchange may send fewer than it packs)
     float *remote_data[kMaxPeers];          // per send peer: where this rank's segment starts inside the peer's mailbox
+    int32_t remote_stride[kMaxPeers];       // floats between the two buffers of that segment (exchanges alternate: epoch & 1)
+    int32_t my_stride[kMaxPeers];           // per recv peer: the same for the segments in this rank's mailbox
     int32_t send_chunk[kMaxPeers + 1];      // 16-byte chunks per send segment (prefix sums): the mailboxes are read and written 16 bytes per lane
     int32_t recv_off[kMaxPeers + 1];        // particles per recv peer (prefix sums), order of the recv peers
     int32_t recv_chunk[kMaxPeers + 1];      // 16-byte chunks per recv segment (prefix sums)
@@ -888,17 +892,6 @@ __device__ __forceinline__ void peer_wait_at_least(const uint32_t *flag, uint32_
         __builtin_amdgcn_s_sleep(8);
         if (++spins > kPeerSpinLimit) { __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); break; }
     }
-}
-
-// The waits run in a ONE-workgroup kernel of their own ahead of the bulk kernel (stream order does the rest): a bulk kernel
-// whose every workgroup waited would fill the GPU with waiting workgroups, and on a device shared by several ranks (the
-// multi-process tests) the neighbour's kernels could then never start.
-// which = 0: before a push -- the neighbours have consumed the previous segments (their acknowledgements >= epoch);
-// which = 1: before an unpack -- every sender's segment of this exchange has arrived (data flags >= epoch + 1).
-__global__ __launch_bounds__(64) void peer_gate_kernel(PeerSlot P, int which) {
-    const uint32_t done = __hip_atomic_load(P.local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int n = which == 0 ? P.n_send : P.n_recv;
-    if ((int)threadIdx.x < n) peer_wait_at_least(which == 0 ? P.my_ack_flag[threadIdx.x] : P.my_data_flag[threadIdx.x], which == 0 ? done : done + 1u, P.error);
 }
 
 // The mailboxes are fine-grained (uncached) memory: they are written and read 16 contiguous bytes per lane -- lane t moves
@@ -928,7 +921,7 @@ __global__ __launch_bounds__(256) void peer_push_kernel(PosView pos, const float
                 if (q == 0) v.x = val; else if (q == 1) v.y = val; else if (q == 2) v.z = val; else v.w = val;
             }
         }
-        if (4 * lc < n_dw) *reinterpret_cast<f32x4 *>(P.remote_data[j] + 4 * (size_t)lc) = v;
+        if (4 * lc < n_dw) *reinterpret_cast<f32x4 *>(P.remote_data[j] + (size_t)(e & 1u) * P.remote_stride[j] + 4 * (size_t)lc) = v;
     }
     // The mailbox is uncached memory: a store is visible to every agent once the memory system has acknowledged it, so
     // waiting for this wave's stores (vmcnt 0) orders them before the flag -- a release FENCE at system scope would write
@@ -940,6 +933,11 @@ __global__ __launch_bounds__(256) void peer_push_kernel(PosView pos, const float
     if (s_last) {                                          // every workgroup's stores have landed: raise the flags
         if (tid == 0) __hip_atomic_store(P.local + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (tid < P.n_send) __hip_atomic_store(P.remote_data_flag[tid], e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        // ... and (this ONE workgroup: a launch full of waiting workgroups would starve the neighbours on a shared device)
+        // wait for what the next kernels in the stream need: this exchange's segments from every sender, and the receivers'
+        // acknowledgement of the PREVIOUS exchange, which frees the buffer the next exchange will write
+        if (tid < P.n_recv) peer_wait_at_least(P.my_data_flag[tid], e, P.error);
+        if (tid < P.n_send) peer_wait_at_least(P.my_ack_flag[tid], e - 1u, P.error);
     }
 }
 
@@ -957,7 +955,7 @@ __global__ __launch_bounds__(256) void peer_unpack_kernel(PosView pos, float *pr
         const int lc = t - P.recv_chunk[j];
         const int n_dw = F * (P.recv_off[j + 1] - P.recv_off[j]);
         if (4 * lc < n_dw) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(P.my_data[j] + 4 * (size_t)lc);
+            const f32x4 v = *reinterpret_cast<const f32x4 *>(P.my_data[j] + (size_t)(e & 1u) * P.my_stride[j] + 4 * (size_t)lc);
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 const int d = 4 * lc + q;

@@ -667,7 +667,7 @@ void build_device(sb_solver *s) {
             for (size_t k = 0; k < D.peers.size(); ++k) {          // one 16-byte aligned segment per sending neighbour
                 PS.my_off[(size_t)slot][(size_t)D.peers[k]] = (uint32_t)words;
                 header[PS.off_table + (size_t)slot * W + (size_t)D.peers[k]] = (uint32_t)words;
-                words += (fl * (size_t)(D.recv_off[k + 1] - D.recv_off[k]) + 3) & ~(size_t)3;
+                words += 2 * ((fl * (size_t)(D.recv_off[k + 1] - D.recv_off[k]) + 3) & ~(size_t)3);      // two buffers, used alternately
             }
             words = (words + 63) & ~(size_t)63;
         }
@@ -718,6 +718,7 @@ void peer_link(sb_solver *s) {
                 P.send_cap[P.n_send] = s->loopback ? std::min(cs, cr) : INT32_MAX;
                 P.send_chunk[P.n_send + 1] = P.send_chunk[P.n_send] + (int32_t)((fl * (size_t)std::min(cs, P.send_cap[P.n_send]) + 3) / 4);
                 P.remote_data[P.n_send] = reinterpret_cast<float *>(rm + off);
+                P.remote_stride[P.n_send] = (int32_t)((fl * (size_t)(s->loopback ? cr : cs) + 3) & ~(size_t)3);     // = the receiver's segment size
                 P.remote_data_flag[P.n_send] = rm + base + (size_t)(s->loopback ? D.peers[k] : me);
                 P.my_ack_flag[P.n_send] = PS.mailbox + base + (size_t)W + (size_t)D.peers[k];
                 ++P.n_send;
@@ -728,6 +729,7 @@ void peer_link(sb_solver *s) {
                 P.recv_off[P.n_recv + 1] = D.recv_off[k + 1];
                 P.recv_chunk[P.n_recv + 1] = P.recv_chunk[P.n_recv] + (int32_t)((fl * (size_t)cr + 3) / 4);
                 P.my_data[P.n_recv] = reinterpret_cast<const float *>(PS.mailbox + PS.my_off[(size_t)slot][(size_t)D.peers[k]]);
+                P.my_stride[P.n_recv] = (int32_t)((fl * (size_t)cr + 3) & ~(size_t)3);
                 P.my_data_flag[P.n_recv] = PS.mailbox + base + (size_t)D.peers[k];
                 P.remote_ack_flag[P.n_recv] = rm + base + (size_t)W + (size_t)(s->loopback ? D.peers[k] : me);
                 ++P.n_recv;
@@ -752,19 +754,14 @@ void halo_exchange(sb_solver *s, int slot, hipStream_t st = nullptr) {
         if (!s->peer.linked) peer_link(s);
         const sbk::PeerSlot &P = s->peer.slots[(size_t)slot];
         const int push_chunks = P.n_send ? P.send_chunk[P.n_send] : 0, unpack_chunks = P.n_recv ? P.recv_chunk[P.n_recv] : 0;
-        if (push_chunks) {
-            hipLaunchKernelGGL(sbk::peer_gate_kernel, dim3(1), dim3(64), 0, st, P, 0);
-            if (with_prev)
-                hipLaunchKernelGGL(sbk::peer_push_kernel<true>, dim3((push_chunks + 255) / 256), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.send_idx.p, push_chunks, P);
-            else
-                hipLaunchKernelGGL(sbk::peer_push_kernel<false>, dim3((push_chunks + 255) / 256), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.send_idx.p, push_chunks, P);
-        }
-        // (always launched for an active slot: it also advances the slot's epoch)
-        if (unpack_chunks) hipLaunchKernelGGL(sbk::peer_gate_kernel, dim3(1), dim3(64), 0, st, P, 1);
-        if (with_prev)
+        // two launches per exchange, both always (the push also carries the waits, the unpack advances the slot's epoch)
+        if (with_prev) {
+            hipLaunchKernelGGL(sbk::peer_push_kernel<true>, dim3(std::max(1, (push_chunks + 255) / 256)), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.send_idx.p, push_chunks, P);
             hipLaunchKernelGGL(sbk::peer_unpack_kernel<true>, dim3(std::max(1, (unpack_chunks + 255) / 256)), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.recv_idx.p, unpack_chunks, P);
-        else
+        } else {
+            hipLaunchKernelGGL(sbk::peer_push_kernel<false>, dim3(std::max(1, (push_chunks + 255) / 256)), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.send_idx.p, push_chunks, P);
             hipLaunchKernelGGL(sbk::peer_unpack_kernel<false>, dim3(std::max(1, (unpack_chunks + 255) / 256)), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.recv_idx.p, unpack_chunks, P);
+        }
         return;
     }
     if (!s->comm) throw HipError(SB_ERR_STATE, "world > 1 needs sb_comm_init before sb_finalize");
