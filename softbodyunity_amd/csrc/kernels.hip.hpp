@@ -867,14 +867,13 @@ __global__ __launch_bounds__(256) void halo_unpack_kernel(PosView pos, float *pr
 constexpr int kMaxPeers = 8;
 struct PeerSlot {
     int32_t n_send, n_recv;                 // peers this rank sends to / receives from on this halo slot
-    int32_t send_off[kMaxPeers + 1];        // particles per send peer (prefix sums), order of the send peers
-    int32_t send_cap[kMaxPeers];            // particles the peer's segment holds (a loopback self-exchange may send fewer than it packs)
+    int32_t send_off[kMaxPeers + 1];        // first ghost of every send peer in send_idx, order of the send peers
+    int32_t send_cap[kMaxPeers];            // ghosts pushed to that peer (a loopback self-exchange may push fewer than it packs)
     float *remote_data[kMaxPeers];          // per send peer: where this rank's segment starts inside the peer's mailbox
     int32_t remote_stride[kMaxPeers];       // floats between the two buffers of that segment (exchanges alternate: epoch & 1)
     int32_t my_stride[kMaxPeers];           // per recv peer: the same for the segments in this rank's mailbox
-    int32_t send_chunk[kMaxPeers + 1];      // 16-byte chunks per send segment (prefix sums): the mailboxes are read and written 16 bytes per lane
-    int32_t recv_off[kMaxPeers + 1];        // particles per recv peer (prefix sums), order of the recv peers
-    int32_t recv_chunk[kMaxPeers + 1];      // 16-byte chunks per recv segment (prefix sums)
+    int32_t recv_off[kMaxPeers + 1];        // first ghost of every recv peer in recv_idx, order of the recv peers
+    int32_t recv_cnt[kMaxPeers];            // ghosts per recv peer
     const float *my_data[kMaxPeers];        // per recv peer: its segment in this rank's mailbox (16-byte aligned)
     uint32_t *remote_data_flag[kMaxPeers];  // per send peer: the peer's "data from this rank arrived" word
     uint32_t *my_ack_flag[kMaxPeers];       // per send peer: local word the peer writes when it has consumed the segment
@@ -894,34 +893,30 @@ __device__ __forceinline__ void peer_wait_at_least(const uint32_t *flag, uint32_
     }
 }
 
-// The mailboxes are fine-grained (uncached) memory: they are written and read 16 contiguous bytes per lane -- lane t moves
-// dwords 4t..4t+3 of a segment, i.e. parts of one or two ghosts -- while the gathers / scatters on the rank's own arrays
-// stay in its caches. A segment holds F floats per ghost (x y z [xprev yprev zprev]), ghosts back to back.
+// A segment holds F floats per ghost (x y z [xprev yprev zprev]), ghosts back to back; one lane moves one ghost (a wave
+// covers a contiguous stretch of the segment; 16-byte chunks per lane with four gathers each were no faster).
 template <bool WITH_PREV>
 __global__ __launch_bounds__(256) void peer_push_kernel(PosView pos, const float *prev, const int32_t *idx, int n_chunks, PeerSlot P) {
     __shared__ uint32_t s_last;
     const int tid = threadIdx.x;
     const uint32_t e = __hip_atomic_load(P.local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    const int t = blockIdx.x * 256 + tid;
-    if (t < n_chunks) {
+    const int k = blockIdx.x * 256 + tid;        // one ghost per lane: 24 (12) contiguous bytes of the segment
+    if (k < n_chunks) {
         int j = 0;
 #pragma unroll
-        for (int q = 1; q < kMaxPeers; ++q) j = (q < P.n_send && t >= P.send_chunk[q]) ? q : j;
+        for (int q = 1; q < kMaxPeers; ++q) j = (q < P.n_send && k >= P.send_off[q]) ? q : j;
         constexpr int F = WITH_PREV ? 6 : 3;
-        const int lc = t - P.send_chunk[j];
-        const int n_dw = F * min(P.send_off[j + 1] - P.send_off[j], P.send_cap[j]);     // dwords of the segment
-        f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int d = 4 * lc + q;
-            if (d < n_dw) {
-                const int p = d / F, c = d - F * p;
-                const size_t o = 3 * (size_t)idx[P.send_off[j] + p];
-                const float val = (WITH_PREV && c >= 3) ? prev[o + c - 3] : pos.xyz[o + c];
-                if (q == 0) v.x = val; else if (q == 1) v.y = val; else if (q == 2) v.z = val; else v.w = val;
+        const int lk = k - P.send_off[j];
+        if (lk >= 0 && lk < P.send_cap[j]) {      // (a neighbour this rank packs for but does not push to leaves a gap in k)
+            float *b = P.remote_data[j] + (size_t)(e & 1u) * P.remote_stride[j] + (size_t)F * lk;
+            const size_t o = 3 * (size_t)idx[k];
+            const f32x3 x = *reinterpret_cast<const f32x3 *>(pos.xyz + o);
+            if (WITH_PREV) {
+                const f32x3 pv = *reinterpret_cast<const f32x3 *>(prev + o);
+                *reinterpret_cast<f32x3 *>(b + 3) = pv;
             }
+            *reinterpret_cast<f32x3 *>(b) = x;
         }
-        if (4 * lc < n_dw) *reinterpret_cast<f32x4 *>(P.remote_data[j] + (size_t)(e & 1u) * P.remote_stride[j] + 4 * (size_t)lc) = v;
     }
     // The mailbox is uncached memory: a store is visible to every agent once the memory system has acknowledged it, so
     // waiting for this wave's stores (vmcnt 0) orders them before the flag -- a release FENCE at system scope would write
@@ -946,26 +941,22 @@ __global__ __launch_bounds__(256) void peer_unpack_kernel(PosView pos, float *pr
     __shared__ uint32_t s_last;
     const int tid = threadIdx.x;
     const uint32_t e = __hip_atomic_load(P.local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    const int t = blockIdx.x * 256 + tid;
-    if (t < n_chunks) {
+    const int k = blockIdx.x * 256 + tid;        // one ghost per lane
+    if (k < n_chunks) {
         int j = 0;
 #pragma unroll
-        for (int q = 1; q < kMaxPeers; ++q) j = (q < P.n_recv && t >= P.recv_chunk[q]) ? q : j;
+        for (int q = 1; q < kMaxPeers; ++q) j = (q < P.n_recv && k >= P.recv_off[q]) ? q : j;
         constexpr int F = WITH_PREV ? 6 : 3;
-        const int lc = t - P.recv_chunk[j];
-        const int n_dw = F * (P.recv_off[j + 1] - P.recv_off[j]);
-        if (4 * lc < n_dw) {
-            const f32x4 v = *reinterpret_cast<const f32x4 *>(P.my_data[j] + (size_t)(e & 1u) * P.my_stride[j] + 4 * (size_t)lc);
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int d = 4 * lc + q;
-                if (d < n_dw) {
-                    const int p = d / F, c = d - F * p;
-                    const size_t o = 3 * (size_t)idx[P.recv_off[j] + p];
-                    const float val = q == 0 ? v.x : (q == 1 ? v.y : (q == 2 ? v.z : v.w));
-                    if (WITH_PREV && c >= 3) prev[o + c - 3] = val; else pos.xyz[o + c] = val;
-                }
+        const int lk = k - P.recv_off[j];
+        if (lk >= 0 && lk < P.recv_cnt[j]) {
+            const float *b = P.my_data[j] + (size_t)(e & 1u) * P.my_stride[j] + (size_t)F * lk;
+            const size_t o = 3 * (size_t)idx[k];
+            const f32x3 x = *reinterpret_cast<const f32x3 *>(b);
+            if (WITH_PREV) {
+                const f32x3 pv = *reinterpret_cast<const f32x3 *>(b + 3);
+                *reinterpret_cast<f32x3 *>(prev + o) = pv;
             }
+            *reinterpret_cast<f32x3 *>(pos.xyz + o) = x;
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's mailbox reads are done

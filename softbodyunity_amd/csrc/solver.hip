@@ -715,8 +715,7 @@ void peer_link(sb_solver *s) {
                 else HIP_CHECK(hipMemcpy(&off, rm + PS.off_table + (size_t)slot * W + (size_t)me, 4, hipMemcpyDeviceToHost));
                 if (off == 0) throw std::runtime_error("peer transport: a neighbour's mailbox has no segment for this rank");
                 P.send_off[P.n_send] = D.send_off[k];
-                P.send_cap[P.n_send] = s->loopback ? std::min(cs, cr) : INT32_MAX;
-                P.send_chunk[P.n_send + 1] = P.send_chunk[P.n_send] + (int32_t)((fl * (size_t)std::min(cs, P.send_cap[P.n_send]) + 3) / 4);
+                P.send_cap[P.n_send] = s->loopback ? std::min(cs, cr) : cs;
                 P.remote_data[P.n_send] = reinterpret_cast<float *>(rm + off);
                 P.remote_stride[P.n_send] = (int32_t)((fl * (size_t)(s->loopback ? cr : cs) + 3) & ~(size_t)3);     // = the receiver's segment size
                 P.remote_data_flag[P.n_send] = rm + base + (size_t)(s->loopback ? D.peers[k] : me);
@@ -727,7 +726,7 @@ void peer_link(sb_solver *s) {
             if (cr) {
                 P.recv_off[P.n_recv] = D.recv_off[k];
                 P.recv_off[P.n_recv + 1] = D.recv_off[k + 1];
-                P.recv_chunk[P.n_recv + 1] = P.recv_chunk[P.n_recv] + (int32_t)((fl * (size_t)cr + 3) / 4);
+                P.recv_cnt[P.n_recv] = cr;
                 P.my_data[P.n_recv] = reinterpret_cast<const float *>(PS.mailbox + PS.my_off[(size_t)slot][(size_t)D.peers[k]]);
                 P.my_stride[P.n_recv] = (int32_t)((fl * (size_t)cr + 3) & ~(size_t)3);
                 P.my_data_flag[P.n_recv] = PS.mailbox + base + (size_t)D.peers[k];
@@ -735,8 +734,8 @@ void peer_link(sb_solver *s) {
                 ++P.n_recv;
             }
         }
-        for (int q = P.n_send + 1; q <= sbk::kMaxPeers; ++q) { P.send_off[q] = INT32_MAX; P.send_chunk[q] = INT32_MAX; }
-        for (int q = P.n_recv + 1; q <= sbk::kMaxPeers; ++q) P.recv_chunk[q] = INT32_MAX;
+        for (int q = P.n_send + 1; q <= sbk::kMaxPeers; ++q) P.send_off[q] = INT32_MAX;
+        for (int q = P.n_recv + 1; q <= sbk::kMaxPeers; ++q) P.recv_off[q] = INT32_MAX;
     }
     PS.linked = true;
 }
@@ -753,7 +752,7 @@ void halo_exchange(sb_solver *s, int slot, hipStream_t st = nullptr) {
     if (s->peer.enabled) {
         if (!s->peer.linked) peer_link(s);
         const sbk::PeerSlot &P = s->peer.slots[(size_t)slot];
-        const int push_chunks = P.n_send ? P.send_chunk[P.n_send] : 0, unpack_chunks = P.n_recv ? P.recv_chunk[P.n_recv] : 0;
+        const int push_chunks = ns, unpack_chunks = nr;       // one lane per ghost (send_idx / recv_idx are indexed by the absolute position)
         // two launches per exchange, both always (the push also carries the waits, the unpack advances the slot's epoch)
         if (with_prev) {
             hipLaunchKernelGGL(sbk::peer_push_kernel<true>, dim3(std::max(1, (push_chunks + 255) / 256)), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.send_idx.p, push_chunks, P);
