@@ -637,8 +637,14 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
             const uint32_t *qbase = base + dsize;                 // the group's tets, then its hinges
             float *lds_f = reinterpret_cast<float *>(lds_pos);
             const int q = tid & 3;
+            // slots are dealt to the waves boustrophedon (row 0: wave 0..NW-1, row 1: NW-1..0, ...), so the wave that got a
+            // hinge slot in one row gets the cheapest slot of the next
+            constexpr int kWavesPerTile = kTileThreads / 64;
+            const int n_slots = n_wb + n_wv + n_wd;
 #pragma unroll 1
-            for (int sw = wave; sw < n_wb + n_wv + n_wd; sw += kTileThreads / 64) {
+            for (int row = 0; row * kWavesPerTile < n_slots; ++row) {
+                const int sw = row * kWavesPerTile + ((row & 1) ? kWavesPerTile - 1 - wave : wave);
+                if (sw >= n_slots) continue;
                 if (sw < n_wb + n_wv) {
                     // four lanes per constraint (see project_volume_quad): lane q of a quad reads component q of the four
                     // particles (lane 3: their inverse masses), writes component q back
