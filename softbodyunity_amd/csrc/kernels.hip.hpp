@@ -604,8 +604,6 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
         }
     } else {
     uint32_t off = d_lo;    // dword offset (from the tile's stream start) of the current group's data
-    uint4 pre = make_uint4(0u, 0u, 0u, 0u);     // QUADS kernels: this wave's first slot of group pre_for, read one group ahead
-    int pre_for = -1;
 #if defined(SB_ABLATE) && SB_ABLATE == 1   // timing experiment only: memory traffic without the rounds
     for (int v = v_begin; v < v_end; v += 100000) {
 #else
@@ -636,23 +634,9 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
             // projection starts first) -- so a group lasts as long as its slowest type, not the sum of the three.
             const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
             const int n_wb = (n_bend + 15) >> 4, n_wv = (n_vol + 15) >> 4, n_wd = (cnt + 63) >> 6;
+            const uint32_t *qbase = base + dsize;                 // the group's tets, then its hinges
             float *lds_f = reinterpret_cast<float *>(lds_pos);
             const int q = tid & 3;
-            // this lane's constraint slot in wave slot sw_ of a group (16 bytes of a tet / hinge, or a spring's 4 / 8 bytes)
-            auto load_slot = [&](const uint32_t *gbase, uint32_t dsz, int c_d, int c_v, int c_b, bool cmp, int sw_, uint4 &out) {
-                const int wb = (c_b + 15) >> 4, wv = (c_v + 15) >> 4;
-                if (sw_ < wb + wv) {
-                    const bool bend = sw_ < wb;
-                    const int c = (bend ? sw_ : sw_ - wb) * 16 + (lane >> 2);
-                    if (c < (bend ? c_b : c_v)) out = *reinterpret_cast<const uint4 *>(gbase + dsz + 4 * (bend ? c_v + c : c));
-                } else {
-                    const int c = (sw_ - wb - wv) * 64 + lane;
-                    if (c < c_d) {
-                        if (cmp) out.x = gbase[c];
-                        else { const uint2 e2 = *reinterpret_cast<const uint2 *>(gbase + 2 * c); out.x = e2.x; out.y = e2.y; }
-                    }
-                }
-            };
             // slots are dealt to the waves boustrophedon (row 0: wave 0..NW-1, row 1: NW-1..0, ...), so the wave that got a
             // hinge slot in one row gets the cheapest slot of the next
             constexpr int kWavesPerTile = kTileThreads / 64;
@@ -661,15 +645,13 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
             for (int row = 0; row * kWavesPerTile < n_slots; ++row) {
                 const int sw = row * kWavesPerTile + ((row & 1) ? kWavesPerTile - 1 - wave : wave);
                 if (sw >= n_slots) continue;
-                uint4 e = make_uint4(0u, 0u, 0u, 0u);
-                if (row == 0 && pre_for == v) e = pre;         // read ahead of the previous group's barrier
-                else load_slot(base, dsize, cnt, n_vol, n_bend, compact, sw, e);
                 if (sw < n_wb + n_wv) {
                     // four lanes per constraint (see project_volume_quad): lane q of a quad reads component q of the four
                     // particles (lane 3: their inverse masses), writes component q back
                     const bool bend = sw < n_wb;
                     const int c = (bend ? sw : sw - n_wb) * 16 + (lane >> 2);
                     if (c < (bend ? n_bend : n_vol)) {
+                        const uint4 e = *reinterpret_cast<const uint4 *>(qbase + 4 * (bend ? n_vol + c : c));
                         const int o0 = 4 * (int)(e.x & 0xffffu) + q, o1 = 4 * (int)(e.x >> 16) + q;
                         const int o2 = 4 * (int)(e.y & 0xffffu) + q, o3 = 4 * (int)(e.y >> 16) + q;
                         float P[4] = {lds_f[o0], lds_f[o1], lds_f[o2], lds_f[o3]};
@@ -682,32 +664,16 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
                     if (c < cnt) {
                         int i, k;
                         float L0;
-                        if (compact) { i = e.x & 0xfffu; k = (e.x >> 12) & 0xfffu; L0 = s_pal[e.x >> 24]; }
-                        else { i = e.x & 0xffffu; k = e.x >> 16; L0 = __uint_as_float(e.y); }
+                        if (compact) {
+                            const uint32_t e = base[c];
+                            i = e & 0xfffu; k = (e >> 12) & 0xfffu; L0 = s_pal[e >> 24];
+                        } else {
+                            const uint2 e = *reinterpret_cast<const uint2 *>(base + 2 * c);
+                            i = e.x & 0xffffu; k = e.x >> 16; L0 = __uint_as_float(e.y);
+                        }
                         float4 a = lds_pos[i], b = lds_pos[k];
                         if (project_distance(a, b, L0, tp.at_d)) { lds_pos[i] = a; lds_pos[k] = b; }
                     }
-                }
-            }
-            // Read this wave's first slot of the NEXT group now, ahead of the barrier: the constraint window is never
-            // written during the rounds, and the slot read is one of the three dependent LDS round trips of a group.
-            pre_for = -1;
-            const int v2 = v + 1;
-            if (v2 < v_end && v2 != R) {
-                const int r2 = v2 < R ? v2 : v2 - R - 1;
-                const uint32_t off2 = v2 == R + 1 ? d_lo : off + size;
-                uint32_t w2;
-                if (rounds_in_lanes) w2 = (uint32_t)__builtin_amdgcn_readlane((int)rwl, __builtin_amdgcn_readfirstlane(r2));
-                else if (rounds_in_lds) w2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)s_rounds[r2]);
-                else w2 = (uint32_t)__builtin_amdgcn_readfirstlane((int)tstream[r2]);
-                const int c_d = w2 & 1023u, c_v = (w2 >> 10) & 1023u, c_b = (w2 >> 20) & 1023u;
-                const bool cmp2 = (w2 >> 30) & 1u;
-                const uint32_t dsz2 = cmp2 ? ((c_d + 3u) & ~3u) : ((2u * c_d + 3u) & ~3u);
-                const uint32_t size2 = dsz2 + 4u * (uint32_t)(c_v + c_b);
-                if (off2 >= win_lo && off2 + size2 <= win_lo + win) {
-                    pre = make_uint4(0u, 0u, 0u, 0u);
-                    load_slot(cbuf + (off2 - win_lo), dsz2, c_d, c_v, c_b, cmp2, wave, pre);
-                    pre_for = v2;
                 }
             }
         } else if (kCPL == 1) {
