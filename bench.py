@@ -65,6 +65,9 @@ def main():
     ap.add_argument("--cpu-sample-n", type=int, default=0, help="cube edge for the CPU baseline sample (0 = the workload itself)")
     ap.add_argument("--allow-stale-traffic", action="store_true",
                     help="do not fail when profiles/hbm_traffic.json disagrees with the compulsory-bytes model (used while re-measuring it)")
+    ap.add_argument("--transport", choices=["rccl", "peer"], default="rccl",
+                    help="ghost exchange for --gpus N > 1: RCCL send/recv (default) or the opt-in peer-store mailboxes (DESIGN.md 7; "
+                         "never run between two devices)")
     ap.add_argument("--loopback-world", type=int, default=0,
                     help="diagnostic: run as rank 0 of this many ranks with SB_TEST_LOOPBACK (RCCL self-exchange on one GPU); "
                          "the reported value counts only the particles this rank owns")
@@ -76,6 +79,8 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    if args.transport == "peer":
+        os.environ["SB_HALO_TRANSPORT"] = "peer"          # read by sb_create
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -251,6 +256,7 @@ def main():
             "config": {"workload": f"{args.n}^3 jelly cube, structural springs (N={N}, M={M}), {args.substeps} substeps/tick, "
                                    f"dt=0.02, explicit index-array graph, tile_particles={args.tile}",
                        "partition": "x".join(str(d) for d in _dims(world)), "graph_replay": (not args.no_graph) and world == 1,
+                       "halo_transport": (os.environ.get("SB_HALO_TRANSPORT") or "rccl") if (world > 1 or loopback) else None,
                        "finite": finite, "parity": parity},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
