@@ -326,6 +326,19 @@ def test_tile_packing_is_invisible(oracle_mod, bunny20k, monkeypatch):
         assert np.array_equal(xa.view(np.uint32), xb.view(np.uint32)) and np.array_equal(va.view(np.uint32), vb.view(np.uint32))
 
 
+@pytest.mark.parametrize("switch", ["SB_NO_MIXED_GROUPS", "SB_NO_CLUSTER_LAYERS", "SB_NO_T2", "SB_NO_PACK", "SB_NO_PALETTE",
+                                    "SB_NO_MASS_PALETTE", "SB_NO_UNIFORM_MASS", "SB_NO_BANK_ORDER", "SB_NO_LAZY_TICK"])
+def test_every_diagnostic_switch_still_matches_the_oracle(oracle_mod, bunny20k, monkeypatch, switch):
+    # the A/B switches of DESIGN.md 6 change the plan (then the published order changes with it) or only the device
+    # layout: either way the plugin must reproduce the oracle walking the order the plugin publishes
+    monkeypatch.setenv(switch, "1")
+    comp = (1e-7, 1e-7, 1e-5)
+    rel, mabs, bit, x, v, o, st = _run_pair(oracle_mod, bunny20k, ticks=2, substeps=7, compliance=comp)
+    assert bit and np.array_equal(v.view(np.uint32), o.v.view(np.uint32)), (switch, rel, mabs)
+    rel, mabs, bit, x, v, o, st = _run_pair(oracle_mod, jelly_cube(20, pin_top=True), ticks=2, substeps=7, tile_particles=64)
+    assert bit and np.array_equal(v.view(np.uint32), o.v.view(np.uint32)), (switch, rel, mabs)
+
+
 @pytest.mark.parametrize("lanes", ["128", "256"])
 def test_both_workgroup_widths_match_the_oracle(oracle_mod, bunny20k, monkeypatch, lanes):
     # small tiles run as 256-lane workgroups (one constraint per lane and round) or, in launches of >= 10240 tiles,
