@@ -79,3 +79,45 @@ def test_peer_transport_loopback_schedules_agree():
     lines = [l for l in out.stdout.splitlines() if l.startswith("peer overlap=")]
     assert len(lines) == 4 and all("rc=0 HASH" in l and l.endswith("True") for l in lines), out.stdout[-1500:]
     assert "peer all equal: True" in out.stdout, out.stdout[-1500:]
+
+
+@pytest.mark.parametrize("world,mesh_kind", [(4, "cube"), (3, "bunny")])
+def test_one_process_drives_every_rank(oracle_mod, monkeypatch, world, mesh_kind):
+    # What a Unity player would do with several GPUs: ONE process (one thread) owns a handle per rank, connects the mailboxes
+    # by pointer (sb_peer_connect with the peer's solver) and calls sb_step on the handles one after the other -- the
+    # exchange is kernels and flags only, so nothing blocks on the host. Here every rank sits on the one device.
+    from softbodyunity_amd import Softbody, native
+    from softbodyunity_amd.mesh import bunny_surrogate, jelly_cube
+    from helpers import build_plan, make_oracle
+    monkeypatch.setenv("SB_HALO_TRANSPORT", "peer")
+    mesh = jelly_cube(24, pin_top=True) if mesh_kind == "cube" else bunny_surrogate(target_verts=3000, seed=9)
+    comp = (0.0, 0.0, 0.0) if mesh_kind == "cube" else (1e-7, 1e-7, 1e-4)
+    tile = 64 if mesh_kind == "cube" else 128
+    L = native.lib()
+    ranks = []
+    try:
+        for r in range(world):
+            ranks.append(Softbody(mesh, substeps=6, device=0, rank=r, world=world, tile_particles=tile, distance_compliance=comp[0],
+                                  volume_compliance=comp[1], bending_compliance=comp[2]).Start())
+        for a in range(world):
+            for b in range(world):
+                if a != b:
+                    native.check(L.sb_peer_connect(ranks[a]._h, b, None, ranks[b]._h))
+        for _ in range(3):
+            for sb in ranks:
+                sb.step()                      # asynchronous: the host never waits for a neighbour
+        x = np.zeros((mesh.n, 3), np.float32); v = np.zeros_like(x); cover = np.zeros(mesh.n, int)
+        for r, sb in enumerate(ranks):
+            own = sb.owner() == r
+            xr = sb.get_positions(); vr = sb.get_velocities()
+            x[own] = xr[own]; v[own] = vr[own]; cover += own
+    finally:
+        for sb in ranks:
+            sb.synchronize() if sb._h is not None else None
+        for sb in ranks:
+            sb.OnDestroy()
+    ref = make_oracle(oracle_mod, mesh, build_plan(mesh, tile_particles=tile), compliance=comp)
+    for _ in range(3):
+        ref.step(0.02, 6)
+    assert np.all(cover == 1)
+    assert np.array_equal(x.view(np.uint32), ref.x.view(np.uint32)) and np.array_equal(v.view(np.uint32), ref.v.view(np.uint32))
