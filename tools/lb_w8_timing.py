@@ -1,12 +1,14 @@
 #!/usr/bin/env python3
 """Rank 0's share of the 256^3 cube split over 8 ranks, RCCL self-exchange (SB_TEST_LOOPBACK), for the four halo schedules;
-no torch in the process (the plugin binds /opt/rocm's RCCL). usage: python tools/lb_w8_timing.py [ticks]"""
+no torch in the process (the plugin binds /opt/rocm's RCCL). usage: python tools/lb_w8_timing.py [ticks] [world] [serial]"""
 import os
 import subprocess
 import sys
 
 ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 TICKS = int(sys.argv[1]) if len(sys.argv) > 1 else 100     # both transports: RCCL send/recv and the peer-store mailboxes
+WORLD = int(sys.argv[2]) if len(sys.argv) > 2 else 8
+ONLY_SERIAL = len(sys.argv) > 3 and sys.argv[3] == "serial"
 CHILD = r'''
 import os, sys, time, hashlib
 sys.path.insert(0, %r)
@@ -14,7 +16,7 @@ import numpy as np
 from softbodyunity_amd import Softbody, comm_unique_id
 from softbodyunity_amd.mesh import jelly_cube
 mesh = jelly_cube(256)
-sb = Softbody(mesh, substeps=20, device=0, rank=0, world=8, unique_id=comm_unique_id()).Start()
+sb = Softbody(mesh, substeps=20, device=0, rank=0, world=%d, unique_id=comm_unique_id()).Start()
 for _ in range(10):
     sb.step()
 sb.synchronize()
@@ -26,10 +28,10 @@ ms = 1e3 * (time.perf_counter() - t0) / %d
 x = sb.get_positions()[sb.owner() == 0]
 print("RESULT %%.4f ms/tick hash %%s finite %%s" %% (ms, hashlib.sha256(x.tobytes()).hexdigest()[:12], bool(np.isfinite(x).all())))
 sb.OnDestroy()
-''' % (ROOT, TICKS, TICKS)
+''' % (ROOT, WORLD, TICKS, TICKS)
 
 for transport in ("rccl", "peer"):
-    for overlap, graph in (("", ""), ("", "1"), ("1", ""), ("1", "1")):
+    for overlap, graph in ((("", ""),) if ONLY_SERIAL else (("", ""), ("", "1"), ("1", ""), ("1", "1"))):
         env = dict(os.environ, SB_TEST_LOOPBACK="1")
         for k, v in (("SB_HALO_OVERLAP", overlap), ("SB_GRAPH_RCCL", graph), ("SB_HALO_TRANSPORT", "peer" if transport == "peer" else "")):
             env.pop(k, None)
@@ -37,4 +39,4 @@ for transport in ("rccl", "peer"):
                 env[k] = v
         r = subprocess.run([sys.executable, "-X", "faulthandler", "-c", CHILD], env=env, capture_output=True, text=True, timeout=400)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
-        print(f"{transport} overlap={overlap or 0} graph={graph or 0}: rc={r.returncode} {line[0] if line else r.stderr[-300:]}", flush=True)
+        print(f"W={WORLD} {transport} overlap={overlap or 0} graph={graph or 0}: rc={r.returncode} {line[0] if line else r.stderr[-300:]}", flush=True)
