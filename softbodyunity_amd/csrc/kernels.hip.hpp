@@ -906,8 +906,9 @@ __global__ __launch_bounds__(256) void peer_push_kernel(PosView pos, const float
     __shared__ uint32_t s_last;
     const int tid = threadIdx.x;
     const uint32_t e = __hip_atomic_load(P.local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    const int k = blockIdx.x * 256 + tid;        // one ghost per lane: 24 (12) contiguous bytes of the segment
-    if (k < n_chunks) {
+    // one ghost per lane and iteration (24 / 12 contiguous bytes of a segment); the grid is capped (solver.hip) because every
+    // workgroup ends with an atomic on ONE word: a thousand of them serialise into more time than the copy itself
+    for (int k = blockIdx.x * 256 + tid; k < n_chunks; k += gridDim.x * 256) {
         int j = 0;
 #pragma unroll
         for (int q = 1; q < kMaxPeers; ++q) j = (q < P.n_send && k >= P.send_off[q]) ? q : j;
@@ -947,8 +948,7 @@ __global__ __launch_bounds__(256) void peer_unpack_kernel(PosView pos, float *pr
     __shared__ uint32_t s_last;
     const int tid = threadIdx.x;
     const uint32_t e = __hip_atomic_load(P.local, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
-    const int k = blockIdx.x * 256 + tid;        // one ghost per lane
-    if (k < n_chunks) {
+    for (int k = blockIdx.x * 256 + tid; k < n_chunks; k += gridDim.x * 256) {      // one ghost per lane and iteration
         int j = 0;
 #pragma unroll
         for (int q = 1; q < kMaxPeers; ++q) j = (q < P.n_recv && k >= P.recv_off[q]) ? q : j;

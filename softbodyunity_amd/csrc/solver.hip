@@ -753,13 +753,15 @@ void halo_exchange(sb_solver *s, int slot, hipStream_t st = nullptr) {
         if (!s->peer.linked) peer_link(s);
         const sbk::PeerSlot &P = s->peer.slots[(size_t)slot];
         const int push_chunks = ns, unpack_chunks = nr;       // one lane per ghost (send_idx / recv_idx are indexed by the absolute position)
-        // two launches per exchange, both always (the push also carries the waits, the unpack advances the slot's epoch)
+        // two launches per exchange, both always (the push also carries the waits, the unpack advances the slot's epoch);
+        // at most kPeerGrid workgroups each: they end with an atomic on one word
+        constexpr int kPeerGrid = 128;
         if (with_prev) {
-            hipLaunchKernelGGL(sbk::peer_push_kernel<true>, dim3(std::max(1, (push_chunks + 255) / 256)), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.send_idx.p, push_chunks, P);
-            hipLaunchKernelGGL(sbk::peer_unpack_kernel<true>, dim3(std::max(1, (unpack_chunks + 255) / 256)), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.recv_idx.p, unpack_chunks, P);
+            hipLaunchKernelGGL(sbk::peer_push_kernel<true>, dim3(std::min(kPeerGrid, std::max(1, (push_chunks + 255) / 256))), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.send_idx.p, push_chunks, P);
+            hipLaunchKernelGGL(sbk::peer_unpack_kernel<true>, dim3(std::min(kPeerGrid, std::max(1, (unpack_chunks + 255) / 256))), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.recv_idx.p, unpack_chunks, P);
         } else {
-            hipLaunchKernelGGL(sbk::peer_push_kernel<false>, dim3(std::max(1, (push_chunks + 255) / 256)), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.send_idx.p, push_chunks, P);
-            hipLaunchKernelGGL(sbk::peer_unpack_kernel<false>, dim3(std::max(1, (unpack_chunks + 255) / 256)), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.recv_idx.p, unpack_chunks, P);
+            hipLaunchKernelGGL(sbk::peer_push_kernel<false>, dim3(std::min(kPeerGrid, std::max(1, (push_chunks + 255) / 256))), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.send_idx.p, push_chunks, P);
+            hipLaunchKernelGGL(sbk::peer_unpack_kernel<false>, dim3(std::min(kPeerGrid, std::max(1, (unpack_chunks + 255) / 256))), dim3(256), 0, st, s->pos_view(), s->d_prev.p, D.recv_idx.p, unpack_chunks, P);
         }
         return;
     }
