@@ -917,17 +917,22 @@ __global__ __launch_bounds__(256) void peer_push_kernel(PosView pos, const float
         if (lk >= 0 && lk < P.send_cap[j]) {      // (a neighbour this rank packs for but does not push to leaves a gap in k)
             float *b = P.remote_data[j] + (size_t)(e & 1u) * P.remote_stride[j] + (size_t)F * lk;
             const size_t o = 3 * (size_t)idx[k];
+            // System-scope stores (write-through: the data must not linger in this XCD's L2 -- the reader may run on another
+            // XCD of the same device, or on another device -- and a release FENCE per wave would write the whole L2 back)
             const f32x3 x = *reinterpret_cast<const f32x3 *>(pos.xyz + o);
+            __hip_atomic_store(b + 0, x.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(b + 1, x.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(b + 2, x.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (WITH_PREV) {
                 const f32x3 pv = *reinterpret_cast<const f32x3 *>(prev + o);
-                *reinterpret_cast<f32x3 *>(b + 3) = pv;
+                __hip_atomic_store(b + 3, pv.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(b + 4, pv.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(b + 5, pv.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-            *reinterpret_cast<f32x3 *>(b) = x;
         }
     }
-    // The mailbox is uncached memory: a store is visible to every agent once the memory system has acknowledged it, so
-    // waiting for this wave's stores (vmcnt 0) orders them before the flag -- a release FENCE at system scope would write
-    // back the whole L2 (the tile kernels' dirty lines), once per wave.
+    // The segment stores above are write-through, so waiting for this wave's stores (vmcnt 0) orders them before the flag;
+    // a release FENCE at system scope would write back the whole L2 (the tile kernels' dirty lines), once per wave.
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) s_last = __hip_atomic_fetch_add(P.local + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gridDim.x - 1 ? 1u : 0u;
@@ -957,9 +962,16 @@ __global__ __launch_bounds__(256) void peer_unpack_kernel(PosView pos, float *pr
         if (lk >= 0 && lk < P.recv_cnt[j]) {
             const float *b = P.my_data[j] + (size_t)(e & 1u) * P.my_stride[j] + (size_t)F * lk;
             const size_t o = 3 * (size_t)idx[k];
-            const f32x3 x = *reinterpret_cast<const f32x3 *>(b);
+            // system-scope loads: past this XCD's L2, where an older copy of the segment may sit
+            f32x3 x;
+            x.x = __hip_atomic_load(b + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            x.y = __hip_atomic_load(b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            x.z = __hip_atomic_load(b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (WITH_PREV) {
-                const f32x3 pv = *reinterpret_cast<const f32x3 *>(b + 3);
+                f32x3 pv;
+                pv.x = __hip_atomic_load(b + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                pv.y = __hip_atomic_load(b + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                pv.z = __hip_atomic_load(b + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 *reinterpret_cast<f32x3 *>(prev + o) = pv;
             }
             *reinterpret_cast<f32x3 *>(pos.xyz + o) = x;
