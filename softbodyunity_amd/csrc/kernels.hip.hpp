@@ -920,14 +920,17 @@ __global__ __launch_bounds__(256) void peer_push_kernel(PosView pos, const float
             // System-scope stores (write-through: the data must not linger in this XCD's L2 -- the reader may run on another
             // XCD of the same device, or on another device -- and a release FENCE per wave would write the whole L2 back)
             const f32x3 x = *reinterpret_cast<const f32x3 *>(pos.xyz + o);
-            __hip_atomic_store(b + 0, x.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(b + 1, x.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(b + 2, x.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            if (WITH_PREV) {
+            if (WITH_PREV) {       // 24 bytes per ghost, 8-byte aligned: three 64-bit stores
                 const f32x3 pv = *reinterpret_cast<const f32x3 *>(prev + o);
-                __hip_atomic_store(b + 3, pv.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(b + 4, pv.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                __hip_atomic_store(b + 5, pv.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                unsigned long long *b8 = reinterpret_cast<unsigned long long *>(b);
+                auto pack2 = [](float lo, float hi) { return (unsigned long long)__float_as_uint(lo) | ((unsigned long long)__float_as_uint(hi) << 32); };
+                __hip_atomic_store(b8 + 0, pack2(x.x, x.y), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(b8 + 1, pack2(x.z, pv.x), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(b8 + 2, pack2(pv.y, pv.z), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            } else {
+                __hip_atomic_store(b + 0, x.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(b + 1, x.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                __hip_atomic_store(b + 2, x.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
     }
@@ -964,15 +967,19 @@ __global__ __launch_bounds__(256) void peer_unpack_kernel(PosView pos, float *pr
             const size_t o = 3 * (size_t)idx[k];
             // system-scope loads: past this XCD's L2, where an older copy of the segment may sit
             f32x3 x;
-            x.x = __hip_atomic_load(b + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            x.y = __hip_atomic_load(b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            x.z = __hip_atomic_load(b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (WITH_PREV) {
+                const unsigned long long *b8 = reinterpret_cast<const unsigned long long *>(b);
+                const unsigned long long q0 = __hip_atomic_load(b8 + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned long long q1 = __hip_atomic_load(b8 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                const unsigned long long q2 = __hip_atomic_load(b8 + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                x.x = __uint_as_float((uint32_t)q0); x.y = __uint_as_float((uint32_t)(q0 >> 32)); x.z = __uint_as_float((uint32_t)q1);
                 f32x3 pv;
-                pv.x = __hip_atomic_load(b + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                pv.y = __hip_atomic_load(b + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-                pv.z = __hip_atomic_load(b + 5, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                pv.x = __uint_as_float((uint32_t)(q1 >> 32)); pv.y = __uint_as_float((uint32_t)q2); pv.z = __uint_as_float((uint32_t)(q2 >> 32));
                 *reinterpret_cast<f32x3 *>(prev + o) = pv;
+            } else {
+                x.x = __hip_atomic_load(b + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                x.y = __hip_atomic_load(b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                x.z = __hip_atomic_load(b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
             *reinterpret_cast<f32x3 *>(pos.xyz + o) = x;
         }
