@@ -330,6 +330,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
     // so each class is a complete matching inside one of the two tilings (see the static split below)
     const int shift_units = ((kk / 2) & 1) ? kk / 2 : std::max(kk / 2 - 1, 1);
     const double shift_frac = (double)shift_units / kk;
+    const double first_t2_frac = shift_frac + 0.5 * (1.0 - shift_frac);     // grid of the first T2 layer: the middle of the widest gap between the T0 and T1 planes
     std::vector<int64_t> cell(n), scell(n);
     P.owner_of_old.resize(n);
     parallel_chunks(n, 1 << 18, [&](int64_t, int64_t pb, int64_t pe) {
@@ -529,6 +530,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
     // side is a set of complete matchings; on irregular meshes it halves the constraint degree of every particle
     // per side, i.e. the number of rounds per tile.
     std::vector<uint8_t> own[3];
+    std::vector<int64_t> layer0_key;       // third list: tile of the third grid per particle (empty: the first T2 layer uses plain grid cells)
     {
         std::vector<std::vector<uint8_t>> bucket(3);
         std::vector<std::vector<int8_t>> label(3);      // -2: not tiled (global), -1: free, 0/1: assigned
@@ -601,6 +603,78 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
                 parallel_chunks(C.count(t), 1 << 20, [&](int64_t, int64_t kb, int64_t ke) {
                     for (int64_t k = kb; k < ke; ++k) if (label[t][k] >= 0) own[t][k] = (uint8_t)label[t][k];
                 });
+        // Third list. On an irregular mesh the constraints that cross the OTHER tiling's planes are forced into one list, so
+        // nearly every tile holds a particle with ~56 of the tile's constraints and needs that many groups. The first T2 layer
+        // is a third grid (shift first_t2_frac): a constraint inside one of its cells may join it instead -- it does whenever
+        // that strictly lowers the larger of the two per-list degrees among its particles. The layer then carries a balanced
+        // share of the mesh (a third list, walked between the other two in every substep) instead of the leftovers only.
+        // Only meshes with leftovers are touched: a structural lattice (none) keeps its two perfect lists.
+        if (tiling && opts.third_tiling && opts.third_list) {
+            bool any_left = false;
+            for (int t = 0; t < 3 && !any_left; ++t) for (int64_t k = 0; k < C.count(t); ++k) if (own[t][k] == 2) { any_left = true; break; }
+            if (any_left) {
+                // the third grid's cells, over-full ones median-split like the cells of T0 and T1 (a mesh that fills only part
+                // of its bounding box has cells far above the average)
+                std::vector<int64_t> &cellm = layer0_key;
+                cellm.assign((size_t)n, 0);
+                parallel_chunks(n, 1 << 18, [&](int64_t, int64_t pb, int64_t pe) {
+                    for (int64_t q = pb; q < pe; ++q) {
+                        int64_t s3[3];
+                        for (int a = 0; a < 3; ++a) {
+                            double r = (in.rest[3 * q + a] - org[a]) / cs;
+                            s3[a] = std::min(std::max((int)std::floor(r - first_t2_frac) + 1, 0), nc[a]);
+                        }
+                        cellm[q] = (s3[2] * (nc[1] + 1) + s3[1]) * (nc[0] + 1) + s3[0];
+                    }
+                });
+                {
+                    std::vector<int32_t> bym(n);
+                    std::iota(bym.begin(), bym.end(), 0);
+                    std::sort(bym.begin(), bym.end(), [&](int32_t a, int32_t b2) { return cellm[a] != cellm[b2] ? cellm[a] < cellm[b2] : a < b2; });
+                    std::vector<int32_t> begins;
+                    for (int32_t b2 = 0; b2 < n;) {
+                        int32_t e = b2 + 1;
+                        while (e < n && cellm[bym[e]] == cellm[bym[b2]]) ++e;
+                        split_group(bym, b2, e, cap, true, in.rest, begins);
+                        b2 = e;
+                    }
+                    begins.push_back(n);
+                    for (size_t c = 0; c + 1 < begins.size(); ++c)
+                        for (int32_t q = begins[c]; q < begins[c + 1]; ++q) cellm[bym[q]] = (int64_t)c;      // tile id of the third grid
+                }
+                std::vector<uint8_t> in_m[3];
+                std::vector<int32_t> deg[3];
+                for (auto &d : deg) d.assign((size_t)n, 0);
+                for (int t = 0; t < 3; ++t) {
+                    in_m[t].assign((size_t)C.count(t), 0);
+                    for (int64_t k = 0; k < C.count(t); ++k) {
+                        const int32_t *v = C.idx(t, k);
+                        bool same = true;
+                        for (int a = 1; a < kVerts[t]; ++a) same &= cellm[v[a]] == cellm[v[0]];
+                        in_m[t][k] = same;
+                        const int lst = own[t][k] == 2 ? (same ? 2 : -1) : own[t][k];
+                        if (lst >= 0) for (int a = 0; a < kVerts[t]; ++a) ++deg[lst][v[a]];
+                    }
+                }
+                for (int pass = 0; pass < 8; ++pass) {
+                    int64_t moved = 0;
+                    for (int t = 0; t < 3; ++t)
+                        for (int64_t k = 0; k < C.count(t); ++k) {
+                            const int a = own[t][k];
+                            if (a > 1 || !in_m[t][k]) continue;
+                            const int32_t *v = C.idx(t, k);
+                            int32_t here = 0, there = 0;
+                            for (int q = 0; q < kVerts[t]; ++q) { here = std::max(here, deg[a][v[q]]); there = std::max(there, deg[2][v[q]]); }
+                            if (there + 1 < here) {
+                                for (int q = 0; q < kVerts[t]; ++q) { --deg[a][v[q]]; ++deg[2][v[q]]; }
+                                own[t][k] = 2;
+                                ++moved;
+                            }
+                        }
+                    if (!moved) break;
+                }
+            }
+        }
     }
 
     timer.lap("static split");
@@ -812,7 +886,7 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         // layer shifts (fractions of a cell): first the middle of the widest gap between the T0 and T1 planes, then a
         // golden-ratio walk, skipping positions within 6 % of a cell of any plane already in use
         std::vector<double> planes = {0.0, shift_frac, 1.0};
-        double next_frac = shift_frac + 0.5 * (1.0 - shift_frac);
+        double next_frac = first_t2_frac;
         for (int layer = 0; layer < kMaxT2Layers; ++layer) {
             double frac = next_frac;
             for (int tries = 0; tries < 32; ++tries) {
@@ -897,9 +971,10 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
                     for (int64_t k = 0; k < C.count(t); ++k) {
                         if (own[t][k] != 2) continue;
                         const int32_t *v = C.idx(t, k);
-                        const int64_t c0 = cell2(v[0]);
+                        const bool keyed = layer == 0 && !layer0_key.empty();
+                        const int64_t c0 = keyed ? layer0_key[v[0]] : cell2(v[0]);
                         bool same = true;
-                        for (int a = 1; a < kVerts[t]; ++a) same &= cell2(v[a]) == c0;
+                        for (int a = 1; a < kVerts[t]; ++a) same &= (keyed ? layer0_key[v[a]] : cell2(v[a])) == c0;
                         if (same) cand.push_back({c0, (uint8_t)t, (int32_t)k});
                     }
             }

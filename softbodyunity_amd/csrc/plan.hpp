@@ -33,6 +33,7 @@ struct Opts {
     int dims[3] = {0, 0, 0};
     int tile_particles = 512;  // -1: no tiling
     bool third_tiling = true;       // constraints inside neither T0 nor T1 get LDS tiles of their own (T2) where they can (SB_NO_T2: A/B runs)
+    bool third_list = true;         // irregular meshes: the first T2 layer takes a balanced share of the constraints, not only the leftovers (SB_NO_THIRD_LIST: A/B runs)
     bool cluster_layers = true;     // once few constraints are left, T2 layers are made of connected components instead of grid cells (SB_NO_CLUSTER_LAYERS: A/B runs)
     bool mixed_groups = true;       // colour the constraint types of a tile together (SB_NO_MIXED_GROUPS: one type per group, A/B runs)
     bool bank_aware_lanes = true;   // order the constraints of a round for conflict-free LDS gathers (SB_NO_BANK_ORDER: A/B runs)

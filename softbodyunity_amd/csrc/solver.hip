@@ -1179,6 +1179,7 @@ int sb_finalize(sb_solver *s) {
         o.third_tiling = !std::getenv("SB_NO_T2");
         o.mixed_groups = !std::getenv("SB_NO_MIXED_GROUPS");
         o.cluster_layers = !std::getenv("SB_NO_CLUSTER_LAYERS");
+        o.third_list = !std::getenv("SB_NO_THIRD_LIST");
         s->plan = std::make_unique<sb_plan>();
         const bool timing = std::getenv("SB_PLAN_TIMING") != nullptr;
         auto t0 = std::chrono::steady_clock::now();
@@ -1683,6 +1684,7 @@ int sb_plan_build(const float *rest, int32_t n, const int32_t *dist_ij, int32_t 
         o.third_tiling = !std::getenv("SB_NO_T2");
         o.mixed_groups = !std::getenv("SB_NO_MIXED_GROUPS");
         o.cluster_layers = !std::getenv("SB_NO_CLUSTER_LAYERS");
+        o.third_list = !std::getenv("SB_NO_THIRD_LIST");
         sbp::Input in = make_input(rest, n, dist_ij, m_d, vol, m_v, bend, m_b);
         auto p = std::make_unique<sb_plan>();
         sbp::build_plan(in, o, p->plan);
