@@ -72,12 +72,19 @@ def test_full_stencil_cube_uses_the_third_tiling_or_global_colours_and_stays_val
     assert 3 in kinds                                             # diagonal springs inside neither T0 nor T1: T2 layers take them
     assert kinds.index(1) < kinds.index(3) < kinds.index(2)       # S_p tiles, T2 layers (+ global colours), S_(1-p) tiles
     in_t2 = sum(p["order_end"] - p["order_begin"] for p in plan.phases(0) if p["kind"] == 3)
+    monkeypatch.setenv("SB_NO_THIRD_LIST", "1")                   # leftovers only in the T2 layers (no balanced third list)
+    left_only = build_plan(mesh, tile_particles=64)
+    _check_plan(mesh, left_only)
+    in_t2_left = sum(p["order_end"] - p["order_begin"] for p in left_only.phases(0) if p["kind"] == 3)
+    assert in_t2 > in_t2_left > 0                                  # the third list takes more than the leftovers
+    in_t2 = in_t2_left
+    in_g_left = sum(p["order_end"] - p["order_begin"] for p in left_only.phases(0) if p["kind"] == 0)
     monkeypatch.setenv("SB_NO_T2", "1")
     plain = build_plan(mesh, tile_particles=64)
     _check_plan(mesh, plain)
     assert all(p["kind"] != 3 for p in plain.phases(0)) and any(p["kind"] == 0 for p in plain.phases(0))
     in_g = sum(p["order_end"] - p["order_begin"] for p in plain.phases(0) if p["kind"] == 0)
-    in_g_now = sum(p["order_end"] - p["order_begin"] for p in plan.phases(0) if p["kind"] == 0)
+    in_g_now = in_g_left
     assert in_t2 + in_g_now == in_g and in_t2 > 0.8 * in_g
     assert [p["order_end"] - p["order_begin"] for p in plain.phases(0) if p["kind"] == 0] == \
            [p["order_end"] - p["order_begin"] for p in plain.phases(1) if p["kind"] == 0]
