@@ -29,6 +29,11 @@ def test_bench_json_line_contract():
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     # frac is a physical fraction of the HBM peak (traffic / time / peak); the algorithmic-bytes figure lives beside it
     assert 0.0 < r["frac"] <= 1.0 and r["frac_algorithmic"] > 0 and r["reuse_factor"] > 1.0
+    # the lattice run is launches of one kernel only: its duration is the timed region's HIP-event time / launches in it,
+    # and must sit at or below the eager event-pair figure (which carries the dispatch gap) but nowhere far from it
+    assert r["kernel_avg_ms_source"].startswith("HIP events over the timed region") and r["kernel_launches_per_tick"] == 20
+    assert abs(r["kernel_avg_ms"] - r["tick_ms_hip_events"] / 20) < 1e-9
+    assert 0.5 * r["kernel_avg_ms_event_pairs"] < r["kernel_avg_ms"] < 1.25 * r["kernel_avg_ms_event_pairs"]
     assert r["model_bytes_per_launch"] > 0 and (r["traffic"] is None or abs(r["traffic"] / r["model_bytes_per_launch"] - 1) <= 0.03)
     p = j["config"]["parity"]
     assert p["ticks"] == 4 and p["finite"] is True
