@@ -34,10 +34,20 @@ struct TileDesc {
     uint32_t pad3;
     int32_t run_overflow;      // runs beyond kInlineRuns live at runs_overflow[run_overflow ...]
     int32_t n_pal;             // palette entries (0 = no dictionary coding), stored after the round words
-    int32_t pad1, pad2;
+    int32_t n_steps;           // wave items per wave (meshes with tets / hinges; 0 = none), see kItem* below
+    uint32_t s_items;          // dword offset (from s_begin) of the items: kItemWaves runs of n_steps dwords, inside the header
     int2 runs[10];             // {first particle (device numbering), first tile-local index}; unused entries: {0, INT_MAX}
 };
 constexpr int kInlineRuns = 10;
+// Wave items (meshes with tets / hinges, 4-wave tiles): the host deals every group's work to the four waves ahead of time --
+// hinges first, then tets (16 four-lane constraints per wave), then springs (64 per wave), boustrophedon over the rows of
+// a group -- and stores for every wave one dword per STEP (= one row of one group): what to project, how many, where the
+// slots lie in the tile's data, and whether the group ends here (workgroup barrier). The kernel's loop over a list is then a
+// v_readlane, three bit-field extracts and one uniform branch per step instead of decoding the group word, the window test
+// and the slot arithmetic (90 scalar instructions and a dozen branches per group on the critical path of every group).
+constexpr int kItemWaves = 4;
+constexpr uint32_t kItemIdle = 0, kItemDistCompact = 1, kItemDistFull = 2, kItemVolume = 3, kItemBending = 4;
+constexpr int kItemCountShift = 3, kItemBarrierBit = 10, kItemOffsetShift = 11;     // type:3 | count:7 | barrier:1 | dword offset:21
 constexpr int kMaxRoundsLds = 128;   // round words cached in LDS; longer programs read them from memory
 constexpr int kMaxPalette = 256;     // rest-length dictionary entries per tile
 
@@ -432,6 +442,12 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
     // v_readlane (no LDS round trip at the head of each round): +3 % at 64^3, +1 % at 256^3
     const bool rounds_in_lanes = n_rounds_all <= 64;
     const uint32_t rwl = tstream[max(min(tid & 63, n_rounds_all - 1), 0)];
+    // wave items (see kItem*): lane l of a wave holds the wave's step l (tiles without items re-read round word 0)
+    uint32_t itreg = 0;
+    if (QUADS && kTileThreads == 64 * kItemWaves) {
+        const int ns = td.n_steps;
+        itreg = tstream[ns > 0 ? td.s_items + (uint32_t)((tid >> 6) * ns + min(tid & 63, ns - 1)) : 0u];
+    }
     const int n_pal = td.n_pal;
     // palette follows the round words; lanes without an entry re-read round word 0 (always inside the tile's stream)
     const uint32_t palw = tstream[tid < n_pal ? ((n_rounds_all + 3) & ~3) + tid : 0];
@@ -462,7 +478,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
     }
 #pragma unroll
     for (int q = 0; q < kW; ++q) asm volatile("" ::"v"(wv[q].x));
-    asm volatile("" ::"v"(rw), "v"(palw), "v"(rwl));
+    asm volatile("" ::"v"(rw), "v"(palw), "v"(rwl), "v"(itreg));
 #pragma unroll
     for (int m = 0; m < PPT; ++m)
         if (g[m] >= 0) *reinterpret_cast<f32x4 *>(lds_pos + tid + m * kTileThreads) = X[m];
@@ -602,6 +618,56 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
 #pragma unroll
             for (int r = 0; r < kRegRounds; ++r) if (r < n_rounds_all) reg_round(rs[r], rl[r], rcnt[r]);
         }
+    } else if (QUADS && kTileThreads == 64 * kItemWaves && td.n_steps > 0 && d_hi - d_lo <= win) {
+        // ---- wave items: the whole data of the tile is in the window, every wave walks its own list of steps ----------------
+        const int n_steps = td.n_steps;
+        const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+        const uint32_t *items = tstream + td.s_items + (uint32_t)(wave * n_steps);
+        float *lds_f = reinterpret_cast<float *>(lds_pos);
+        const int q = tid & 3;
+        auto run_pass = [&]() {
+            if (n_steps > 64) itreg = items[min(lane, n_steps - 1)];      // (the prologue loaded the first 64 steps)
+#pragma unroll 1
+            for (int st = 0; st < n_steps; ++st) {
+                if ((st & 63) == 0 && st > 0) itreg = items[min(st + lane, n_steps - 1)];
+                const uint32_t it = (uint32_t)__builtin_amdgcn_readlane((int)itreg, st & 63);
+                const uint32_t type = it & 7u;
+                const int cnt = (int)((it >> kItemCountShift) & 127u);
+                const uint32_t *slots = cbuf + (it >> kItemOffsetShift);
+                if (type >= kItemVolume) {
+                    // four lanes per constraint (see project_volume_quad): lane q of a quad reads component q of the four
+                    // particles (lane 3: their inverse masses), writes component q back
+                    const int c = lane >> 2;
+                    if (c < cnt) {
+                        const uint4 e = *reinterpret_cast<const uint4 *>(slots + 4 * c);
+                        const int o0 = 4 * (int)(e.x & 0xffffu) + q, o1 = 4 * (int)(e.x >> 16) + q;
+                        const int o2 = 4 * (int)(e.y & 0xffffu) + q, o3 = 4 * (int)(e.y >> 16) + q;
+                        float P[4] = {lds_f[o0], lds_f[o1], lds_f[o2], lds_f[o3]};
+                        const bool ok = type == kItemBending ? project_bending_quad(P, __uint_as_float(e.z), __uint_as_float(e.w), tp.at_b, q)
+                                                             : project_volume_quad(P, __uint_as_float(e.z), tp.at_v);
+                        if (ok && q < 3) { lds_f[o0] = P[0]; lds_f[o1] = P[1]; lds_f[o2] = P[2]; lds_f[o3] = P[3]; }
+                    }
+                } else if (type != kItemIdle) {
+                    if (lane < cnt) {
+                        int i, k;
+                        float L0;
+                        if (type == kItemDistCompact) {
+                            const uint32_t e = slots[lane];
+                            i = e & 0xfffu; k = (e >> 12) & 0xfffu; L0 = s_pal[e >> 24];
+                        } else {
+                            const uint2 e = *reinterpret_cast<const uint2 *>(slots + 2 * lane);
+                            i = e.x & 0xffffu; k = e.x >> 16; L0 = __uint_as_float(e.y);
+                        }
+                        float4 a = lds_pos[i], b = lds_pos[k];
+                        if (project_distance(a, b, L0, tp.at_d)) { lds_pos[i] = a; lds_pos[k] = b; }
+                    }
+                }
+                if (it & (1u << kItemBarrierBit)) lds_barrier();
+            }
+        };
+        if (KIND != 0) run_pass();
+        if (KIND != 3) { mark_step(); lds_barrier(); }
+        if (KIND == 0 || KIND == 1) run_pass();
     } else {
     uint32_t off = d_lo;    // dword offset (from the tile's stream start) of the current group's data
 #if defined(SB_ABLATE) && SB_ABLATE == 1   // timing experiment only: memory traffic without the rounds

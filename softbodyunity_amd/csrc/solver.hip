@@ -426,6 +426,8 @@ void build_device(sb_solver *s) {
         struct Part { int32_t member; int32_t cnt[3]; int64_t first_d, first_q; };   // a member's group inside a pack group
         struct PackRound { int32_t cnt[3]; std::vector<Part> parts; };                 // constraints per type (distance, volume, bending)
         const bool no_palette = std::getenv("SB_NO_PALETTE") != nullptr;
+        // meshes with tets / hinges: per-wave step lists beside the group words (springs-only meshes never run the kernels that read them)
+        const bool emit_items = (!s->vol_rest.empty() || !s->bend_rest.empty()) && !std::getenv("SB_NO_WAVE_ITEMS");
         constexpr int64_t kPacksPerChunk = 128;
         const int64_t n_chunks = ((int64_t)packs.size() + kPacksPerChunk - 1) / kPacksPerChunk;
         std::vector<Piece> pieces((size_t)n_chunks);
@@ -500,7 +502,7 @@ void build_device(sb_solver *s) {
                 }
             }
             td.n_rounds = (int32_t)prog.size();
-            if (stream.size() > 0xfffffff0ull - 4ull * (size_t)n_cons - 4ull * prog.size() - 1024ull)
+            if (stream.size() > 0xfffffff0ull - 4ull * (size_t)n_cons - 48ull * prog.size() - 1024ull)      // (group word + up to 40 wave items per group)
                 throw std::runtime_error("tile constraint stream exceeds 2^32 dwords");
             td.s_begin = (uint32_t)stream.size();
             const size_t s0 = stream.size();
@@ -527,6 +529,41 @@ void build_device(sb_solver *s) {
             while ((stream.size() - s0) & 3) stream.push_back(0);
             max_pal = std::max(max_pal, (int32_t)pal.size());
             max_rounds = std::max(max_rounds, td.n_rounds);
+            if (emit_items && !prog.empty()) {
+                // wave items (kernels.hip.hpp kItem*): the work of every group dealt to the four waves of a tile, one dword per
+                // wave and step. Slots of a group: its hinges (16 per wave slot), its tets (16), its springs (64); rows of
+                // four slots, dealt boustrophedon (the wave that took a hinge slot in one row takes the cheapest of the next).
+                std::vector<uint32_t> it[sbk::kItemWaves];
+                uint32_t off = 0;                       // dwords from the start of the tile's data
+                bool fits = true;
+                for (const PackRound &R : prog) {
+                    const uint32_t nd = (uint32_t)R.cnt[0], nv = (uint32_t)R.cnt[1], nb = (uint32_t)R.cnt[2];
+                    const uint32_t dsize = compact ? ((nd + 3u) & ~3u) : ((2u * nd + 3u) & ~3u), qoff = off + dsize;
+                    const int n_wb = (int)((nb + 15) >> 4), n_wv = (int)((nv + 15) >> 4), n_wd = (int)((nd + 63) >> 6);
+                    const int n_slots = n_wb + n_wv + n_wd, rows = std::max(1, (n_slots + sbk::kItemWaves - 1) / sbk::kItemWaves);
+                    for (int row = 0; row < rows; ++row)
+                        for (int wave = 0; wave < sbk::kItemWaves; ++wave) {
+                            const int sw = row * sbk::kItemWaves + ((row & 1) ? sbk::kItemWaves - 1 - wave : wave);
+                            uint32_t type = sbk::kItemIdle, cnt = 0, o = 0;
+                            if (sw < n_wb) { type = sbk::kItemBending; cnt = std::min(16u, nb - 16u * (uint32_t)sw); o = qoff + 4u * (nv + 16u * (uint32_t)sw); }
+                            else if (sw < n_wb + n_wv) { const uint32_t c0 = 16u * (uint32_t)(sw - n_wb); type = sbk::kItemVolume; cnt = std::min(16u, nv - c0); o = qoff + 4u * c0; }
+                            else if (sw < n_slots) {
+                                const uint32_t c0 = 64u * (uint32_t)(sw - n_wb - n_wv);
+                                type = compact ? sbk::kItemDistCompact : sbk::kItemDistFull; cnt = std::min(64u, nd - c0); o = off + (compact ? c0 : 2u * c0);
+                            }
+                            if (o >= (1u << (32 - sbk::kItemOffsetShift))) fits = false;
+                            it[wave].push_back(type | (cnt << sbk::kItemCountShift) | (row + 1 == rows ? 1u << sbk::kItemBarrierBit : 0u) |
+                                               (o << sbk::kItemOffsetShift));
+                        }
+                    off += dsize + 4u * (nv + nb);
+                }
+                if (fits) {
+                    td.n_steps = (int32_t)it[0].size();
+                    td.s_items = (uint32_t)(stream.size() - s0);
+                    for (int wave = 0; wave < sbk::kItemWaves; ++wave) stream.insert(stream.end(), it[wave].begin(), it[wave].end());
+                    while ((stream.size() - s0) & 3) stream.push_back(0);
+                }
+            }
             td.s_hdr = (uint32_t)(stream.size() - s0);
             for (const PackRound &R : prog) {
                 // a group's data: its distance slots (padded to 4 dwords), then its volume slots, then its bending slots
@@ -589,6 +626,49 @@ void build_device(sb_solver *s) {
                 max_rounds = std::max(max_rounds, Q.max_rounds); max_data = std::max(max_data, Q.max_data);
                 D.has_quads |= Q.has_quads;
                 Piece().tiles.swap(Q.tiles); std::vector<uint32_t>().swap(Q.stream);
+            }
+        }
+        // Cost order inside a launch. Tiles of one launch share no particle, so their order is free; workgroups are dispatched
+        // in index order, and a launch of a few hundred tiles puts the first 256 on a compute unit each and the rest beside
+        // them. On an irregular mesh the launch lasts as long as its longest tile (40+ groups against a mean of 29): run the
+        // long tiles first, so that none of them starts late or beside another long one. The position of the w-th heaviest
+        // tile is the one workgroup w reads (the XCD remap of tile_kernel). Large launches (a lattice: equal tiles, placed
+        // for L2 locality) and launches of equal tiles are left alone.
+        if (!std::getenv("SB_NO_COST_ORDER")) {
+            constexpr int32_t kCostOrderMaxTiles = 2048;
+            const int32_t n = (int32_t)tiles.size();
+            std::vector<std::pair<int32_t, int32_t>> ranges;
+            if (tl == 2) ranges = s->t2_layer_range;
+            else if (D.n_boundary > 0 && D.n_boundary < n) {
+                const int32_t cut = tl == 0 ? D.n_boundary : n - D.n_boundary;
+                ranges = {{0, cut}, {cut, n}};
+            } else ranges = {{0, n}};
+            for (const auto &rg : ranges) {
+                const int32_t nr = rg.second - rg.first;
+                if (nr < 2 || nr > kCostOrderMaxTiles) continue;
+                std::vector<int32_t> cost((size_t)nr), idx((size_t)nr);
+                for (int32_t k = 0; k < nr; ++k) {
+                    const sbk::TileDesc &td = tiles[(size_t)(rg.first + k)];
+                    int32_t c = 0;
+                    for (int32_t r = 0; r < td.n_rounds; ++r) {
+                        const uint32_t w = stream[(size_t)td.s_begin + (size_t)r];
+                        const int32_t nd = (int32_t)(w & 1023u), nv = (int32_t)((w >> 10) & 1023u), nb = (int32_t)((w >> 20) & 1023u);
+                        if (D.has_quads) c += std::max(1, (((nd + 63) >> 6) + ((nv + 15) >> 4) + ((nb + 15) >> 4) + 3) >> 2) + (nb > 0 ? 1 : 0);
+                        else c += std::max(1, (nd + sbk::kRoundSlots - 1) / sbk::kRoundSlots);
+                    }
+                    cost[(size_t)k] = c; idx[(size_t)k] = k;
+                }
+                const auto mm = std::minmax_element(cost.begin(), cost.end());
+                if ((int64_t)*mm.second * 4 <= (int64_t)*mm.first * 5) continue;       // equal within 25 %
+                std::stable_sort(idx.begin(), idx.end(), [&](int32_t a, int32_t b2) { return cost[(size_t)a] > cost[(size_t)b2]; });
+                std::vector<sbk::TileDesc> placed((size_t)nr);
+                const int32_t xq = nr >> 3, xr = nr & 7;
+                for (int32_t w = 0; w < nr; ++w) {
+                    const int32_t xcd = w & 7;
+                    const int32_t pos = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (w >> 3);
+                    placed[(size_t)pos] = tiles[(size_t)(rg.first + idx[(size_t)w])];
+                }
+                std::copy(placed.begin(), placed.end(), tiles.begin() + rg.first);
             }
         }
         D.n_tiles = (int32_t)tiles.size();
