@@ -45,7 +45,7 @@ constexpr int kInlineRuns = 10;
 // slots lie in the tile's data, and whether the group ends here (workgroup barrier). The kernel's loop over a list is then a
 // v_readlane, three bit-field extracts and one uniform branch per step instead of decoding the group word, the window test
 // and the slot arithmetic (90 scalar instructions and a dozen branches per group on the critical path of every group).
-constexpr int kItemWaves = 4;
+constexpr int kItemWaves = 4;        // dealt for 4-wave tiles (8 with SB_QUAD_LANES=512)
 constexpr uint32_t kItemIdle = 0, kItemDistCompact = 1, kItemDistFull = 2, kItemVolume = 3, kItemBending = 4;
 constexpr int kItemCountShift = 3, kItemBarrierBit = 10, kItemOffsetShift = 11;     // type:3 | count:7 | barrier:1 | dword offset:21
 constexpr int kMaxRoundsLds = 128;   // round words cached in LDS; longer programs read them from memory
@@ -84,6 +84,7 @@ struct TileArgs {
     int32_t win_dwords;       // constraint window held in LDS (multiple of 4, >= the largest round)
     int32_t tile_base;        // this launch covers tiles tile_base + blockIdx.x (boundary / interior split)
     int32_t w_uniform;        // WPAL kernels: every particle has the same inverse mass -> all lanes read index 0 (one cache line, no per-particle byte)
+    int32_t item_waves;       // waves per tile the wave items of this tiling were dealt for (0 = none)
 };
 
 // Lanes per tile (template parameter THREADS of tile_kernel). A round holds up to kRoundSlots independent constraints,
@@ -92,6 +93,7 @@ struct TileArgs {
 // at 256^3. A launch whose tiles all fit on the chip at once is latency-bound instead and wants the wide workgroup
 // (64^3: 256 lanes are 22 % faster), so the host picks per launch (solver.hip launch_tile).
 constexpr int kNarrowTileThreads = 128;                     // small tiles, launches that oversubscribe the chip
+constexpr int kQuadTileThreads = 512;                       // tiles with four-lane constraints (tets, hinges): 8 wave slots per group row
 constexpr int kWideTileThreads = 256;                       // small tiles in latency-bound launches, and all large tiles
 constexpr int kRoundSlots = 256;                            // plan.hpp kRoundThreads
 constexpr int kSmallTile = 512, kLargeTile = 1024;          // the two particle capacities the kernels are built for
@@ -333,12 +335,12 @@ __device__ __forceinline__ bool project_bending_quad(float (&P)[4], float rest_c
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // Register budget (HIP: second launch-bound = waves per SIMD). LDS allows ~14 tiles per CU, so aim for that many waves.
-template <bool QUADS, int THREADS> constexpr int kWavesPerSimd = QUADS ? (THREADS == 64 ? 3 : 4) : (THREADS == 256 ? 8 : (THREADS == 128 ? 6 : 4));   // 128 lanes: 7 waves (72 VGPRs) measured 1 % slower, 8 spill
+template <bool QUADS, int THREADS> constexpr int kWavesPerSimd = QUADS ? (THREADS == 64 ? 3 : (THREADS == 512 ? 2 : 4)) : (THREADS == 256 ? 8 : (THREADS == 128 ? 6 : 4));   // 128 lanes: 7 waves (72 VGPRs) measured 1 % slower, 8 spill
 // WPAL = inverse masses are read as one-byte palette indices (the palette entry comes from another lane by ds_bpermute).
 template <int KIND, bool QUADS, int THREADS, int PPT, bool WPAL>
 __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile_kernel(TileArgs A) {
     constexpr int kTileThreads = THREADS;
-    constexpr int kCPL = kRoundSlots / THREADS;       // constraints per lane per round
+    constexpr int kCPL = THREADS >= kRoundSlots ? 1 : kRoundSlots / THREADS;       // constraints per lane per round (8-wave tiles: QUADS only)
     extern __shared__ uint4 lds_raw[];
     float4 *lds_pos = reinterpret_cast<float4 *>(lds_raw);
     uint32_t *s_rounds = reinterpret_cast<uint32_t *>(lds_pos + A.max_local);
@@ -444,7 +446,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
     const uint32_t rwl = tstream[max(min(tid & 63, n_rounds_all - 1), 0)];
     // wave items (see kItem*): lane l of a wave holds the wave's step l (tiles without items re-read round word 0)
     uint32_t itreg = 0;
-    if (QUADS && kTileThreads == 64 * kItemWaves) {
+    if (QUADS && kTileThreads == 64 * A.item_waves) {
         const int ns = td.n_steps;
         itreg = tstream[ns > 0 ? td.s_items + (uint32_t)((tid >> 6) * ns + min(tid & 63, ns - 1)) : 0u];
     }
@@ -618,7 +620,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
 #pragma unroll
             for (int r = 0; r < kRegRounds; ++r) if (r < n_rounds_all) reg_round(rs[r], rl[r], rcnt[r]);
         }
-    } else if (QUADS && kTileThreads == 64 * kItemWaves && td.n_steps > 0 && d_hi - d_lo <= win) {
+    } else if (QUADS && kTileThreads == 64 * A.item_waves && td.n_steps > 0 && d_hi - d_lo <= win) {
         // ---- wave items: the whole data of the tile is in the window, every wave walks its own list of steps ----------------
         const int n_steps = td.n_steps;
         const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -627,6 +629,9 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
         const int q = tid & 3;
         auto run_pass = [&]() {
             if (n_steps > 64) itreg = items[min(lane, n_steps - 1)];      // (the prologue loaded the first 64 steps)
+#if defined(SB_ABLATE) && SB_ABLATE == 1   // timing experiment only: the launch without its steps
+            if (n_steps >= 0) return;
+#endif
 #pragma unroll 1
             for (int st = 0; st < n_steps; ++st) {
                 if ((st & 63) == 0 && st > 0) itreg = items[min(st + lane, n_steps - 1)];

@@ -82,6 +82,7 @@ struct DevTiling {
     int32_t n_boundary = 0;      // world > 1: T0 -- the FIRST n_boundary tiles hold every particle some peer needs; T1 -- the LAST
                                  // n_boundary tiles hold every ghost and every sent particle
     bool has_quads = false;
+    int32_t item_waves = 0;      // waves per tile the wave items were dealt for (0 = the streams hold none)
     DevBuf<sbk::TileDesc> tiles;
     DevBuf<int2> runs_overflow;
     DevBuf<uint32_t> stream;     // per tile: [round words][rest-length dictionary][round data], see kernels.hip.hpp
@@ -156,6 +157,8 @@ struct sb_solver {
     int deferred_substeps = 0;
     bool lazy_tick = true;           // SB_NO_LAZY_TICK unset (read once in sb_create)
     int tile_lanes = 0;              // SB_TILE_LANES=128|256 forces the workgroup width of small tiles (0 = by launch size)
+    int quad_lanes = 512;            // SB_QUAD_LANES=256|512: workgroup width of tiles that hold tets / hinges (8 waves: every group of the
+                                     // 100 k surrogate fits one row of wave slots; 1.99 against 2.11 ms per tick with 4 waves)
     int narrow_min_tiles = 10240;    // SB_NARROW_MIN_TILES; measured crossover: 160^3 (8000 tiles) ties, 192^3 (13824) +4 % narrow
     size_t lds_pad = 0;              // SB_LDS_PAD bytes of unused LDS per workgroup (occupancy experiments)
     bool pack_tiles = true;          // SB_NO_PACK unset: under-full tiles share a workgroup (build_device)
@@ -428,6 +431,8 @@ void build_device(sb_solver *s) {
         const bool no_palette = std::getenv("SB_NO_PALETTE") != nullptr;
         // meshes with tets / hinges: per-wave step lists beside the group words (springs-only meshes never run the kernels that read them)
         const bool emit_items = (!s->vol_rest.empty() || !s->bend_rest.empty()) && !std::getenv("SB_NO_WAVE_ITEMS");
+        const int item_waves = s->quad_lanes / 64;
+        D.item_waves = emit_items ? item_waves : 0;
         constexpr int64_t kPacksPerChunk = 128;
         const int64_t n_chunks = ((int64_t)packs.size() + kPacksPerChunk - 1) / kPacksPerChunk;
         std::vector<Piece> pieces((size_t)n_chunks);
@@ -533,17 +538,17 @@ void build_device(sb_solver *s) {
                 // wave items (kernels.hip.hpp kItem*): the work of every group dealt to the four waves of a tile, one dword per
                 // wave and step. Slots of a group: its hinges (16 per wave slot), its tets (16), its springs (64); rows of
                 // four slots, dealt boustrophedon (the wave that took a hinge slot in one row takes the cheapest of the next).
-                std::vector<uint32_t> it[sbk::kItemWaves];
+                std::vector<uint32_t> it[8];
                 uint32_t off = 0;                       // dwords from the start of the tile's data
                 bool fits = true;
                 for (const PackRound &R : prog) {
                     const uint32_t nd = (uint32_t)R.cnt[0], nv = (uint32_t)R.cnt[1], nb = (uint32_t)R.cnt[2];
                     const uint32_t dsize = compact ? ((nd + 3u) & ~3u) : ((2u * nd + 3u) & ~3u), qoff = off + dsize;
                     const int n_wb = (int)((nb + 15) >> 4), n_wv = (int)((nv + 15) >> 4), n_wd = (int)((nd + 63) >> 6);
-                    const int n_slots = n_wb + n_wv + n_wd, rows = std::max(1, (n_slots + sbk::kItemWaves - 1) / sbk::kItemWaves);
+                    const int n_slots = n_wb + n_wv + n_wd, rows = std::max(1, (n_slots + item_waves - 1) / item_waves);
                     for (int row = 0; row < rows; ++row)
-                        for (int wave = 0; wave < sbk::kItemWaves; ++wave) {
-                            const int sw = row * sbk::kItemWaves + ((row & 1) ? sbk::kItemWaves - 1 - wave : wave);
+                        for (int wave = 0; wave < item_waves; ++wave) {
+                            const int sw = row * item_waves + ((row & 1) ? item_waves - 1 - wave : wave);
                             uint32_t type = sbk::kItemIdle, cnt = 0, o = 0;
                             if (sw < n_wb) { type = sbk::kItemBending; cnt = std::min(16u, nb - 16u * (uint32_t)sw); o = qoff + 4u * (nv + 16u * (uint32_t)sw); }
                             else if (sw < n_wb + n_wv) { const uint32_t c0 = 16u * (uint32_t)(sw - n_wb); type = sbk::kItemVolume; cnt = std::min(16u, nv - c0); o = qoff + 4u * c0; }
@@ -560,7 +565,7 @@ void build_device(sb_solver *s) {
                 if (fits) {
                     td.n_steps = (int32_t)it[0].size();
                     td.s_items = (uint32_t)(stream.size() - s0);
-                    for (int wave = 0; wave < sbk::kItemWaves; ++wave) stream.insert(stream.end(), it[wave].begin(), it[wave].end());
+                    for (int wave = 0; wave < item_waves; ++wave) stream.insert(stream.end(), it[wave].begin(), it[wave].end());
                     while ((stream.size() - s0) & 3) stream.push_back(0);
                 }
             }
@@ -888,14 +893,22 @@ void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = 
     A.tp = s->d_tp.p;
     A.gather = D.gather.p;
     A.w_uniform = s->w_uniform ? 1 : 0;
+    A.item_waves = D.item_waves;
     A.max_local = D.max_local; A.win_dwords = D.win_dwords; A.tile_base = tile_begin; A.pal_dwords = D.pal_dwords; A.rounds_dwords = D.rounds_dwords;
     const bool small = D.max_local <= sbk::kSmallTile;   // every tile <= 512 particles
     // narrow (2-wave) workgroups once the launch oversubscribes the chip; wide ones while every tile is resident at once
     const bool narrow = small && (s->tile_lanes ? s->tile_lanes == sbk::kNarrowTileThreads : tile_end - tile_begin >= s->narrow_min_tiles);
-    const dim3 grid(tile_end - tile_begin), block(narrow ? sbk::kNarrowTileThreads : sbk::kWideTileThreads);
+    // tiles with tets / hinges: optionally 8 waves, so that a group's wave slots (16 four-lane constraints or 64 springs each) fit one row
+    const bool quad8 = D.has_quads && s->quad_lanes == sbk::kQuadTileThreads;
+    const dim3 grid(tile_end - tile_begin), block(quad8 ? sbk::kQuadTileThreads : (narrow ? sbk::kNarrowTileThreads : sbk::kWideTileThreads));
 #define SB_LAUNCH_TILE(Q, W)                                                                                                  \
     do {                                                                                                                      \
-        if (narrow) hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kNarrowTileThreads, sbk::kSmallTile / sbk::kNarrowTileThreads, W>), \
+        if (Q && quad8) {                                                                                                     \
+            if (small) hipLaunchKernelGGL((sbk::tile_kernel<KIND, true, sbk::kQuadTileThreads, sbk::kSmallTile / sbk::kQuadTileThreads, W>), \
+                                          grid, block, D.lds_bytes + s->lds_pad, s->stream, A);                                           \
+            else hipLaunchKernelGGL((sbk::tile_kernel<KIND, true, sbk::kQuadTileThreads, sbk::kLargeTile / sbk::kQuadTileThreads, W>), \
+                                    grid, block, D.lds_bytes + s->lds_pad, s->stream, A);                                                 \
+        } else if (narrow) hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kNarrowTileThreads, sbk::kSmallTile / sbk::kNarrowTileThreads, W>), \
                                        grid, block, D.lds_bytes + s->lds_pad, s->stream, A);                                              \
         else if (small) hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kWideTileThreads, sbk::kSmallTile / sbk::kWideTileThreads, W>), \
                                            grid, block, D.lds_bytes + s->lds_pad, s->stream, A);                                          \
@@ -1094,6 +1107,7 @@ int sb_create(const sb_desc *desc, sb_solver **out) {
         s->pack_tiles = !std::getenv("SB_NO_PACK");
         if (const char *e = std::getenv("SB_LDS_PAD")) s->lds_pad = (size_t)std::max(0, std::atoi(e));
         if (const char *e = std::getenv("SB_TILE_LANES")) s->tile_lanes = std::atoi(e) == 128 ? 128 : (std::atoi(e) == 256 ? 256 : 0);
+        if (const char *e = std::getenv("SB_QUAD_LANES")) s->quad_lanes = std::atoi(e) == 256 ? 256 : 512;
         if (const char *e = std::getenv("SB_NARROW_MIN_TILES")) s->narrow_min_tiles = std::max(1, std::atoi(e));
         HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreate(&s->ev0));

@@ -350,6 +350,16 @@ def test_both_workgroup_widths_match_the_oracle(oracle_mod, bunny20k, monkeypatc
     assert bit and np.array_equal(v.view(np.uint32), o.v.view(np.uint32)), (rel, mabs)
 
 
+@pytest.mark.parametrize("lanes", ["256", "512"])
+@pytest.mark.parametrize("tile", [256, 1024])
+def test_both_widths_of_tiles_with_tets_and_hinges_match_the_oracle(oracle_mod, bunny20k, monkeypatch, lanes, tile):
+    # tiles that hold four-lane constraints run as 4-wave or 8-wave workgroups (SB_QUAD_LANES): the host deals the wave
+    # items for that many waves, the bits must not change; 1024-particle tiles use the large-tile instantiations
+    monkeypatch.setenv("SB_QUAD_LANES", lanes)
+    rel, mabs, bit, x, v, o, st = _run_pair(oracle_mod, bunny20k, ticks=2, substeps=6, compliance=(1e-7, 1e-7, 1e-5), tile_particles=tile)
+    assert bit and np.array_equal(v.view(np.uint32), o.v.view(np.uint32)), (rel, mabs)
+
+
 def test_bench_configuration_256_properties(monkeypatch):
     # BASELINE.json:9 at full size (16.8 M particles, 50.1 M springs): no oracle run, size-independent properties instead --
     # (1) the rest lattice is a bitwise fixed point without gravity, (2) both workgroup widths and the unpacked launch

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Interleaved A/B of one environment switch of the plugin (read at sb_create / sb_finalize) on config 5 (100 k surrogate) and
-the 64^3 cube: ms per tick without and with VAR=1. usage: python tools/env_ab.py SB_NO_COST_ORDER [rounds]"""
+the 64^3 cube: ms per tick without and with VAR=1 (or VAR=VALUE). usage: python tools/env_ab.py SB_NO_COST_ORDER|SB_QUAD_LANES=512 [rounds]"""
 import json
 import os
 import sys
@@ -26,7 +26,8 @@ def run(mesh, ticks, **kw):
 
 
 def main():
-    var = sys.argv[1]
+    var, _, val = sys.argv[1].partition("=")
+    val = val or "1"
     rounds = int(sys.argv[2]) if len(sys.argv) > 2 else 3
     bunny = bunny_surrogate(target_verts=100_000)
     cube = jelly_cube(64)
@@ -35,10 +36,10 @@ def main():
         for state in ("unset", "set"):
             os.environ.pop(var, None)
             if state == "set":
-                os.environ[var] = "1"
+                os.environ[var] = val
             res["bunny100k"][state].append(run(bunny, 100, distance_compliance=1e-7, volume_compliance=1e-7, bending_compliance=1e-5))
             res["cube64"][state].append(run(cube, 400))
-    print(json.dumps({"switch": var, **res}))
+    print(json.dumps({"switch": f"{var}={val}", **res}))
 
 
 if __name__ == "__main__":
