@@ -611,12 +611,17 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
             }
             lds_barrier();
         };
-        if (KIND != 0) {
+#if defined(SB_ABLATE) && SB_ABLATE == 1   // timing experiment only: the launch without its rounds
+        constexpr bool kRunRounds = false;
+#else
+        constexpr bool kRunRounds = true;
+#endif
+        if (KIND != 0 && kRunRounds) {
 #pragma unroll
             for (int r = 0; r < kRegRounds; ++r) if (r < n_rounds_all) reg_round(rs[r], rl[r], rcnt[r]);
         }
         if (KIND != 3) { mark_step(); lds_barrier(); }
-        if (KIND == 0 || KIND == 1) {
+        if ((KIND == 0 || KIND == 1) && kRunRounds) {
 #pragma unroll
             for (int r = 0; r < kRegRounds; ++r) if (r < n_rounds_all) reg_round(rs[r], rl[r], rcnt[r]);
         }
