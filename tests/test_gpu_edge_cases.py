@@ -209,3 +209,49 @@ def test_hub_particle_with_300_springs(oracle_mod, tile):
     # valence 300 -> 300+ rounds in one tile (round words read from memory, not LDS or lanes) / 300 global colours
     from test_plan import _hub_mesh
     _pair(oracle_mod, _hub_mesh(), ticks=2, S=3, tile_particles=tile)
+
+
+def _fan_mesh(n_ring=150, n_hinges=40, seed=7):
+    """A hub and an apex joined to a ring: tet (hub, r_i, r_i+1, apex) for every ring edge, springs hub - r_i and along the ring,
+    hinges on the edge (hub, apex) with wings (r_i, r_i+1): hub and apex sit in every tet and hinge, so one tile walks n_ring + n_hinges
+    groups (more than the 64 wave items a register holds)."""
+    rng = np.random.default_rng(seed)
+    ang = np.linspace(0.0, 2.0 * np.pi, n_ring, endpoint=False)
+    ring = np.stack([np.cos(ang), np.zeros(n_ring), np.sin(ang)], axis=1) * rng.uniform(0.9, 1.1, (n_ring, 1))
+    pos = np.concatenate([[[0.0, -0.4, 0.0]], [[0.0, 0.9, 0.0]], ring]).astype(f32)
+    hub, apex, r = 0, 1, lambda i: 2 + i % n_ring
+    ij = np.array([(hub, r(i)) for i in range(n_ring)] + [(r(i), r(i + 1)) for i in range(n_ring)] + [(hub, apex)], np.int32)
+    rest = (np.linalg.norm(pos[ij[:, 0]] - pos[ij[:, 1]], axis=1) * 0.95).astype(f32)
+    tets = np.array([(hub, r(i), r(i + 1), apex) for i in range(n_ring)], np.int32)
+    e1, e2, e3 = pos[tets[:, 1]] - pos[tets[:, 0]], pos[tets[:, 2]] - pos[tets[:, 0]], pos[tets[:, 3]] - pos[tets[:, 0]]
+    vol = (np.einsum("ij,ij->i", e1, np.cross(e2, e3)) / 6.0 * 0.97).astype(f32)
+    step = max(1, n_ring // n_hinges)
+    hinges = np.array([(hub, apex, r(i), r(i + 1)) for i in range(0, n_ring, step)][:n_hinges], np.int32)
+    phi = np.full(len(hinges), 0.3, np.float64)
+    bend = np.stack([np.cos(phi), np.sin(phi)], axis=1).astype(f32)
+    return SoftbodyMesh(rest_pos=pos.copy(), pos=pos.copy(), vel=np.zeros_like(pos), inv_mass=np.ones(len(pos), f32), dist_ij=ij, dist_rest=rest,
+                        vol_ijkl=tets, vol_rest=vol, bend_ijkl=hinges, bend_rest=bend)
+
+
+@pytest.mark.parametrize("lanes", ["256", "512"])
+@pytest.mark.parametrize("window", [None, "1024"])
+def test_hub_with_tets_and_hinges_walks_more_than_64_steps(oracle_mod, monkeypatch, lanes, window):
+    # the wave items of a tile are kept 64 steps at a time in a register: 190 dependent groups reload it twice per pass;
+    # with a 4 KiB LDS window the tile's data does not fit and the generic group loop (window refills) runs instead
+    monkeypatch.setenv("SB_QUAD_LANES", lanes)
+    if window:
+        monkeypatch.setenv("SB_WIN_DWORDS", window)
+    mesh = _fan_mesh()
+    kw = dict(distance_compliance=1e-6, volume_compliance=1e-6, bending_compliance=1e-3)
+    sb = Softbody(mesh, substeps=4, **kw).Start()
+    try:
+        plan = sb.plan()
+        assert len(plan.groups(0)) - 1 >= 150
+        o = make_oracle(oracle_mod, mesh, plan, compliance=(1e-6, 1e-6, 1e-3))
+        for _ in range(3):
+            sb.step(); o.step(0.02, 4)
+        x, v = sb.get_positions(), sb.get_velocities()
+    finally:
+        sb.OnDestroy()
+    assert np.isfinite(x).all()
+    assert np.array_equal(x.view(np.uint32), o.x.view(np.uint32)) and np.array_equal(v.view(np.uint32), o.v.view(np.uint32))
