@@ -1,4 +1,7 @@
 #!/bin/bash
+# Config 5 kernel trace with the steps of every launch removed (the fixed cost per launch). Build the variant first (in the container):
+#   make -C softbodyunity_amd/csrc VARIANT=abl1 EXTRA=-DSB_ABLATE=1
+# usage on the GPU box: bash tools/bunny_ablate.sh
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 export SB_LIB_VARIANT=abl1
