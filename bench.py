@@ -58,7 +58,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=256, help="cube edge (particles = n^3)")
+    ap.add_argument("--n", "--cube-edge", dest="n", type=int, default=256,
+                    help="cube edge (particles = n^3); under torch.distributed.run spell it --cube-edge (its parser takes --n for an abbreviation of its own options)")
     ap.add_argument("--substeps", type=int, default=20)
     ap.add_argument("--tile", type=int, default=512, help="target particles per LDS tile, -1 = global colours only")
     ap.add_argument("--no-graph", action="store_true")
@@ -111,7 +112,8 @@ def main():
     N = mesh.n
     M = len(mesh.dist_rest)
     uid = None
-    if world > 1:
+    peer = args.transport == "peer"
+    if world > 1 and not peer:       # (the peer transport needs no RCCL communicator: the mailbox handles travel over gloo below)
         buf = torch.zeros(128, dtype=torch.uint8)
         if rank == 0:
             buf = torch.tensor(list(comm_unique_id()), dtype=torch.uint8)
@@ -126,6 +128,13 @@ def main():
         uid = comm_unique_id()
     sb = Softbody(mesh, substeps=args.substeps, fixed_delta_time=dt, device=device, rank=rank, world=sb_world,
                   tile_particles=args.tile, use_graph=not args.no_graph, unique_id=uid).Start()
+    if world > 1 and peer:
+        handles = [torch.zeros(64, dtype=torch.uint8) for _ in range(world)]
+        dist.all_gather(handles, torch.from_numpy(sb.peer_mailbox_handle().copy()))
+        for r in range(world):
+            if r != rank:
+                sb.peer_connect(r, handles[r].numpy())
+        dist.barrier()
     stats = sb.stats()
     setup_s = time.time() - t_setup
 

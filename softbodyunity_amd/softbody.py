@@ -134,6 +134,18 @@ class Softbody:
     def synchronize(self):
         check(native.lib().sb_synchronize(self._h))
 
+    # peer-store halo transport (SB_HALO_TRANSPORT=peer): the host carries the 64-byte mailbox handles between
+    # the ranks with whatever channel it has (bench.py: a gloo all_gather) and connects every other rank's mailbox before the first tick
+    def peer_mailbox_handle(self):
+        out = np.zeros(native.SB_IPC_HANDLE_BYTES, np.uint8)
+        check(native.lib().sb_peer_mailbox_handle(self._h, ptr(out)))
+        return out
+
+    def peer_connect(self, rank, handle):
+        h = np.ascontiguousarray(handle, np.uint8)
+        assert h.shape == (native.SB_IPC_HANDLE_BYTES,)
+        check(native.lib().sb_peer_connect(self._h, int(rank), ptr(h), None))
+
     def get_positions(self, out=None):
         out = np.zeros((self.n, 3), np.float32) if out is None else out
         check(native.lib().sb_get_positions(self._h, ptr(out), self.n))
