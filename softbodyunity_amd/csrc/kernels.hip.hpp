@@ -52,6 +52,7 @@ constexpr int kMaxRoundsLds = 128;   // round words cached in LDS; longer progra
 constexpr int kMaxPalette = 256;     // rest-length dictionary entries per tile
 
 // Positions in HBM: packed xyz (12 B) + the static inverse mass in a side array (never rewritten).
+typedef float f32x3_t __attribute__((ext_vector_type(3)));
 struct PosView {
     float *xyz;        // 3 floats per local particle
     const float *w;    // inverse mass per local particle
@@ -63,6 +64,16 @@ __device__ __forceinline__ float4 pv_load(const PosView &P, int g) {
 __device__ __forceinline__ void pv_store(const PosView &P, int g, const float4 &v) {
     const size_t o = 3 * (size_t)g;
     P.xyz[o] = v.x; P.xyz[o + 1] = v.y; P.xyz[o + 2] = v.z;
+}
+
+// 12-byte store that writes through the L2 (sc0 sc1). The 8 XCDs' L2s are not coherent with each other, so a kernel ends with a
+// write-back of every dirty line; in a launch of a few thousand tiles (every tile resident at once, the kernel a chain of
+// latencies) that write-back is a third of the kernel -- 64^3: a launch with its rounds removed takes 5.9 us, of which 3.2 us are
+// the MARK step's and the final stores plus the end of the kernel. Written through, the state leaves the chip while the kernel
+// still runs (64^3: 7.9 -> 6.1 us per launch). Large launches keep ordinary stores (256^3: write-through is 4 % slower).
+__device__ __forceinline__ void store3_through(float *p, float x, float y, float z) {
+    f32x3_t v = {x, y, z};
+    asm volatile("global_store_dwordx3 %0, %1, off sc0 sc1" ::"v"(p), "v"(v) : "memory");
 }
 
 constexpr int kMaxMassPalette = 64;   // distinct inverse masses that fit the one-byte-per-particle coding (one per lane)
@@ -85,6 +96,7 @@ struct TileArgs {
     int32_t tile_base;        // this launch covers tiles tile_base + blockIdx.x (boundary / interior split)
     int32_t w_uniform;        // WPAL kernels: every particle has the same inverse mass -> all lanes read index 0 (one cache line, no per-particle byte)
     int32_t item_waves;       // waves per tile the wave items of this tiling were dealt for (0 = none)
+    int32_t store_through;    // positions / previous positions are stored through the L2 (small launches, see store3_through)
 };
 
 // Lanes per tile (template parameter THREADS of tile_kernel). A round holds up to kRoundSlots independent constraints,
@@ -367,6 +379,9 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
     const int run_count = td.run_count;
     const TickParams tp = *A.tp;
     const uint32_t *tstream = A.stream + td.s_begin;
+#if defined(SB_ABLATE) && SB_ABLATE == 4   // timing experiment only: dispatch + descriptor fetch
+    if (n_local >= 0) { if (n_rounds_all == 0x7fffffff) A.vel[0] = tp.h; return; }
+#endif
 
     // ---- particle ownership: lane tid owns tile-local particles tid + THREADS*m ------------------
     // Branch-free run lookup: the runs are sorted by their first local index and unused inline entries hold
@@ -500,6 +515,9 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
         for (uint32_t i = tid + kW * kTileThreads; i < n4_first; i += kTileThreads) dst[i] = wsrc[i];
     }
     __syncthreads();   // also covers the staging loads
+#if defined(SB_ABLATE) && SB_ABLATE == 5   // timing experiment only: dispatch + descriptor + every load of the tile, nothing else
+    if (n_local >= 0) { if (lds_pos[tid].x == 1.2345e-30f && cbuf[tid] == 0x12345678u) A.vel[0] = tp.h; return; }
+#endif
 
     // MARK step (SPEC.md §2): collide + velocity update of the substep that just finished, integrate of the next one
     auto mark_step = [&]() {
@@ -529,7 +547,8 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
                 if (KIND == 2) {
                     A.vel[o + 0] = vx; A.vel[o + 1] = vy; A.vel[o + 2] = vz;
                 } else {
-                    A.prev[o + 0] = P.x; A.prev[o + 1] = P.y; A.prev[o + 2] = P.z;
+                    if (A.store_through) store3_through(A.prev + o, P.x, P.y, P.z);
+                    else { A.prev[o + 0] = P.x; A.prev[o + 1] = P.y; A.prev[o + 2] = P.z; }
                     if (P.w > 0.0f) {
                         vx = vx + tp.hgx; vy = vy + tp.hgy; vz = vz + tp.hgz;
                         float hx = tp.h * vx, hy = tp.h * vy, hz = tp.h * vz;
@@ -829,7 +848,11 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
     }
 #pragma unroll
     for (int m = 0; m < PPT; ++m)
-        if (g[m] >= 0) pv_store(A.pos, g[m], lds_pos[tid + m * kTileThreads]);
+        if (g[m] >= 0) {
+            const float4 P = lds_pos[tid + m * kTileThreads];
+            if (A.store_through) store3_through(A.pos.xyz + 3 * (size_t)g[m], P.x, P.y, P.z);
+            else pv_store(A.pos, g[m], P);
+        }
 }
 
 // Global-colour kernels: one constraint per lane, gather/scatter straight on HBM.
@@ -916,11 +939,12 @@ __global__ __launch_bounds__(256) void halo_pack_kernel(PosView pos, const float
     float *b = buf + (size_t)F * k;
     // 12-byte vector accesses: one load and one store per array instead of three
     const f32x3 x = *reinterpret_cast<const f32x3 *>(pos.xyz + o);
+    // (stores through the L2, see store3_through: these kernels are a few hundred workgroups between two dependent launches)
     if (WITH_PREV) {
         const f32x3 p = *reinterpret_cast<const f32x3 *>(prev + o);
-        *reinterpret_cast<f32x3 *>(b + 3) = p;
+        store3_through(b + 3, p.x, p.y, p.z);
     }
-    *reinterpret_cast<f32x3 *>(b) = x;
+    store3_through(b, x.x, x.y, x.z);
 }
 template <bool WITH_PREV>
 __global__ __launch_bounds__(256) void halo_unpack_kernel(PosView pos, float *prev, const int32_t *idx, const float *buf, int count) {
@@ -932,9 +956,9 @@ __global__ __launch_bounds__(256) void halo_unpack_kernel(PosView pos, float *pr
     const f32x3 x = *reinterpret_cast<const f32x3 *>(b);
     if (WITH_PREV) {
         const f32x3 p = *reinterpret_cast<const f32x3 *>(b + 3);
-        *reinterpret_cast<f32x3 *>(prev + o) = p;
+        store3_through(prev + o, p.x, p.y, p.z);
     }
-    *reinterpret_cast<f32x3 *>(pos.xyz + o) = x;
+    store3_through(pos.xyz + o, x.x, x.y, x.z);
 }
 
 // ---- peer-store halo transport (opt-in, SB_HALO_TRANSPORT=peer; solver.hip) ---------------------------------------
@@ -1051,13 +1075,13 @@ __global__ __launch_bounds__(256) void peer_unpack_kernel(PosView pos, float *pr
                 x.x = __uint_as_float((uint32_t)q0); x.y = __uint_as_float((uint32_t)(q0 >> 32)); x.z = __uint_as_float((uint32_t)q1);
                 f32x3 pv;
                 pv.x = __uint_as_float((uint32_t)(q1 >> 32)); pv.y = __uint_as_float((uint32_t)q2); pv.z = __uint_as_float((uint32_t)(q2 >> 32));
-                *reinterpret_cast<f32x3 *>(prev + o) = pv;
+                store3_through(prev + o, pv.x, pv.y, pv.z);
             } else {
                 x.x = __hip_atomic_load(b + 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 x.y = __hip_atomic_load(b + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 x.z = __hip_atomic_load(b + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             }
-            *reinterpret_cast<f32x3 *>(pos.xyz + o) = x;
+            store3_through(pos.xyz + o, x.x, x.y, x.z);
         }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // this wave's mailbox reads are done

@@ -159,6 +159,8 @@ struct sb_solver {
     int tile_lanes = 0;              // SB_TILE_LANES=128|256 forces the workgroup width of small tiles (0 = by launch size)
     int quad_lanes = 512;            // SB_QUAD_LANES=256|512: workgroup width of tiles that hold tets / hinges (8 waves: every group of the
                                      // 100 k surrogate fits one row of wave slots; 1.99 against 2.11 ms per tick with 4 waves)
+    int store_through_max_tiles = 6144;   // SB_STORE_THROUGH_MAX_TILES: launches of at most this many tiles store their state through the L2
+                                          // (measured: 96^3 -18 %, 128^3 = 4096 tiles -3 %, 160^3 = 8000 tiles +2 %, 256^3 +4 %)
     int narrow_min_tiles = 10240;    // SB_NARROW_MIN_TILES; measured crossover: 160^3 (8000 tiles) ties, 192^3 (13824) +4 % narrow
     size_t lds_pad = 0;              // SB_LDS_PAD bytes of unused LDS per workgroup (occupancy experiments)
     bool pack_tiles = true;          // SB_NO_PACK unset: under-full tiles share a workgroup (build_device)
@@ -894,6 +896,7 @@ void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = 
     A.gather = D.gather.p;
     A.w_uniform = s->w_uniform ? 1 : 0;
     A.item_waves = D.item_waves;
+    A.store_through = tile_end - tile_begin <= s->store_through_max_tiles ? 1 : 0;
     A.max_local = D.max_local; A.win_dwords = D.win_dwords; A.tile_base = tile_begin; A.pal_dwords = D.pal_dwords; A.rounds_dwords = D.rounds_dwords;
     const bool small = D.max_local <= sbk::kSmallTile;   // every tile <= 512 particles
     // narrow (2-wave) workgroups once the launch oversubscribes the chip; wide ones while every tile is resident at once
@@ -1108,6 +1111,7 @@ int sb_create(const sb_desc *desc, sb_solver **out) {
         if (const char *e = std::getenv("SB_LDS_PAD")) s->lds_pad = (size_t)std::max(0, std::atoi(e));
         if (const char *e = std::getenv("SB_TILE_LANES")) s->tile_lanes = std::atoi(e) == 128 ? 128 : (std::atoi(e) == 256 ? 256 : 0);
         if (const char *e = std::getenv("SB_QUAD_LANES")) s->quad_lanes = std::atoi(e) == 256 ? 256 : 512;
+        if (const char *e = std::getenv("SB_STORE_THROUGH_MAX_TILES")) s->store_through_max_tiles = std::max(0, std::atoi(e));
         if (const char *e = std::getenv("SB_NARROW_MIN_TILES")) s->narrow_min_tiles = std::max(1, std::atoi(e));
         HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreate(&s->ev0));

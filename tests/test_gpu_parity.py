@@ -328,7 +328,7 @@ def test_tile_packing_is_invisible(oracle_mod, bunny20k, monkeypatch):
 
 @pytest.mark.parametrize("switch", ["SB_NO_MIXED_GROUPS", "SB_NO_CLUSTER_LAYERS", "SB_NO_THIRD_LIST", "SB_NO_T2", "SB_NO_PACK", "SB_NO_PALETTE",
                                     "SB_NO_MASS_PALETTE", "SB_NO_UNIFORM_MASS", "SB_NO_BANK_ORDER", "SB_NO_LAZY_TICK", "SB_NO_WAVE_ITEMS",
-                                    "SB_NO_COST_ORDER"])
+                                    "SB_NO_COST_ORDER", "SB_STORE_THROUGH_MAX_TILES"])
 def test_every_diagnostic_switch_still_matches_the_oracle(oracle_mod, bunny20k, monkeypatch, switch):
     # the A/B switches of DESIGN.md 6 change the plan (then the published order changes with it) or only the device
     # layout: either way the plugin must reproduce the oracle walking the order the plugin publishes
