@@ -350,7 +350,10 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <bool QUADS, int THREADS> constexpr int kWavesPerSimd = QUADS ? (THREADS == 64 ? 3 : (THREADS == 512 ? 2 : 4)) : (THREADS == 256 ? 8 : (THREADS == 128 ? 6 : 4));   // 128 lanes: 7 waves (72 VGPRs) measured 1 % slower, 8 spill
 // WPAL = inverse masses are read as one-byte palette indices (the palette entry comes from another lane by ds_bpermute).
 template <int KIND, bool QUADS, int THREADS, int PPT, bool WPAL>
-__global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile_kernel(TileArgs A) {
+__global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile_kernel(const TileDesc *tiles_at_base, int n_workgroups, TileArgs A) {
+    // The first two arguments (3 dwords) are preloaded into SGPRs at dispatch (-mllvm -amdgpu-kernarg-preload-count=3, Makefile):
+    // the descriptor fetch starts with the kernel instead of behind the kernel-argument load (one memory round trip less on the
+    // latency chain of a small launch). n_workgroups = gridDim.x (reading gridDim would be another kernel-argument load).
     constexpr int kTileThreads = THREADS;
     constexpr int kCPL = THREADS >= kRoundSlots ? 1 : kRoundSlots / THREADS;       // constraints per lane per round (8-wave tiles: QUADS only)
     extern __shared__ uint4 lds_raw[];
@@ -366,13 +369,13 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
     // give each XCD a contiguous range of tiles, so that neighbouring tiles -- whose runs meet inside a 128-byte line
     // wherever a T1 tile's pieces of one T0 tile lie side by side -- read and write those lines through the same L2.
 #ifndef SB_NO_XCD_REMAP
-    const int nwg = (int)gridDim.x, wg = (int)blockIdx.x;
+    const int nwg = n_workgroups, wg = (int)blockIdx.x;
     const int xq = nwg >> 3, xr = nwg & 7, xcd = wg & 7;
     const int tile_index = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wg >> 3);
 #else
     const int tile_index = (int)blockIdx.x;
 #endif
-    const TileDesc __attribute__((address_space(4))) &td = *((ConstTileDescPtr)(uintptr_t)A.tiles + (A.tile_base + tile_index));
+    const TileDesc __attribute__((address_space(4))) &td = *((ConstTileDescPtr)(uintptr_t)tiles_at_base + tile_index);
     const int n_rounds_all = td.n_rounds;
     const int tid = threadIdx.x;
     const int n_local = td.n_local;

@@ -898,6 +898,8 @@ void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = 
     A.item_waves = D.item_waves;
     A.store_through = tile_end - tile_begin <= s->store_through_max_tiles ? 1 : 0;
     A.max_local = D.max_local; A.win_dwords = D.win_dwords; A.tile_base = tile_begin; A.pal_dwords = D.pal_dwords; A.rounds_dwords = D.rounds_dwords;
+    const sbk::TileDesc *tiles_at_base = D.tiles.p + tile_begin;      // the two preloaded kernel arguments (tile_kernel)
+    const int n_wg = tile_end - tile_begin;
     const bool small = D.max_local <= sbk::kSmallTile;   // every tile <= 512 particles
     // narrow (2-wave) workgroups once the launch oversubscribes the chip; wide ones while every tile is resident at once
     const bool narrow = small && (s->tile_lanes ? s->tile_lanes == sbk::kNarrowTileThreads : tile_end - tile_begin >= s->narrow_min_tiles);
@@ -908,15 +910,15 @@ void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = 
     do {                                                                                                                      \
         if (Q && quad8) {                                                                                                     \
             if (small) hipLaunchKernelGGL((sbk::tile_kernel<KIND, true, sbk::kQuadTileThreads, sbk::kSmallTile / sbk::kQuadTileThreads, W>), \
-                                          grid, block, D.lds_bytes + s->lds_pad, s->stream, A);                                           \
+                                          grid, block, D.lds_bytes + s->lds_pad, s->stream, tiles_at_base, n_wg, A);                                           \
             else hipLaunchKernelGGL((sbk::tile_kernel<KIND, true, sbk::kQuadTileThreads, sbk::kLargeTile / sbk::kQuadTileThreads, W>), \
-                                    grid, block, D.lds_bytes + s->lds_pad, s->stream, A);                                                 \
+                                    grid, block, D.lds_bytes + s->lds_pad, s->stream, tiles_at_base, n_wg, A);                                                 \
         } else if (narrow) hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kNarrowTileThreads, sbk::kSmallTile / sbk::kNarrowTileThreads, W>), \
-                                       grid, block, D.lds_bytes + s->lds_pad, s->stream, A);                                              \
+                                       grid, block, D.lds_bytes + s->lds_pad, s->stream, tiles_at_base, n_wg, A);                                              \
         else if (small) hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kWideTileThreads, sbk::kSmallTile / sbk::kWideTileThreads, W>), \
-                                           grid, block, D.lds_bytes + s->lds_pad, s->stream, A);                                          \
+                                           grid, block, D.lds_bytes + s->lds_pad, s->stream, tiles_at_base, n_wg, A);                                          \
         else hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kWideTileThreads, sbk::kLargeTile / sbk::kWideTileThreads, W>), \
-                                grid, block, D.lds_bytes + s->lds_pad, s->stream, A);                                                     \
+                                grid, block, D.lds_bytes + s->lds_pad, s->stream, tiles_at_base, n_wg, A);                                                     \
     } while (0)
     if (s->w_palette) { if (D.has_quads) SB_LAUNCH_TILE(true, true); else SB_LAUNCH_TILE(false, true); }
     else { if (D.has_quads) SB_LAUNCH_TILE(true, false); else SB_LAUNCH_TILE(false, false); }
