@@ -331,6 +331,71 @@ __device__ __forceinline__ bool project_bending_quad(float (&P)[4], float rest_c
     return true;
 }
 
+// SPEC.md §6 on a ROW of 16 lanes (wave items path). A hinge is the longest projection of a step -- on four lanes it is 280
+// instructions against 90 for a tet, and a step lasts as long as its slowest wave: with every hinge priced like a tet the 100 k
+// surrogate's tick is 1.62 instead of 1.93 ms -- and the groups of a tile hold one to three hinges, so lanes are not what is
+// scarce. Its two triangles and its independent divisions are therefore spread over the four quads of a DPP row:
+//   quad 0: n1, m1 = n1/q1, ta1 -> ga          quad 1: n2, m2 = n2/q2, ta2 -> gb
+//   quad 2: n1, u1 = n1/sqrt(q1), tb1, cos / sin of the angle, C -> gc      quad 3: n2, u2 = n2/sqrt(q2), tb2 -> gd
+// (one cross product, one square root, two divisions per lane instead of two, two and six), the quads exchange values with row
+// rotations (row_ror) and ds_bpermute broadcasts, and quad k finishes with the update of particle k. Every value is computed by
+// the operation SPEC.md prescribes on the operands it prescribes, so the bits equal project_bending (and the oracle).
+// k = quad of the row (0..3), q = lane & 3, row_base4 = 4 * (first lane of the row). Xk: in/out, component q of particle k.
+template <int CTRL>
+__device__ __forceinline__ float rperm(float v) {
+    return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+__device__ __forceinline__ float from_next(float v) { return rperm<0x12c>(v); }    // lane i <- lane i + 4  (row_ror:12, measured: lane i reads lane i - n)
+__device__ __forceinline__ float from_plus2(float v) { return rperm<0x128>(v); }   // lane i <- lane i + 8
+__device__ __forceinline__ float from_prev(float v) { return rperm<0x124>(v); }    // lane i <- lane i - 4
+__device__ __forceinline__ float row_bcast_quad(float v, int row_base4, int quad) {
+    return __int_as_float(__builtin_amdgcn_ds_bpermute(row_base4 + 16 * quad, __float_as_int(v)));
+}
+__device__ __forceinline__ bool project_bending_row(const float (&P)[4], float rest_c, float rest_s, float at_b, int k, int row_base4,
+                                                    float &Xk) {
+    const float xa = P[0], xb = P[1], xc = P[2], xd = P[3];
+    const float e = xb - xa;
+    const float el2 = qdot(e, e);
+    const float el = sqrtf(el2);
+    const float ac = xa - xc, bc = xb - xc, bd = xb - xd, ad = xa - xd;
+    const bool side2 = (k & 1) != 0;
+    const float Pv = side2 ? bd : ac, Qv = side2 ? ad : bc;
+    const float n = qcross(Pv, Qv);                  // n1 in quads 0, 2; n2 in quads 1, 3
+    const float qq = qdot(n, n);                     // q1 / q2
+    const float qo = from_next(qq);                  // the other triangle's (quad k + 1 holds the other side)
+    if (!(el > 0.0f) || !(qq > 0.0f) || !(qo > 0.0f)) return false;
+    const float sq = sqrtf(qq);
+    const float r = n / (k >= 2 ? sq : qq);          // m1, m2, u1, u2
+    const float cb = xc - xb, db = xd - xb;
+    const float V = k == 0 ? cb : (k == 1 ? db : (k == 2 ? ac : ad));
+    const float t = qdot(V, e) / el;                 // ta1, ta2, tb1, tb2
+    const float t2 = from_plus2(t);                  // quad 0: tb1, quad 1: tb2
+    const float p_own = t * r, p_x = t2 * r;         // quad 0: ta1*m1, tb1*m1; quad 1: ta2*m2, tb2*m2
+    const float ga = p_own + from_next(p_own);       // (quad 0)  ta1*m1 + ta2*m2
+    const float gb = from_prev(p_x) + p_x;           // (quad 1)  tb1*m1 + tb2*m2
+    const float g23 = from_plus2(el * r);            // quad 2: gc = el*m1, quad 3: gd = el*m2
+    const float g = k == 0 ? ga : (k == 1 ? gb : g23);
+    // quad 2: u1 = r, u2 = quad 3's r
+    const float u2 = from_next(r);
+    const float cs = qdot(r, u2);
+    const float cr = qcross(r, u2);
+    const float sn = -(qdot(cr, e) / el);
+    const float t0 = sn * rest_c, t1 = cs * rest_s;
+    const float C = row_bcast_quad(t0 - t1, row_base4, 2);
+    const float xk = Xk;
+    const float Wk = qb3(xk);
+    const float ak = Wk * qdot(g, g);
+    const float a0 = row_bcast_quad(ak, row_base4, 0), a1 = row_bcast_quad(ak, row_base4, 1);
+    const float a2 = row_bcast_quad(ak, row_base4, 2), a3 = row_bcast_quad(ak, row_base4, 3);
+    const float den = (((a0 + a1) + a2) + a3) + at_b;
+    if (!(den > 0.0f)) return false;
+    const float s = (-C) / den;
+    const float sk = Wk * s;
+    const float d = sk * g;
+    Xk = xk + d;
+    return true;
+}
+
 // One workgroup = one tile (or one pack of under-full tiles, solver.hip build_device) of THREADS lanes; a tile owns one
 // constraint list, cut into rounds of at most kRoundSlots independent constraints (plan.hpp):
 //   KIND 0 (first kernel of a tick)  : MARK: v from the velocity array, integrate; the tile's rounds
@@ -666,7 +731,22 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
                 const uint32_t type = it & 7u;
                 const int cnt = (int)((it >> kItemCountShift) & 127u);
                 const uint32_t *slots = cbuf + (it >> kItemOffsetShift);
-                if (type >= kItemVolume) {
+                if (type == kItemBending) {
+                    // sixteen lanes per hinge (see project_bending_row): every quad of the row reads the four particles, quad k
+                    // writes particle k back
+                    const int c = lane >> 4;
+                    if (c < cnt) {
+                        const uint4 e = *reinterpret_cast<const uint4 *>(slots + 4 * c);
+                        const int k = (lane >> 2) & 3;
+                        const int o0 = 4 * (int)(e.x & 0xffffu) + q, o1 = 4 * (int)(e.x >> 16) + q;
+                        const int o2 = 4 * (int)(e.y & 0xffffu) + q, o3 = 4 * (int)(e.y >> 16) + q;
+                        const float P[4] = {lds_f[o0], lds_f[o1], lds_f[o2], lds_f[o3]};
+                        float Xk = k == 0 ? P[0] : (k == 1 ? P[1] : (k == 2 ? P[2] : P[3]));
+                        const int ok_off = k == 0 ? o0 : (k == 1 ? o1 : (k == 2 ? o2 : o3));
+                        const bool ok = project_bending_row(P, __uint_as_float(e.z), __uint_as_float(e.w), tp.at_b, k, (lane & 48) << 2, Xk);
+                        if (ok && q < 3) lds_f[ok_off] = Xk;
+                    }
+                } else if (type == kItemVolume) {
                     // four lanes per constraint (see project_volume_quad): lane q of a quad reads component q of the four
                     // particles (lane 3: their inverse masses), writes component q back
                     const int c = lane >> 2;
@@ -675,8 +755,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
                         const int o0 = 4 * (int)(e.x & 0xffffu) + q, o1 = 4 * (int)(e.x >> 16) + q;
                         const int o2 = 4 * (int)(e.y & 0xffffu) + q, o3 = 4 * (int)(e.y >> 16) + q;
                         float P[4] = {lds_f[o0], lds_f[o1], lds_f[o2], lds_f[o3]};
-                        const bool ok = type == kItemBending ? project_bending_quad(P, __uint_as_float(e.z), __uint_as_float(e.w), tp.at_b, q)
-                                                             : project_volume_quad(P, __uint_as_float(e.z), tp.at_v);
+                        const bool ok = project_volume_quad(P, __uint_as_float(e.z), tp.at_v);
                         if (ok && q < 3) { lds_f[o0] = P[0]; lds_f[o1] = P[1]; lds_f[o2] = P[2]; lds_f[o3] = P[3]; }
                     }
                 } else if (type != kItemIdle) {

@@ -546,13 +546,14 @@ void build_device(sb_solver *s) {
                 for (const PackRound &R : prog) {
                     const uint32_t nd = (uint32_t)R.cnt[0], nv = (uint32_t)R.cnt[1], nb = (uint32_t)R.cnt[2];
                     const uint32_t dsize = compact ? ((nd + 3u) & ~3u) : ((2u * nd + 3u) & ~3u), qoff = off + dsize;
-                    const int n_wb = (int)((nb + 15) >> 4), n_wv = (int)((nv + 15) >> 4), n_wd = (int)((nd + 63) >> 6);
+                    // (a hinge takes a row of 16 lanes in the wave-items path, kernels.hip.hpp project_bending_row: 4 per wave slot)
+                    const int n_wb = (int)((nb + 3) >> 2), n_wv = (int)((nv + 15) >> 4), n_wd = (int)((nd + 63) >> 6);
                     const int n_slots = n_wb + n_wv + n_wd, rows = std::max(1, (n_slots + item_waves - 1) / item_waves);
                     for (int row = 0; row < rows; ++row)
                         for (int wave = 0; wave < item_waves; ++wave) {
                             const int sw = row * item_waves + ((row & 1) ? item_waves - 1 - wave : wave);
                             uint32_t type = sbk::kItemIdle, cnt = 0, o = 0;
-                            if (sw < n_wb) { type = sbk::kItemBending; cnt = std::min(16u, nb - 16u * (uint32_t)sw); o = qoff + 4u * (nv + 16u * (uint32_t)sw); }
+                            if (sw < n_wb) { type = sbk::kItemBending; cnt = std::min(4u, nb - 4u * (uint32_t)sw); o = qoff + 4u * (nv + 4u * (uint32_t)sw); }
                             else if (sw < n_wb + n_wv) { const uint32_t c0 = 16u * (uint32_t)(sw - n_wb); type = sbk::kItemVolume; cnt = std::min(16u, nv - c0); o = qoff + 4u * c0; }
                             else if (sw < n_slots) {
                                 const uint32_t c0 = 64u * (uint32_t)(sw - n_wb - n_wv);
