@@ -743,7 +743,11 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
                         const float P[4] = {lds_f[o0], lds_f[o1], lds_f[o2], lds_f[o3]};
                         float Xk = k == 0 ? P[0] : (k == 1 ? P[1] : (k == 2 ? P[2] : P[3]));
                         const int ok_off = k == 0 ? o0 : (k == 1 ? o1 : (k == 2 ? o2 : o3));
+#if defined(SB_ABLATE) && SB_ABLATE == 2   // timing experiment only (WRONG results): LDS traffic and barriers without the arithmetic
+                        const bool ok = true; Xk += __uint_as_float(e.z) * P[1];
+#else
                         const bool ok = project_bending_row(P, __uint_as_float(e.z), __uint_as_float(e.w), tp.at_b, k, (lane & 48) << 2, Xk);
+#endif
                         if (ok && q < 3) lds_f[ok_off] = Xk;
                     }
                 } else if (type == kItemVolume) {
@@ -755,7 +759,11 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
                         const int o0 = 4 * (int)(e.x & 0xffffu) + q, o1 = 4 * (int)(e.x >> 16) + q;
                         const int o2 = 4 * (int)(e.y & 0xffffu) + q, o3 = 4 * (int)(e.y >> 16) + q;
                         float P[4] = {lds_f[o0], lds_f[o1], lds_f[o2], lds_f[o3]};
+#if defined(SB_ABLATE) && SB_ABLATE == 2
+                        const bool ok = true; P[0] += __uint_as_float(e.z); P[1] -= P[2]; P[3] += P[0];
+#else
                         const bool ok = project_volume_quad(P, __uint_as_float(e.z), tp.at_v);
+#endif
                         if (ok && q < 3) { lds_f[o0] = P[0]; lds_f[o1] = P[1]; lds_f[o2] = P[2]; lds_f[o3] = P[3]; }
                     }
                 } else if (type != kItemIdle) {
@@ -770,7 +778,11 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
                             i = e.x & 0xffffu; k = e.x >> 16; L0 = __uint_as_float(e.y);
                         }
                         float4 a = lds_pos[i], b = lds_pos[k];
+#if defined(SB_ABLATE) && SB_ABLATE == 2
+                        a.x += L0; b.x -= tp.at_d; lds_pos[i] = a; lds_pos[k] = b;
+#else
                         if (project_distance(a, b, L0, tp.at_d)) { lds_pos[i] = a; lds_pos[k] = b; }
+#endif
                     }
                 }
                 if (it & (1u << kItemBarrierBit)) lds_barrier();
