@@ -96,7 +96,7 @@ struct TileArgs {
     int32_t tile_base;        // this launch covers tiles tile_base + blockIdx.x (boundary / interior split)
     int32_t w_uniform;        // WPAL kernels: every particle has the same inverse mass -> all lanes read index 0 (one cache line, no per-particle byte)
     int32_t item_waves;       // waves per tile the wave items of this tiling were dealt for (0 = none)
-    int32_t store_through;    // positions / previous positions are stored through the L2 (small launches, see store3_through)
+    int32_t store_through;    // bit 0: previous positions, bit 1: positions are stored through the L2 (small launches, see store3_through)
 };
 
 // Lanes per tile (template parameter THREADS of tile_kernel). A round holds up to kRoundSlots independent constraints,
@@ -615,7 +615,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
                 if (KIND == 2) {
                     A.vel[o + 0] = vx; A.vel[o + 1] = vy; A.vel[o + 2] = vz;
                 } else {
-                    if (A.store_through) store3_through(A.prev + o, P.x, P.y, P.z);
+                    if (A.store_through & 1) store3_through(A.prev + o, P.x, P.y, P.z);
                     else { A.prev[o + 0] = P.x; A.prev[o + 1] = P.y; A.prev[o + 2] = P.z; }
                     if (P.w > 0.0f) {
                         vx = vx + tp.hgx; vy = vy + tp.hgy; vz = vz + tp.hgz;
@@ -944,7 +944,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
     for (int m = 0; m < PPT; ++m)
         if (g[m] >= 0) {
             const float4 P = lds_pos[tid + m * kTileThreads];
-            if (A.store_through) store3_through(A.pos.xyz + 3 * (size_t)g[m], P.x, P.y, P.z);
+            if (A.store_through & 2) store3_through(A.pos.xyz + 3 * (size_t)g[m], P.x, P.y, P.z);
             else pv_store(A.pos, g[m], P);
         }
 }

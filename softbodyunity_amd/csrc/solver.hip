@@ -161,6 +161,7 @@ struct sb_solver {
                                      // 100 k surrogate fits one row of wave slots; 1.99 against 2.11 ms per tick with 4 waves)
     int store_through_max_tiles = 6144;   // SB_STORE_THROUGH_MAX_TILES: launches of at most this many tiles store their state through the L2
                                           // (measured: 96^3 -18 %, 128^3 = 4096 tiles -3 %, 160^3 = 8000 tiles +2 %, 256^3 +4 %)
+    int store_through_large = 0;          // SB_STORE_THROUGH_LARGE=mask: the same for larger launches (experiments; bit 0 previous positions, bit 1 positions)
     int narrow_min_tiles = 10240;    // SB_NARROW_MIN_TILES; measured crossover: 160^3 (8000 tiles) ties, 192^3 (13824) +4 % narrow
     size_t lds_pad = 0;              // SB_LDS_PAD bytes of unused LDS per workgroup (occupancy experiments)
     bool pack_tiles = true;          // SB_NO_PACK unset: under-full tiles share a workgroup (build_device)
@@ -897,7 +898,7 @@ void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = 
     A.gather = D.gather.p;
     A.w_uniform = s->w_uniform ? 1 : 0;
     A.item_waves = D.item_waves;
-    A.store_through = tile_end - tile_begin <= s->store_through_max_tiles ? 1 : 0;
+    A.store_through = tile_end - tile_begin <= s->store_through_max_tiles ? 3 : s->store_through_large;
     A.max_local = D.max_local; A.win_dwords = D.win_dwords; A.tile_base = tile_begin; A.pal_dwords = D.pal_dwords; A.rounds_dwords = D.rounds_dwords;
     const sbk::TileDesc *tiles_at_base = D.tiles.p + tile_begin;      // the two preloaded kernel arguments (tile_kernel)
     const int n_wg = tile_end - tile_begin;
@@ -1115,6 +1116,7 @@ int sb_create(const sb_desc *desc, sb_solver **out) {
         if (const char *e = std::getenv("SB_TILE_LANES")) s->tile_lanes = std::atoi(e) == 128 ? 128 : (std::atoi(e) == 256 ? 256 : 0);
         if (const char *e = std::getenv("SB_QUAD_LANES")) s->quad_lanes = std::atoi(e) == 256 ? 256 : 512;
         if (const char *e = std::getenv("SB_STORE_THROUGH_MAX_TILES")) s->store_through_max_tiles = std::max(0, std::atoi(e));
+        if (const char *e = std::getenv("SB_STORE_THROUGH_LARGE")) s->store_through_large = std::atoi(e) & 3;
         if (const char *e = std::getenv("SB_NARROW_MIN_TILES")) s->narrow_min_tiles = std::max(1, std::atoi(e));
         HIP_CHECK(hipStreamCreateWithFlags(&s->stream, hipStreamNonBlocking));
         HIP_CHECK(hipEventCreate(&s->ev0));
