@@ -1,11 +1,11 @@
 #!/bin/bash
 # One round's committed evidence, run on the GPU box: bash tools/profile_round.sh <round tag, e.g. r01g>
-# kernel trace + stats (n256, n64), FETCH_SIZE / WRITE_SIZE passes (n256), bench JSON lines (n256 with CPU baseline, n64).
+# kernel trace + stats (n256, n64; the timed region of the default bench run: 3 warm-up + 20 timed ticks), FETCH_SIZE / WRITE_SIZE passes (n256), bench JSON lines (n256 with CPU baseline, n64).
 TAG=${1:?round tag}
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 for n in 256 64; do
-  rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_n$n -o kt --output-format csv -- python3 $R/bench.py --n $n --steps 6 --warmup 1 --no-cpu-baseline --no-parity --allow-stale-traffic > $R/gpurun_out/prof_${TAG}_n$n.out 2> $R/gpurun_out/prof_${TAG}_n$n.err || exit 1
+  rocprofv3 --kernel-trace --stats -d $R/gpurun_out/prof_${TAG}_n$n -o kt --output-format csv -- python3 $R/bench.py --n $n --steps ${STEPS:-20} --warmup ${WARMUP:-3} --no-cpu-baseline --no-parity --allow-stale-traffic > $R/gpurun_out/prof_${TAG}_n$n.out 2> $R/gpurun_out/prof_${TAG}_n$n.err || exit 1
 done
 rocprofv3 --pmc FETCH_SIZE -d $R/gpurun_out/pmc_fetch_${TAG} -o pmc --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity --allow-stale-traffic > /dev/null 2> $R/gpurun_out/pmc_fetch_${TAG}.err || exit 1
 rocprofv3 --pmc WRITE_SIZE -d $R/gpurun_out/pmc_write_${TAG} -o pmc --output-format csv -- python3 $R/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-parity --allow-stale-traffic > /dev/null 2> $R/gpurun_out/pmc_write_${TAG}.err || exit 1
