@@ -81,6 +81,71 @@ namespace SoftbodyMI355X
             sb.volumeIJKL = idx.ToArray(); sb.volumeRest = vol.ToArray();
         }
 
+        /// Gmsh .msh, ASCII 2.2 or 4.1: the 4-node tetrahedra (element type 4) of the file -> FromTetMesh. Node tags need not be
+        /// consecutive; nodes no tet uses (geometry points) are dropped. Mirrors softbodyunity_amd/mesh.py read_gmsh.
+        public static void ReadGmsh(Softbody sb, string path)
+        {
+            var sect = new Dictionary<string, List<string>>();
+            string name = null; List<string> cur = null;
+            foreach (var raw in System.IO.File.ReadAllLines(path))
+            {
+                var ln = raw.Trim();
+                if (ln.Length == 0) continue;
+                if (ln.StartsWith("$End")) { name = null; cur = null; }
+                else if (ln.StartsWith("$")) { name = ln.Substring(1); cur = new List<string>(); sect[name] = cur; }
+                else if (cur != null) cur.Add(ln);
+            }
+            var inv = System.Globalization.CultureInfo.InvariantCulture;
+            var fmt = sect["MeshFormat"][0].Split((char[])null, StringSplitOptions.RemoveEmptyEntries);
+            if (int.Parse(fmt[1]) != 0) throw new FormatException("binary .msh files are not read: export ASCII");
+            bool v2 = double.Parse(fmt[0], inv) < 3.0;
+            var tag = new List<long>(); var xyz = new List<Vector3>(); var tet = new List<long>();
+            var N = sect["Nodes"]; var E = sect["Elements"];
+            Func<string, string[]> split = l => l.Split((char[])null, StringSplitOptions.RemoveEmptyEntries);
+            if (v2)
+            {
+                int n = int.Parse(N[0]);
+                for (int i = 1; i <= n; ++i) { var t = split(N[i]); tag.Add(long.Parse(t[0])); xyz.Add(new Vector3(float.Parse(t[1], inv), float.Parse(t[2], inv), float.Parse(t[3], inv))); }
+                int m = int.Parse(E[0]);
+                for (int i = 1; i <= m; ++i)
+                {
+                    var t = split(E[i]);
+                    if (int.Parse(t[1]) != 4) continue;
+                    int first = 3 + int.Parse(t[2]);
+                    for (int q = 0; q < 4; ++q) tet.Add(long.Parse(t[first + q]));
+                }
+            }
+            else
+            {
+                int k = 1, blocks = int.Parse(split(N[0])[0]);
+                for (int b = 0; b < blocks; ++b)
+                {
+                    int cnt = int.Parse(split(N[k++])[3]);
+                    for (int i = 0; i < cnt; ++i) tag.Add(long.Parse(N[k + i]));
+                    k += cnt;
+                    for (int i = 0; i < cnt; ++i) { var t = split(N[k + i]); xyz.Add(new Vector3(float.Parse(t[0], inv), float.Parse(t[1], inv), float.Parse(t[2], inv))); }
+                    k += cnt;
+                }
+                k = 1; blocks = int.Parse(split(E[0])[0]);
+                for (int b = 0; b < blocks; ++b)
+                {
+                    var h = split(E[k++]); int etype = int.Parse(h[2]), cnt = int.Parse(h[3]);
+                    if (etype == 4) for (int i = 0; i < cnt; ++i) { var t = split(E[k + i]); for (int q = 1; q <= 4; ++q) tet.Add(long.Parse(t[q])); }
+                    k += cnt;
+                }
+            }
+            if (tet.Count == 0) throw new FormatException("no 4-node tetrahedra (element type 4) in the file");
+            var indexOf = new Dictionary<long, int>();
+            for (int i = 0; i < tag.Count; ++i) indexOf[tag[i]] = i;
+            var used = new SortedSet<int>();
+            foreach (var t in tet) used.Add(indexOf[t]);
+            var remap = new Dictionary<int, int>(); var nodes = new List<Vector3>();
+            foreach (int u in used) { remap[u] = nodes.Count; nodes.Add(xyz[u]); }
+            var tets = new int[tet.Count];
+            for (int i = 0; i < tet.Count; ++i) tets[i] = remap[indexOf[tet[i]]];
+            FromTetMesh(sb, nodes.ToArray(), tets);
+        }
+
         static void AddEdge(SortedDictionary<(int, int), List<int>> edges, int a, int b, int opp)
         {
             var k = (Math.Min(a, b), Math.Max(a, b));

@@ -5,5 +5,5 @@ P/Invoke layer (native.py), the Softbody component mirror (softbody.py) and the 
 generators (mesh.py). The CPU oracle lives in /oracle and is never imported from here.
 """
 from .mesh import (SoftbodyMesh, bunny_surrogate, from_tet_mesh, from_triangle_mesh, jelly_cube,  # noqa: F401
-                   read_tetgen)
+                   read_gmsh, read_tetgen)
 from .softbody import Softbody, comm_unique_id  # noqa: F401

@@ -241,3 +241,55 @@ def read_tetgen(node_path, ele_path):
     assert npt >= 4
     tets = np.array([[int(c) - base for c in r[1:5]] for r in er[1:1 + n_tets]])
     return from_tet_mesh(nodes, tets, label=f"tetgen:{node_path}")
+
+
+def read_gmsh(path):
+    """Gmsh .msh, ASCII format 2.2 or 4.1 -> from_tet_mesh (4-node tetrahedra, element type 4; other element types are skipped).
+
+    The second tet-mesh input SURVEY.md 8f names beside TetGen's .node/.ele. Node tags need not be consecutive."""
+    lines = [ln.strip() for ln in open(path)]
+    sect = {}
+    i = 0
+    while i < len(lines):
+        if lines[i].startswith("$") and not lines[i].startswith("$End"):
+            name = lines[i][1:]
+            j = i + 1
+            while j < len(lines) and lines[j] != "$End" + name:
+                j += 1
+            sect[name] = [ln for ln in lines[i + 1:j] if ln]
+            i = j + 1
+        else:
+            i += 1
+    fmt = sect["MeshFormat"][0].split()
+    version, is_binary = float(fmt[0]), int(fmt[1])
+    assert is_binary == 0, "binary .msh files are not read: export ASCII (gmsh -format msh2 / msh4 without -bin)"
+    tags, coords, tets = [], [], []
+    N, E = sect["Nodes"], sect["Elements"]
+    if version < 3.0:                                   # 2.2: "n" then "tag x y z"; "m" then "tag type ntags tags... nodes..."
+        for ln in N[1:1 + int(N[0])]:
+            t = ln.split(); tags.append(int(t[0])); coords.append([float(c) for c in t[1:4]])
+        for ln in E[1:1 + int(E[0])]:
+            t = [int(c) for c in ln.split()]
+            if t[1] == 4:
+                tets.append(t[3 + t[2]:3 + t[2] + 4])
+    else:                                               # 4.x: entity blocks
+        nb = int(N[0].split()[0]); k = 1
+        for _ in range(nb):
+            cnt = int(N[k].split()[3]); k += 1
+            tags += [int(t) for t in N[k:k + cnt]]; k += cnt
+            coords += [[float(c) for c in ln.split()[:3]] for ln in N[k:k + cnt]]; k += cnt
+        nb = int(E[0].split()[0]); k = 1
+        for _ in range(nb):
+            h = E[k].split(); etype, cnt = int(h[2]), int(h[3]); k += 1
+            if etype == 4:
+                tets += [[int(c) for c in ln.split()[1:5]] for ln in E[k:k + cnt]]
+            k += cnt
+    assert tets, "no 4-node tetrahedra (element type 4) in the file"
+    tags = np.asarray(tags, np.int64)
+    index_of = np.full(tags.max() + 1, -1, np.int64)
+    index_of[tags] = np.arange(len(tags))
+    T = index_of[np.asarray(tets, np.int64)]
+    assert (T >= 0).all(), "an element refers to a node the file does not define"
+    used = np.unique(T)                                 # drop nodes no tet uses (geometry points of the CAD model)
+    remap = np.full(len(tags), -1, np.int64); remap[used] = np.arange(len(used))
+    return from_tet_mesh(np.asarray(coords, np.float64)[used], remap[T], label=f"gmsh:{path}")

@@ -96,6 +96,48 @@ def test_tet_mesh_and_tetgen_reader(tmp_path, oracle_mod):
     assert abs(vol(o.x.astype(np.float64)) - 1.0) < 0.02
 
 
+def _write_msh(path, nodes, tets, version):
+    tags = [10 + 3 * i for i in range(len(nodes))]        # non-consecutive node tags
+    with open(path, "w") as f:
+        if version == 2:
+            f.write("$MeshFormat\n2.2 0 8\n$EndMeshFormat\n$Nodes\n%d\n" % (len(nodes) + 1))
+            f.write("5 9.0 9.0 9.0\n")                     # a geometry point no element uses
+            for t, p in zip(tags, nodes):
+                f.write("%d %r %r %r\n" % (t, float(p[0]), float(p[1]), float(p[2])))
+            f.write("$EndNodes\n$Elements\n%d\n1 15 2 0 1 5\n2 2 2 0 1 %d %d %d\n" % (len(tets) + 2, tags[0], tags[1], tags[2]))
+            for k, t in enumerate(tets):
+                f.write("%d 4 2 0 1 %d %d %d %d\n" % (k + 3, *[tags[v] for v in t]))
+            f.write("$EndElements\n")
+        else:
+            f.write("$MeshFormat\n4.1 0 8\n$EndMeshFormat\n$Nodes\n2 %d 5 %d\n" % (len(nodes) + 1, tags[-1]))
+            f.write("0 1 0 1\n5\n9.0 9.0 9.0\n")
+            f.write("3 1 0 %d\n" % len(nodes))
+            for t in tags:
+                f.write("%d\n" % t)
+            for p in nodes:
+                f.write("%r %r %r\n" % (float(p[0]), float(p[1]), float(p[2])))
+            f.write("$EndNodes\n$Elements\n2 %d 1 %d\n2 1 2 1\n1 %d %d %d\n3 1 4 %d\n" % (len(tets) + 1, len(tets) + 1, tags[0], tags[1], tags[2], len(tets)))
+            for k, t in enumerate(tets):
+                f.write("%d %d %d %d %d\n" % (k + 2, *[tags[v] for v in t]))
+            f.write("$EndElements\n")
+
+
+@pytest.mark.parametrize("version", [2, 4])
+def test_gmsh_reader_gives_the_mesh_from_tet_mesh_gives(tmp_path, version):
+    # ".node/.ele or .msh reader" -- both exist; the .msh reader (ASCII 2.2 and 4.1) must give exactly the
+    # authoring result of from_tet_mesh on the same nodes and tets: non-consecutive node tags, unused nodes and non-tet elements skipped
+    from softbodyunity_amd.mesh import read_gmsh
+    rng = np.random.default_rng(5)
+    nodes = np.array([[0, 0, 0], [1, 0, 0], [0, 1, 0], [0, 0, 1], [1, 1, 1], [2, 0.5, 0.5]], np.float64) + rng.uniform(-0.05, 0.05, (6, 3))
+    tets = np.array([[0, 1, 2, 3], [1, 2, 3, 4], [1, 4, 2, 5]])
+    path = tmp_path / f"m{version}.msh"
+    _write_msh(path, nodes, tets, version)
+    a, b = read_gmsh(str(path)), from_tet_mesh(nodes, tets)
+    for f in ("rest_pos", "inv_mass", "dist_ij", "dist_rest", "vol_ijkl", "vol_rest", "bend_ijkl", "bend_rest"):
+        assert np.array_equal(getattr(a, f), getattr(b, f)), f
+    assert a.n == 6 and len(a.vol_rest) == 3 and (a.vol_rest > 0).all()
+
+
 @pytest.mark.gpu
 def test_cloth_through_the_plugin(oracle_mod):
     from softbodyunity_amd import Softbody
