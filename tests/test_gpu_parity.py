@@ -340,6 +340,17 @@ def test_every_diagnostic_switch_still_matches_the_oracle(oracle_mod, bunny20k, 
     assert bit and np.array_equal(v.view(np.uint32), o.v.view(np.uint32)), (switch, rel, mabs)
 
 
+@pytest.mark.parametrize("mask", ["1", "2", "3"])
+def test_write_through_store_masks_match_the_oracle(oracle_mod, bunny20k, monkeypatch, mask):
+    # small launches store previous positions (bit 0) and positions (bit 1) through the L2; force each choice separately
+    monkeypatch.setenv("SB_STORE_THROUGH_MAX_TILES", "0")
+    monkeypatch.setenv("SB_STORE_THROUGH_LARGE", mask)
+    rel, mabs, bit, x, v, o, st = _run_pair(oracle_mod, jelly_cube(40), ticks=2, substeps=20, ground_plane=None)
+    assert bit and np.array_equal(v.view(np.uint32), o.v.view(np.uint32)), (rel, mabs)
+    rel, mabs, bit, x, v, o, st = _run_pair(oracle_mod, bunny20k, ticks=2, substeps=6, compliance=(1e-7, 1e-7, 1e-5))
+    assert bit and np.array_equal(v.view(np.uint32), o.v.view(np.uint32)), (rel, mabs)
+
+
 @pytest.mark.parametrize("lanes", ["128", "256"])
 def test_both_workgroup_widths_match_the_oracle(oracle_mod, bunny20k, monkeypatch, lanes):
     # small tiles run as 256-lane workgroups (one constraint per lane and round) or, in launches of >= 10240 tiles,
