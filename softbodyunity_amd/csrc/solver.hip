@@ -354,7 +354,7 @@ void build_device(sb_solver *s) {
         const int capacity = sbk::kSmallTile;         // packs stay small tiles; plan tiles above that size are left alone
         // only tiles with short programs share a workgroup (the rim of a lattice: 3-4 rounds): zipping long programs of
         // an irregular mesh (40+ rounds per tile) lengthens them, and such launches do not fill the chip anyway
-        constexpr int kPackMaxRounds = 8;
+        constexpr int kPackMaxRounds = 8;     // (16: -0.2 %, 32: +0.7 %, 64: +11 % on the 100 k surrogate, profiles/r02zq_pack_rounds.json)
         std::vector<std::vector<int32_t>> packs;      // members (indices into LT.tile_ids), in execution order
         {
             std::vector<int32_t> pack_of(n_plan_tiles, -1), cand;
@@ -662,7 +662,10 @@ void build_device(sb_solver *s) {
                     for (int32_t r = 0; r < td.n_rounds; ++r) {
                         const uint32_t w = stream[(size_t)td.s_begin + (size_t)r];
                         const int32_t nd = (int32_t)(w & 1023u), nv = (int32_t)((w >> 10) & 1023u), nb = (int32_t)((w >> 20) & 1023u);
-                        if (D.has_quads) c += std::max(1, (((nd + 63) >> 6) + ((nv + 15) >> 4) + ((nb + 15) >> 4) + 3) >> 2) + (nb > 0 ? 1 : 0);
+                        if (D.has_quads) {       // rows of wave slots (as dealt for the wave items), a step with a hinge counts double
+                            const int nw = std::max(1, (int)D.item_waves ? (int)D.item_waves : 4);
+                            c += std::max(1, (((nd + 63) >> 6) + ((nv + 15) >> 4) + ((nb + 3) >> 2) + nw - 1) / nw) + (nb > 0 ? 1 : 0);
+                        }
                         else c += std::max(1, (nd + sbk::kRoundSlots - 1) / sbk::kRoundSlots);
                     }
                     cost[(size_t)k] = c; idx[(size_t)k] = k;
