@@ -1,4 +1,4 @@
-// SoftbodyNative.cs — P/Invoke layer over libsoftbody_mi355x.so (include/softbody.h, ABI version 3).
+// SoftbodyNative.cs — P/Invoke layer over libsoftbody_mi355x.so (include/softbody.h, ABI version 6).
 //
 // One [DllImport] per exported function, same name and argument order as the header; the Python twin
 // used by the test-suite is softbodyunity_amd/native.py (tests/test_abi.py keeps the three in sync).
@@ -23,6 +23,12 @@ namespace SoftbodyMI355X
         public float damping;
         public int tileParticles;
         public int useGraph;
+        public int partition;        // SoftbodyNative.Partition*
+        public uint planFlags;       // SoftbodyNative.PlanNo*: every rank the same (checked across the ranks at sb_finalize)
+        public int haloTransport;    // SoftbodyNative.Transport*
+        public int haloSchedule;     // SoftbodyNative.Schedule*
+        public uint debugFlags;      // test-only, leave 0
+        public int reserved0, reserved1, reserved2;
     }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -37,6 +43,21 @@ namespace SoftbodyMI355X
         public long nT2Layers, nT2Tiles, t2Constraints;
         // compulsory HBM bytes of one launch: mid-tick on T0 / T1, first, last kernel of a tick, all T2 layers of a substep
         public long launchBytesMidT0, launchBytesMidT1, launchBytesFirst, launchBytesLast, launchBytesT2;
+        // partition (world > 1)
+        public int partition, haloPeers;
+        public long partitionCost, partitionCostMax, partitionCostTotal;
+        public long haloParticlesRecv;
+        public ulong planHash;
+        public int haloSchedule, reserved;
+    }
+
+    [StructLayout(LayoutKind.Sequential, CharSet = CharSet.Ansi)]
+    public struct SbRuntimeInfo
+    {
+        public int hipRuntimeVersion, hipDriverVersion, rcclVersion, rcclHeaderVersion;
+        public int rcclWasResident, captureSerialOk, captureOverlapOk, reserved;
+        [MarshalAs(UnmanagedType.ByValTStr, SizeConst = 256)] public string hipLibrary;
+        [MarshalAs(UnmanagedType.ByValTStr, SizeConst = 256)] public string rcclLibrary;
     }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -45,6 +66,8 @@ namespace SoftbodyMI355X
         public int rank, world;
         public int partDimX, partDimY, partDimZ;
         public int tileParticles;
+        public int partition;
+        public uint planFlags;
     }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -59,6 +82,10 @@ namespace SoftbodyMI355X
         const string Lib = "softbody_mi355x";
         const CallingConvention CC = CallingConvention.Cdecl;
         public const int UniqueIdBytes = 128;
+        public const int PartitionAuto = 0, PartitionBlocks = 1, PartitionRcb = 2;
+        public const uint PlanNoT2 = 1, PlanNoThirdList = 2, PlanNoClusterLayers = 4, PlanNoMixedGroups = 8, PlanNoBankOrder = 16;
+        public const int TransportRccl = 0, TransportPeer = 1;
+        public const int ScheduleAuto = 0, ScheduleSerialEager = 1, ScheduleSerialGraph = 2, ScheduleOverlapEager = 3, ScheduleOverlapGraph = 4;
 
         [DllImport(Lib, CallingConvention = CC)] public static extern void sb_desc_default(ref SbDesc d);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_create(ref SbDesc desc, out IntPtr solver);
@@ -91,7 +118,8 @@ namespace SoftbodyMI355X
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_debug_halo_pack(IntPtr s, int slot, IntPtr hostOut, long capacityFloats, out long countFloats);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_debug_halo_unpack(IntPtr s, int slot, IntPtr hostIn, long countFloats);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_get_stats(IntPtr s, out SbStats stats);
-        // opt-in peer-store halo transport (SB_HALO_TRANSPORT=peer): see softbody.h
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_runtime_info(out SbRuntimeInfo info);
+        // opt-in peer-store halo transport (SbDesc.haloTransport = TransportPeer): see softbody.h
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_peer_mailbox_handle(IntPtr s, byte[] handle64);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_peer_connect(IntPtr s, int rank, byte[] handle64, IntPtr sameProcessPeer);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_build(IntPtr restXyz, int n, IntPtr distIj, int mD, IntPtr volIjkl, int mV, IntPtr bendIjkl, int mB, ref SbPlanOpts opts, out IntPtr plan);

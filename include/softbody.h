@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SB_ABI_VERSION 5
+#define SB_ABI_VERSION 6
 
 typedef enum {
     SB_OK = 0,
@@ -46,18 +46,52 @@ typedef enum {
 typedef struct sb_solver sb_solver; /* opaque, plugin-owned */
 typedef struct sb_plan sb_plan;     /* opaque, plugin-owned */
 
-/* Mirrors the [SerializeField] block of csharp/Softbody.cs. Zero-initialise, then set fields. */
+/* Spatial partition of a world > 1 solver (which rank owns which particles). Ownership is always by whole T0 cells. */
+#define SB_PARTITION_AUTO   0   /* block grid when it balances the ranks within 10 % (regular meshes), else RCB */
+#define SB_PARTITION_BLOCKS 1   /* part_dims[0] x part_dims[1] x part_dims[2] blocks of cells (lattices: 2x2x2 for 8) */
+#define SB_PARTITION_RCB    2   /* recursive coordinate bisection over the occupied cells, weighted by constraint cost */
+
+/* Switches that CHANGE THE PLAN (the published order, the tiles, the ghost lists). Every rank of a partitioned solver must
+ * pass the same value: sb_finalize compares a hash of plan, options and halo lists across the ranks and fails with
+ * SB_ERR_STATE on a mismatch. 0 = the product's plan; the bits exist for A/B measurements. */
+#define SB_PLAN_NO_T2             1u   /* no third tiling: constraints inside neither T0 nor T1 go to global colours */
+#define SB_PLAN_NO_THIRD_LIST     2u   /* irregular meshes: the first T2 layer takes the leftovers only */
+#define SB_PLAN_NO_CLUSTER_LAYERS 4u   /* T2 layers from grids only */
+#define SB_PLAN_NO_MIXED_GROUPS   8u   /* one constraint type per group of a tile */
+#define SB_PLAN_NO_BANK_ORDER    16u   /* keep the colouring order inside a group (no LDS-bank-aware lane order) */
+
+/* Ghost exchange of a world > 1 solver. */
+#define SB_TRANSPORT_RCCL 0            /* pack -> grouped ncclSend/ncclRecv -> unpack (default) */
+#define SB_TRANSPORT_PEER 1            /* peer-store mailboxes (opt-in; see sb_peer_connect) */
+#define SB_SCHEDULE_AUTO               0   /* today: SB_SCHEDULE_SERIAL_EAGER (the only schedule that needs nothing of the bound
+                                              RCCL / HIP runtime beyond plain send/recv; see sb_runtime_info) */
+#define SB_SCHEDULE_SERIAL_EAGER       1
+#define SB_SCHEDULE_SERIAL_GRAPH       2   /* the tick, exchange included, captured in a hipGraph */
+#define SB_SCHEDULE_OVERLAP_EAGER      3   /* exchange on a second stream beside the interior tiles */
+#define SB_SCHEDULE_OVERLAP_GRAPH      4   /* refused (SB_ERR_UNSUPPORTED) on a HIP runtime it is known to fault on */
+
+/* Test-only behaviour; a product host leaves this 0. */
+#define SB_DEBUG_NO_COMM  1u           /* world > 1 without any transport: the host carries the halo through sb_debug_* */
+#define SB_DEBUG_LOOPBACK 2u           /* every peer is this rank itself (size-1 communicator): one-GPU pipeline tests */
+
+/* Mirrors the [SerializeField] block of csharp/Softbody.cs. Zero-initialise (or sb_desc_default), then set fields. */
 typedef struct {
     int32_t device;          /* HIP device ordinal for this rank (LOCAL_RANK in a multi-process job) */
     int32_t rank;            /* this process' part of the spatial partition, 0..world-1 */
     int32_t world;           /* number of partitions == number of GPUs (1,2,4,8); 0 is read as 1 */
-    int32_t part_dims[3];    /* blocks per axis, product == world; {0,0,0} = auto (2x2x2 for 8, ...) */
+    int32_t part_dims[3];    /* SB_PARTITION_BLOCKS: blocks per axis, product == world; {0,0,0} = auto (2x2x2 for 8, ...) */
     float   gravity[3];
     float   damping;
     int32_t tile_particles;  /* target particles per LDS tile; 0 = automatic (512; 256 when the mesh has volume or
                                 bending constraints); -1 = no tiling:
                                 every constraint goes through the global-colour kernels */
     int32_t use_graph;       /* 1 = replay the substep loop as a hipGraph (default 1 via sb_desc_default) */
+    int32_t partition;       /* SB_PARTITION_* */
+    uint32_t plan_flags;     /* SB_PLAN_* */
+    int32_t halo_transport;  /* SB_TRANSPORT_* */
+    int32_t halo_schedule;   /* SB_SCHEDULE_* */
+    uint32_t debug_flags;    /* SB_DEBUG_* */
+    int32_t reserved[3];     /* must be 0 */
 } sb_desc;
 
 void sb_desc_default(sb_desc *d);
@@ -88,14 +122,20 @@ int sb_finalize(sb_solver *s);
 int sb_comm_unique_id(uint8_t out_id[SB_UNIQUE_ID_BYTES]);
 int sb_comm_init(sb_solver *s, const uint8_t id[SB_UNIQUE_ID_BYTES]);
 
-/* Opt-in peer-store halo transport (environment SB_HALO_TRANSPORT=peer, read by sb_create): instead of pack -> ncclSend /
+/* Opt-in peer-store halo transport (sb_desc.halo_transport = SB_TRANSPORT_PEER): instead of pack -> ncclSend /
  * ncclRecv -> unpack, a rank stores its neighbours' ghosts straight into their mailboxes (one device allocation per rank,
  * mapped by IPC handle, or by plain pointer inside one process) and raises a flag there; the neighbour's unpack kernel
  * waits for the flags, copies and acknowledges. With an RCCL communicator present sb_finalize exchanges the handles by
  * itself (one ncclAllGather at setup). Without one the host connects the mailboxes after sb_finalize: every rank
  * exports its handle, every rank connects each neighbour's (ranks it shares no halo with may be skipped). A rank that
  * lives in the SAME process is connected by passing its solver (handle may then be NULL): hipIpcOpenMemHandle refuses
- * handles of the opening process. Unverified between two devices (1-GPU box); RCCL stays the default. */
+ * handles of the opening process. Unverified between two devices (1-GPU box); RCCL stays the default.
+ *  - Waits are bounded (about 2^24 polls, tens of seconds): a flag that never arrives sets an error word instead of hanging
+ *    the GPU; sb_step (before it enqueues), sb_readback_end, sb_synchronize and sb_get_* report it as SB_ERR_RCCL.
+ *  - One process driving SEVERAL ranks on ONE device must give every rank a hardware queue of its own (environment
+ *    GPU_MAX_HW_QUEUES >= ranks, set before the first HIP call): a waiting kernel blocks the streams that share its queue.
+ *  - sb_destroy of a peer-transport solver frees the mailbox its neighbours store into: every neighbour must be quiescent
+ *    first (sb_synchronize on every rank, then a host barrier, then sb_destroy). */
 #define SB_IPC_HANDLE_BYTES 64
 int sb_peer_mailbox_handle(sb_solver *s, uint8_t out_handle[SB_IPC_HANDLE_BYTES]);
 int sb_peer_connect(sb_solver *s, int32_t rank, const uint8_t handle[SB_IPC_HANDLE_BYTES], sb_solver *same_process_peer /* or NULL */);
@@ -178,6 +218,16 @@ typedef struct {
      * G = 0: 0 / 1 = mid-tick kernel on T0 / T1, 2 = first kernel of a tick, 3 = last kernel of a tick (on T0; on T1 it
      * moves launch_bytes[1] - (launch_bytes[0] - launch_bytes[3])), 4 = all T2 layers of one substep. */
     int64_t launch_bytes[5];
+    /* partition (world > 1): how the ownership was made and what it balanced */
+    int32_t partition;                              /* SB_PARTITION_BLOCKS or SB_PARTITION_RCB (what AUTO resolved to) */
+    int32_t halo_peers;                             /* ranks this rank exchanges ghosts with (any slot) */
+    int64_t partition_cost;                         /* cost units of the particles this rank owns (12 per particle + the vertex
+                                                       shares of their constraints: 12 / 24 / 48 per spring / tet / hinge) */
+    int64_t partition_cost_max, partition_cost_total;   /* over all ranks: max / mean = partition_cost_max * world / total */
+    int64_t halo_particles_recv;                    /* ghosts received per refresh, all slots */
+    uint64_t plan_hash;                             /* hash of the published orders, ownership and plan options: equal on every rank */
+    int32_t halo_schedule;                          /* SB_SCHEDULE_* in force (what AUTO resolved to) */
+    int32_t reserved;
 } sb_stats;
 int sb_get_stats(sb_solver *s, sb_stats *out);
 
@@ -187,7 +237,9 @@ int sb_get_stats(sb_solver *s, sb_stats *out);
 typedef struct {
     int32_t rank, world;
     int32_t part_dims[3];
-    int32_t tile_particles;
+    int32_t tile_particles;  /* as sb_desc.tile_particles (0 = automatic by the same rule); opts == NULL: all fields 0 */
+    int32_t partition;       /* SB_PARTITION_* */
+    uint32_t plan_flags;     /* SB_PLAN_* */
 } sb_plan_opts;
 typedef struct {
     int32_t kind;               /* 0 = global colour, 1 = a tiling's tiles, first phase of the substep, 2 = the other tiling's tiles,
@@ -234,6 +286,27 @@ int sb_plan_get_halo(const sb_plan *p, int32_t slot, int32_t peer, int32_t *send
 /* Which order entries this rank executes (1) or skips (0) — cut constraints run on every rank that owns
  * one of their particles. */
 int sb_plan_get_local_order_mask(const sb_plan *p, int32_t parity, uint8_t *mask_out);
+
+/* ---- what the plugin is running on -------------------------------------------------------------------- */
+/* The plugin links the HIP runtime and loads RCCL on first use (sb_comm_unique_id / sb_comm_init / this call) with dlopen: the
+ * librccl.so.1 ALREADY IN THE PROCESS when there is one (a host that imported PyTorch first brings PyTorch's own RCCL and HIP
+ * runtime; two ROCm stacks in one process is what must never happen), else the system's (the plugin's RUNPATH, /opt/rocm/lib).
+ * world == 1 hosts never load RCCL. The schedules a world > 1 solver admits depend on what was bound:
+ *   capture_overlap_ok = 0 on HIP runtimes older than 7.2: hipStreamEndCapture recurses without bound when a captured stream that
+ *   was itself forked (the exchange stream) is forked again by RCCL's internal stream (profiles/r03a_*). */
+typedef struct {
+    int32_t hip_runtime_version;       /* hipRuntimeGetVersion, e.g. 70226015 */
+    int32_t hip_driver_version;
+    int32_t rccl_version;              /* ncclGetVersion, e.g. 22707; 0 = RCCL could not be loaded */
+    int32_t rccl_header_version;       /* NCCL_VERSION_CODE of the rccl.h the plugin was compiled against */
+    int32_t rccl_was_resident;         /* 1 = the process had an RCCL loaded already (it was used), 0 = the plugin loaded the system's */
+    int32_t capture_serial_ok;         /* SB_SCHEDULE_SERIAL_GRAPH admitted */
+    int32_t capture_overlap_ok;        /* SB_SCHEDULE_OVERLAP_GRAPH admitted */
+    int32_t reserved;
+    char hip_library[256];             /* file the HIP runtime symbols resolve to */
+    char rccl_library[256];            /* file the RCCL symbols resolve to ("" = not loaded) */
+} sb_runtime_info_t;
+int sb_runtime_info(sb_runtime_info_t *out);
 
 const char *sb_last_error(void);
 int sb_abi_version(void);

@@ -349,6 +349,121 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
     });
     const int64_t n_cells = (int64_t)nc[0] * nc[1] * nc[2], n_scells = (int64_t)(nc[0] + 1) * (nc[1] + 1) * (nc[2] + 1);
     const int cap = tiling ? std::min(kMaxTileLocal, std::max(2 * target, 64)) : 512;
+    // ---- ownership (world > 1) -------------------------------------------------------------------
+    // A rank owns whole T0 cells, so T0 tiles are single-owner whatever the partition. Regular meshes: the block grid
+    // above (dims). A mesh that fills its bounding box unevenly (a tet mesh of a bunny: the corner blocks are nearly
+    // empty) is cut by recursive coordinate bisection over the occupied cells instead, each cell weighted by the cost
+    // of its particles (kCostParticle each + their vertex shares of the constraints).
+    P.partition = 1;
+    P.rank_cost.assign((size_t)opts.world, 0);
+    if (opts.world > 1) {
+        if (opts.partition < 0 || opts.partition > 2) throw std::runtime_error("partition must be 0 (automatic), 1 (blocks) or 2 (RCB)");
+        // cost of every rank under the ownership `own`: partial sums over fixed chunks (integers: any order gives the same)
+        auto rank_costs = [&](const std::vector<int32_t> &own, std::vector<int64_t> &out) {
+            out.assign((size_t)opts.world, 0);
+            std::mutex mu;
+            auto add = [&](const std::vector<int64_t> &part) { std::lock_guard<std::mutex> g(mu); for (int r = 0; r < opts.world; ++r) out[(size_t)r] += part[(size_t)r]; };
+            parallel_chunks(n, 1 << 20, [&](int64_t, int64_t pb, int64_t pe) {
+                std::vector<int64_t> part((size_t)opts.world, 0);
+                for (int64_t q = pb; q < pe; ++q) part[(size_t)own[(size_t)q]] += kCostParticle;
+                add(part);
+            });
+            for (int t = 0; t < 3; ++t)
+                parallel_chunks(C.count(t), 1 << 20, [&](int64_t, int64_t kb, int64_t ke) {
+                    std::vector<int64_t> part((size_t)opts.world, 0);
+                    for (int64_t k = kb; k < ke; ++k) {
+                        const int32_t *v = C.idx(t, k);
+                        for (int a = 0; a < kVerts[t]; ++a) part[(size_t)own[(size_t)v[a]]] += kCostVertexShare[t];
+                    }
+                    add(part);
+                });
+        };
+        rank_costs(P.owner_of_old, P.rank_cost);
+        bool rcb = opts.partition == 2;
+        if (opts.partition == 0 && !(opts.dims[0] > 0 && opts.dims[1] > 0 && opts.dims[2] > 0)) {
+            int64_t total = 0, worst = 0;
+            for (int64_t c : P.rank_cost) { total += c; worst = std::max(worst, c); }
+            rcb = worst * opts.world * 10 > total * 11;      // the block grid leaves a rank more than 10 % above the mean
+        }
+        if (rcb) {
+            // occupied cells and their weights
+            const bool dense = n_cells <= 8 * (int64_t)n + 4096;
+            std::vector<int64_t> occ;                   // occupied cell ids, ascending
+            std::vector<int32_t> dense_index;           // dense: cell id -> index into occ (-1: empty)
+            if (dense) {
+                dense_index.assign((size_t)n_cells, -1);
+                for (int32_t q = 0; q < n; ++q) dense_index[(size_t)cell[(size_t)q]] = 0;
+                for (int64_t c = 0; c < n_cells; ++c) if (dense_index[(size_t)c] == 0) { dense_index[(size_t)c] = (int32_t)occ.size(); occ.push_back(c); }
+            } else {
+                occ = cell;
+                std::sort(occ.begin(), occ.end());
+                occ.erase(std::unique(occ.begin(), occ.end()), occ.end());
+            }
+            auto index_of = [&](int64_t c) -> size_t {
+                return dense ? (size_t)dense_index[(size_t)c] : (size_t)(std::lower_bound(occ.begin(), occ.end(), c) - occ.begin());
+            };
+            std::vector<int64_t> wcell(occ.size(), 0);
+            for (int32_t q = 0; q < n; ++q) wcell[index_of(cell[(size_t)q])] += kCostParticle;
+            for (int t = 0; t < 3; ++t)
+                for (int64_t k = 0; k < C.count(t); ++k) {
+                    const int32_t *v = C.idx(t, k);
+                    for (int a = 0; a < kVerts[t]; ++a) wcell[index_of(cell[(size_t)v[a]])] += kCostVertexShare[t];
+                }
+            struct RcbCell { int32_t c[3]; int32_t idx; };
+            std::vector<RcbCell> cells(occ.size());
+            for (size_t k = 0; k < occ.size(); ++k) {
+                int64_t id = occ[k];
+                cells[k].c[0] = (int32_t)(id % nc[0]); id /= nc[0];
+                cells[k].c[1] = (int32_t)(id % nc[1]); cells[k].c[2] = (int32_t)(id / nc[1]);
+                cells[k].idx = (int32_t)k;
+            }
+            std::vector<int32_t> owner_of_cell(occ.size(), 0);
+            struct Job { size_t b, e; int r0, r1; };
+            std::vector<Job> jobs{{0, cells.size(), 0, opts.world}};
+            while (!jobs.empty()) {
+                const Job j = jobs.back();
+                jobs.pop_back();
+                if (j.r1 - j.r0 <= 1 || j.e <= j.b) {
+                    for (size_t k = j.b; k < j.e; ++k) owner_of_cell[(size_t)cells[k].idx] = j.r0;
+                    continue;
+                }
+                // cut across the longest axis of the subset (cells are cubes: count them), ties -> lowest axis; the cut
+                // is a plane with one staircase step: cells in lexicographic order of (axis, next axis, third axis)
+                int32_t lo3[3] = {INT32_MAX, INT32_MAX, INT32_MAX}, hi3[3] = {INT32_MIN, INT32_MIN, INT32_MIN};
+                for (size_t k = j.b; k < j.e; ++k)
+                    for (int a = 0; a < 3; ++a) { lo3[a] = std::min(lo3[a], cells[k].c[a]); hi3[a] = std::max(hi3[a], cells[k].c[a]); }
+                int ax = 0;
+                for (int a = 1; a < 3; ++a) if (hi3[a] - lo3[a] > hi3[ax] - lo3[ax]) ax = a;
+                const int a1 = (ax + 1) % 3, a2 = (ax + 2) % 3;
+                std::sort(cells.begin() + (std::ptrdiff_t)j.b, cells.begin() + (std::ptrdiff_t)j.e, [&](const RcbCell &x, const RcbCell &y) {
+                    if (x.c[ax] != y.c[ax]) return x.c[ax] < y.c[ax];
+                    if (x.c[a1] != y.c[a1]) return x.c[a1] < y.c[a1];
+                    return x.c[a2] < y.c[a2];
+                });
+                const int nl = (j.r1 - j.r0) / 2, nr = (j.r1 - j.r0) - nl;
+                int64_t total = 0;
+                for (size_t k = j.b; k < j.e; ++k) total += wcell[(size_t)cells[k].idx];
+                // the prefix closest to nl / (nl + nr) of the weight (first such position)
+                const size_t size = j.e - j.b;
+                size_t best = 0; int64_t best_err = INT64_MAX, prefix = 0;
+                for (size_t k = 0; k <= size; ++k) {
+                    const int64_t err = std::llabs(prefix * (int64_t)(nl + nr) - total * (int64_t)nl);
+                    if (err < best_err) { best_err = err; best = k; }
+                    if (k < size) prefix += wcell[(size_t)cells[j.b + k].idx];
+                }
+                // no side goes without a cell while there are enough cells
+                const size_t k_lo = std::min<size_t>((size_t)nl, size), k_hi = std::max(k_lo, size - std::min<size_t>((size_t)nr, size - k_lo));
+                best = std::min(std::max(best, k_lo), k_hi);
+                jobs.push_back({j.b + best, j.e, j.r0 + nl, j.r1});
+                jobs.push_back({j.b, j.b + best, j.r0, j.r0 + nl});
+            }
+            parallel_chunks(n, 1 << 18, [&](int64_t, int64_t pb, int64_t pe) {
+                for (int64_t q = pb; q < pe; ++q) P.owner_of_old[(size_t)q] = owner_of_cell[index_of(cell[(size_t)q])];
+            });
+            rank_costs(P.owner_of_old, P.rank_cost);
+            P.partition = 2;
+        }
+    }
 
     timer.lap("geometry + cells");
     // ---- tiling T1 (shifted cells), computed first so that T0 can order its particles by T1 tile ----

@@ -32,6 +32,8 @@ struct Opts {
     int rank = 0, world = 1;
     int dims[3] = {0, 0, 0};
     int tile_particles = 512;  // -1: no tiling
+    int partition = 0;         // world > 1: 0 = automatic (block grid when that balances the ranks within 10 %, else RCB), 1 = block grid
+                               // (dims), 2 = recursive coordinate bisection over whole T0 cells weighted by constraint cost
     bool third_tiling = true;       // constraints inside neither T0 nor T1 get LDS tiles of their own (T2) where they can (SB_NO_T2: A/B runs)
     bool third_list = true;         // irregular meshes: the first T2 layer takes a balanced share of the constraints, not only the leftovers (SB_NO_THIRD_LIST: A/B runs)
     bool cluster_layers = true;     // once few constraints are left, T2 layers are made of connected components instead of grid cells (SB_NO_CLUSTER_LAYERS: A/B runs)
@@ -48,6 +50,9 @@ constexpr int kRoundThreads = 256;          // constraints of one type per group
 constexpr int kMaxTileLocal = 1024;         // particles staged per tile (4 per lane)
 constexpr int kMaxTileRuns = 64;
 constexpr int kMaxT2Layers = 6;             // shifted grids tried in turn for the constraints inside neither T0 nor T1
+// partition cost units: a particle 12; a constraint 12 / 24 / 48 (distance / volume / bending), split evenly over its vertices
+constexpr int64_t kCostParticle = 12;
+constexpr int64_t kCostVertexShare[3] = {6, 6, 12};
 constexpr int kLdsGroup = 8;                // lanes whose 16-byte LDS accesses are served together (measured: 8 beats 16, 32, 64)
 
 struct Tile {
@@ -101,6 +106,9 @@ struct Plan {
     int32_t n = 0;
     int64_t m[3] = {0, 0, 0};
     int dims[3] = {1, 1, 1};
+    int partition = 1;          // what the ownership was made with: 1 = block grid (dims), 2 = RCB over T0 cells
+    std::vector<int64_t> rank_cost;     // [world] cost units of the particles a rank owns (kCostParticle per particle + the vertex
+                                        // shares of their constraints): what the partitioner balances
     bool tiling = true;
     // particle numbering
     std::vector<int32_t> new_of_old, old_of_new, owner_of_old;

@@ -5,7 +5,8 @@
 // memory, the substep loop (hipGraph replay), the RCCL ghost exchange and the plan inspection API.
 // There is deliberately no CPU execution path: without a gfx950 device sb_create fails.
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>      // types and prototypes only: the library itself is bound at run time (RcclApi below)
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <atomic>
@@ -17,6 +18,8 @@
 #include <cstring>
 #include <map>
 #include <memory>
+#include <mutex>
+#include <type_traits>
 #include <stdexcept>
 #include <string>
 #include <utility>
@@ -41,12 +44,67 @@ struct HipError : std::runtime_error {
         if (e_ != hipSuccess)                                                                             \
             throw HipError(SB_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_));                \
     } while (0)
+// RCCL is NOT a link-time dependency. A world == 1 host never loads it (the library is 570 MB); a world > 1 host binds, on
+// first use, the librccl.so.1 that is ALREADY in the process when there is one -- a host that imported PyTorch first brought
+// PyTorch's own RCCL together with PyTorch's own HIP runtime, which this plugin's libamdhip64.so.7 dependency resolved to as
+// well, and a second ROCm stack in one process is the one thing that must not happen -- and the system's otherwise (the
+// plugin's RUNPATH: /opt/rocm/lib). What was bound is reported by sb_runtime_info and decides which schedules are admitted.
+struct RcclApi {
+    void *handle = nullptr;
+    bool was_resident = false;
+    int version = 0;
+    std::string path, error;
+    decltype(&ncclGetVersion) GetVersion = nullptr;
+    decltype(&ncclGetUniqueId) GetUniqueId = nullptr;
+    decltype(&ncclCommInitRank) CommInitRank = nullptr;
+    decltype(&ncclCommDestroy) CommDestroy = nullptr;
+    decltype(&ncclGetErrorString) GetErrorString = nullptr;
+    decltype(&ncclGroupStart) GroupStart = nullptr;
+    decltype(&ncclGroupEnd) GroupEnd = nullptr;
+    decltype(&ncclSend) Send = nullptr;
+    decltype(&ncclRecv) Recv = nullptr;
+    decltype(&ncclAllGather) AllGather = nullptr;
+    bool ok() const { return handle != nullptr; }
+};
+RcclApi &rccl(bool required = true) {
+    static RcclApi api;
+    static std::once_flag once;
+    std::call_once(once, [] {
+        const char *names[] = {"librccl.so.1", "librccl.so"};
+        for (const char *nm : names) if (!api.handle) { api.handle = dlopen(nm, RTLD_NOW | RTLD_NOLOAD); api.was_resident = api.handle != nullptr; }
+        for (const char *nm : names) if (!api.handle) api.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
+        if (!api.handle) { const char *e = dlerror(); api.error = std::string("RCCL could not be loaded: ") + (e ? e : "librccl.so.1 not found"); return; }
+        bool all = true;
+        auto sym = [&](auto &fn, const char *name) { fn = reinterpret_cast<std::remove_reference_t<decltype(fn)>>(dlsym(api.handle, name)); all &= fn != nullptr; };
+        sym(api.GetVersion, "ncclGetVersion"); sym(api.GetUniqueId, "ncclGetUniqueId"); sym(api.CommInitRank, "ncclCommInitRank");
+        sym(api.CommDestroy, "ncclCommDestroy"); sym(api.GetErrorString, "ncclGetErrorString"); sym(api.GroupStart, "ncclGroupStart");
+        sym(api.GroupEnd, "ncclGroupEnd"); sym(api.Send, "ncclSend"); sym(api.Recv, "ncclRecv"); sym(api.AllGather, "ncclAllGather");
+        if (!all) { api.error = "RCCL library lacks a symbol the plugin needs"; api.handle = nullptr; return; }
+        Dl_info di;
+        if (dladdr(reinterpret_cast<void *>(api.Send), &di) && di.dli_fname) api.path = di.dli_fname;
+        if (api.GetVersion(&api.version) != ncclSuccess) api.version = 0;
+        // the plugin uses only calls whose signatures have not changed since NCCL 2.7 (send/recv); refuse anything older
+        if (api.version < 20700) { api.error = "RCCL " + std::to_string(api.version) + " is older than 2.7 (no ncclSend/ncclRecv)"; api.handle = nullptr; }
+    });
+    if (required && !api.ok()) throw HipError(SB_ERR_UNSUPPORTED, api.error);
+    return api;
+}
 #define NCCL_CHECK(expr)                                                                                  \
     do {                                                                                                  \
         ncclResult_t r_ = (expr);                                                                         \
         if (r_ != ncclSuccess)                                                                            \
-            throw HipError(SB_ERR_RCCL, std::string(#expr) + ": " + ncclGetErrorString(r_));              \
+            throw HipError(SB_ERR_RCCL, std::string(#expr) + ": " + rccl().GetErrorString(r_));          \
     } while (0)
+
+// HIP runtimes older than 7.2 recurse without bound in hipStreamEndCapture when a captured stream that was itself forked
+// from the origin (the exchange stream of the overlapped schedule) is forked again (RCCL's internal stream joins the capture
+// from the stream it is called on): the list of parallel capture streams becomes cyclic. Found with a native backtrace on
+// PyTorch's bundled HIP 7.0.51831 (profiles/r03a_overlap_capture_backtrace.txt); the same process on HIP 7.2.26015 is fine.
+int hip_runtime_version() {
+    static const int v = [] { int x = 0; return hipRuntimeGetVersion(&x) == hipSuccess ? x : 0; }();
+    return v;
+}
+bool capture_overlap_ok() { return hip_runtime_version() >= 70200000; }
 
 template <class T>
 struct DevBuf {
@@ -113,7 +171,9 @@ struct sb_solver {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     ncclComm_t comm = nullptr;
-    bool loopback = false;           // SB_TEST_LOOPBACK: every peer is this rank itself (1-GPU pipeline test)
+    bool loopback = false;           // SB_DEBUG_LOOPBACK: every peer is this rank itself (1-GPU pipeline test)
+    int schedule = SB_SCHEDULE_SERIAL_EAGER;   // world > 1: what desc.halo_schedule resolved to (sb_finalize)
+    uint64_t plan_hash = 0;          // hash of the published orders, ownership and plan options (equal on every rank)
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_boundary = nullptr, ev_halo = nullptr;
     bool overlap_halo = false;       // T0 boundary tiles first, ghost exchange on comm_stream beside the interior
@@ -165,12 +225,12 @@ struct sb_solver {
     int narrow_min_tiles = 10240;    // SB_NARROW_MIN_TILES; measured crossover: 160^3 (8000 tiles) ties, 192^3 (13824) +4 % narrow
     size_t lds_pad = 0;              // SB_LDS_PAD bytes of unused LDS per workgroup (occupancy experiments)
     bool pack_tiles = true;          // SB_NO_PACK unset: under-full tiles share a workgroup (build_device)
-    bool graph_rccl = false;         // SB_GRAPH_RCCL set: capture the RCCL calls of a multi-rank tick in the hipGraph
+    bool graph_rccl = false;         // a multi-rank tick, exchange included, is captured in the hipGraph (SB_SCHEDULE_*_GRAPH)
     std::vector<float> h_stage;
     // peer-store halo transport (SB_HALO_TRANSPORT=peer; kernels.hip.hpp): one mailbox per rank = [header words | ghost segments]
     struct PeerState {
         bool enabled = false, linked = false, fine_grained = false;
-        uint32_t *mailbox = nullptr;            // header: word 0 = error; per slot: data flags[world], ack flags[world], epoch, 2 counters; then the offset table
+        uint32_t *mailbox = nullptr;            // header: words 0-1 = the rank's plan hash; per slot: data flags[world], ack flags[world], epoch, 2 counters; then the offset table
         size_t bytes = 0, data_off_words = 0, off_table = 0;
         int n_slots = 0;
         std::vector<uint32_t *> remote;         // [world]: the ranks' mailboxes as this process sees them (own pointer for itself)
@@ -178,7 +238,8 @@ struct sb_solver {
         std::vector<std::vector<uint32_t>> my_off;   // [slot][rank]: first word (from the mailbox start) of rank's segment in MY mailbox
         std::vector<sbk::PeerSlot> slots;
         uint32_t *local = nullptr;              // 8 ordinary (cached) words per slot: epoch, workgroup counters, go words
-        size_t slot_base(int slot, int world) const { return 1 + (size_t)slot * (2 * (size_t)world + 3); }
+        uint32_t *h_error = nullptr;            // pinned host word the kernels set when a wait gives up: the host reads it without a copy
+        size_t slot_base(int slot, int world) const { return 2 + (size_t)slot * (2 * (size_t)world + 3); }
     } peer;
     // asynchronous render readback (sb_readback_begin / sb_readback_end): two snapshot slots
     hipStream_t copy_stream = nullptr;
@@ -206,11 +267,19 @@ struct sb_solver {
     int snap_last_ended = -1;
 
     ~sb_solver() {
+        // Teardown order: everything the device may still be running for this solver first (compute, exchange and copy
+        // streams), then the graph executables (captured RCCL launches hold references into the communicator), then the
+        // communicator, then the streams and events.
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (comm_stream) (void)hipStreamSynchronize(comm_stream);
+        if (copy_stream) (void)hipStreamSynchronize(copy_stream);
         for (auto &g : graphs) (void)hipGraphExecDestroy(g.second.exec);
-        if (comm) (void)ncclCommDestroy(comm);
+        graphs.clear();
+        if (comm) (void)rccl(false).CommDestroy(comm);
         for (size_t r = 0; r < peer.remote.size(); ++r) if (peer.opened[r] && peer.remote[r]) (void)hipIpcCloseMemHandle(peer.remote[r]);
         if (peer.mailbox) (void)hipFree(peer.mailbox);
         if (peer.local) (void)hipFree(peer.local);
+        if (peer.h_error) (void)hipHostFree(peer.h_error);
         if (ev_boundary) (void)hipEventDestroy(ev_boundary);
         if (ev_halo) (void)hipEventDestroy(ev_halo);
         if (comm_stream) (void)hipStreamDestroy(comm_stream);
@@ -236,6 +305,55 @@ sbp::Input make_input(const float *rest, int32_t n, const int32_t *d, int64_t md
     sbp::Input in;
     in.rest = rest; in.n = n; in.dist_ij = d; in.m_d = md; in.vol = v; in.m_v = mv; in.bend = b; in.m_b = mb;
     return in;
+}
+
+// The planner options behind the ABI's fields: ONE rule for sb_finalize and sb_plan_build, so the CPU schedule a host builds
+// with sb_plan_build is the one the GPU solver of the same mesh runs.
+sbp::Opts plan_opts(int rank, int world, const int32_t dims[3], int32_t tile_particles, int32_t partition, uint32_t plan_flags,
+                    int64_t m_v, int64_t m_b) {
+    sbp::Opts o;
+    o.rank = rank; o.world = world <= 0 ? 1 : world;
+    for (int a = 0; a < 3; ++a) o.dims[a] = dims ? dims[a] : 0;
+    // automatic tile size: 512 particles for spring meshes (bandwidth-bound: the fewest rim tiles that still fill the chip),
+    // 256 when tets or hinges are present (latency-bound: shorter programs per tile, more tiles in flight)
+    o.tile_particles = tile_particles != 0 ? tile_particles : (m_v + m_b > 0 ? 256 : 512);
+    o.partition = partition;
+    o.third_tiling = !(plan_flags & SB_PLAN_NO_T2);
+    o.third_list = !(plan_flags & SB_PLAN_NO_THIRD_LIST);
+    o.cluster_layers = !(plan_flags & SB_PLAN_NO_CLUSTER_LAYERS);
+    o.mixed_groups = !(plan_flags & SB_PLAN_NO_MIXED_GROUPS);
+    o.bank_aware_lanes = !(plan_flags & SB_PLAN_NO_BANK_ORDER);
+    return o;
+}
+constexpr uint32_t kPlanFlagsAll = SB_PLAN_NO_T2 | SB_PLAN_NO_THIRD_LIST | SB_PLAN_NO_CLUSTER_LAYERS | SB_PLAN_NO_MIXED_GROUPS | SB_PLAN_NO_BANK_ORDER;
+
+// 64-bit FNV-1a over everything the ranks of a partitioned solver must agree on: the published orders, who owns which
+// particle, the phase list with its halo slots, and the options that shaped them. (The halo lists are functions of these.)
+uint64_t hash_plan(const sbp::Plan &P) {
+    uint64_t h = 1469598103934665603ull;
+    auto mix = [&](const void *p, size_t bytes) {
+        const uint8_t *b = static_cast<const uint8_t *>(p);
+        // 8 bytes at a time (the arrays are tens of MB at 256^3), tail bytewise
+        size_t k = 0;
+        for (; k + 8 <= bytes; k += 8) { uint64_t w; std::memcpy(&w, b + k, 8); h = (h ^ w) * 1099511628211ull; }
+        for (; k < bytes; ++k) h = (h ^ b[k]) * 1099511628211ull;
+    };
+    const int32_t head[8] = {P.n, P.opts.world, P.opts.tile_particles, P.partition,
+                             (int32_t)((P.opts.third_tiling ? 0 : 1) | (P.opts.third_list ? 0 : 2) | (P.opts.cluster_layers ? 0 : 4) |
+                                       (P.opts.mixed_groups ? 0 : 8) | (P.opts.bank_aware_lanes ? 0 : 16)),
+                             P.dims[0], P.dims[1], P.dims[2]};
+    mix(head, sizeof(head));
+    mix(P.m, sizeof(P.m));
+    for (int p = 0; p < 2; ++p) {
+        mix(P.order_type[p].data(), P.order_type[p].size());
+        mix(P.order_id[p].data(), P.order_id[p].size() * sizeof(int32_t));
+        for (const sbp::Phase &ph : P.phases[p]) {
+            const int64_t rec[6] = {ph.kind, ph.tiling, ph.halo_slot, ph.layer, ph.order_begin, ph.order_end};
+            mix(rec, sizeof(rec));
+        }
+    }
+    mix(P.owner_of_old.data(), P.owner_of_old.size() * sizeof(int32_t));
+    return h;
 }
 
 // SPEC.md §2 host-side scalars (same operation order as oracle.c orc_scalars_for).
@@ -648,7 +766,9 @@ void build_device(sb_solver *s) {
             const int32_t n = (int32_t)tiles.size();
             std::vector<std::pair<int32_t, int32_t>> ranges;
             if (tl == 2) ranges = s->t2_layer_range;
-            else if (D.n_boundary > 0 && D.n_boundary < n) {
+            else if (s->overlap_halo && D.n_boundary > 0 && D.n_boundary < n) {
+                // (only the overlapped schedule launches the boundary and the interior tiles separately; a launch of the whole
+                // tiling remaps with its own workgroup count, so the placement must be made for that launch)
                 const int32_t cut = tl == 0 ? D.n_boundary : n - D.n_boundary;
                 ranges = {{0, cut}, {cut, n}};
             } else ranges = {{0, n}};
@@ -751,6 +871,7 @@ void build_device(sb_solver *s) {
         const size_t hdr_words = PS.off_table + (size_t)PS.n_slots * W;
         PS.data_off_words = (hdr_words + 63) & ~(size_t)63;
         std::vector<uint32_t> header(PS.data_off_words, 0u);
+        header[0] = (uint32_t)s->plan_hash; header[1] = (uint32_t)(s->plan_hash >> 32);      // compared by the neighbours (peer_link)
         PS.my_off.assign((size_t)PS.n_slots, std::vector<uint32_t>((size_t)W, 0u));
         size_t words = PS.data_off_words;
         for (int slot = 0; slot < PS.n_slots; ++slot) {
@@ -775,6 +896,8 @@ void build_device(sb_solver *s) {
         HIP_CHECK(hipMemcpy(PS.mailbox, header.data(), header.size() * 4, hipMemcpyHostToDevice));
         HIP_CHECK(hipMalloc((void **)&PS.local, (size_t)PS.n_slots * 8 * sizeof(uint32_t)));
         HIP_CHECK(hipMemset(PS.local, 0, (size_t)PS.n_slots * 8 * sizeof(uint32_t)));
+        HIP_CHECK(hipHostMalloc((void **)&PS.h_error, sizeof(uint32_t), hipHostMallocMapped));
+        *PS.h_error = 0;
         PS.remote.assign((size_t)W, nullptr);
         PS.opened.assign((size_t)W, 0);
         PS.remote[(size_t)L.rank] = PS.mailbox;
@@ -792,13 +915,24 @@ void peer_link(sb_solver *s) {
         const size_t base = PS.slot_base(slot, W);
         const size_t fl = slot == 1 ? 6 : 3;
         P.local = PS.local + (size_t)slot * 8;
-        P.error = PS.mailbox;
+        P.error = PS.h_error;         // (pinned host memory is device-accessible at the same address)
         for (size_t k = 0; k < D.peers.size(); ++k) {
             const int r = s->loopback ? me : D.peers[k];
             int cs = D.send_off[k + 1] - D.send_off[k], cr = D.recv_off[k + 1] - D.recv_off[k];
             if (s->loopback && (cs == 0 || cr == 0)) cs = cr = 0;       // a self-exchange needs both directions
             uint32_t *rm = PS.remote[(size_t)r];
             if ((cs || cr) && !rm) throw HipError(SB_ERR_STATE, "peer transport: the mailbox of rank " + std::to_string(r) + " is not connected (sb_peer_connect)");
+            if ((cs || cr) && !s->loopback) {       // ranks plan independently: the neighbour must have arrived at the same plan
+                uint32_t hw[2] = {0, 0};
+                HIP_CHECK(hipMemcpy(hw, rm, sizeof(hw), hipMemcpyDeviceToHost));
+                const uint64_t theirs = (uint64_t)hw[0] | ((uint64_t)hw[1] << 32);
+                if (theirs != s->plan_hash) {
+                    char msg[256];
+                    std::snprintf(msg, sizeof msg, "peer transport: rank %d planned a different schedule than rank %d (plan hash %016llx vs %016llx): every rank "
+                                  "must pass the same mesh, tile_particles, partition and plan_flags", r, me, (unsigned long long)theirs, (unsigned long long)s->plan_hash);
+                    throw HipError(SB_ERR_STATE, msg);
+                }
+            }
             if (cs) {
                 if (P.n_send >= sbk::kMaxPeers) throw std::runtime_error("peer transport: too many neighbours");
                 // where my segment starts inside the peer's mailbox: the peer's own offset table says
@@ -866,20 +1000,20 @@ void halo_exchange(sb_solver *s, int slot, hipStream_t st = nullptr) {
             hipLaunchKernelGGL(sbk::halo_pack_kernel<false>, dim3((ns + 255) / 256), dim3(256), 0, st, s->pos_view(),
                                s->d_prev.p, D.send_idx.p, s->d_sendbuf.p, ns);
     }
-    NCCL_CHECK(ncclGroupStart());
+    NCCL_CHECK(rccl().GroupStart());
     try {
         for (size_t k = 0; k < D.peers.size(); ++k) {
             int cs = D.send_off[k + 1] - D.send_off[k], cr = D.recv_off[k + 1] - D.recv_off[k];
             if (s->loopback) cs = cr = std::min(cs, cr);   // a self-exchange must post equal sizes (real peers always do)
             const size_t fl = with_prev ? 6 : 3;   // floats per ghost; one message per peer and direction
-            if (cs) NCCL_CHECK(ncclSend(s->d_sendbuf.p + fl * D.send_off[k], fl * (size_t)cs, ncclFloat, s->loopback ? 0 : D.peers[k], s->comm, st));
-            if (cr) NCCL_CHECK(ncclRecv(s->d_recvbuf.p + fl * D.recv_off[k], fl * (size_t)cr, ncclFloat, s->loopback ? 0 : D.peers[k], s->comm, st));
+            if (cs) NCCL_CHECK(rccl().Send(s->d_sendbuf.p + fl * D.send_off[k], fl * (size_t)cs, ncclFloat, s->loopback ? 0 : D.peers[k], s->comm, st));
+            if (cr) NCCL_CHECK(rccl().Recv(s->d_recvbuf.p + fl * D.recv_off[k], fl * (size_t)cr, ncclFloat, s->loopback ? 0 : D.peers[k], s->comm, st));
         }
     } catch (...) {
-        (void)ncclGroupEnd();      // never leave the group open behind an error
+        (void)rccl().GroupEnd();      // never leave the group open behind an error
         throw;
     }
-    NCCL_CHECK(ncclGroupEnd());
+    NCCL_CHECK(rccl().GroupEnd());
     if (nr) {
         if (with_prev)
             hipLaunchKernelGGL(sbk::halo_unpack_kernel<true>, dim3((nr + 255) / 256), dim3(256), 0, st, s->pos_view(),
@@ -1048,10 +1182,8 @@ void upload_tick_params(sb_solver *s, float dt, int substeps) {
 
 // Peer transport: a wait that gave up (a neighbour never delivered / never acknowledged) must not pass silently.
 void check_peer_error(sb_solver *s) {
-    if (!s->peer.enabled || !s->peer.mailbox) return;
-    uint32_t flag = 0;
-    HIP_CHECK(hipMemcpyAsync(&flag, s->peer.mailbox, sizeof(flag), hipMemcpyDeviceToHost, s->stream));
-    HIP_CHECK(hipStreamSynchronize(s->stream));
+    if (!s->peer.enabled || !s->peer.h_error) return;
+    const uint32_t flag = *reinterpret_cast<volatile uint32_t *>(s->peer.h_error);     // a host load: cheap enough for every sb_step
     if (flag) throw HipError(SB_ERR_RCCL, "peer transport: a halo wait gave up (a neighbour never delivered or never acknowledged)");
 }
 
@@ -1081,6 +1213,28 @@ extern "C" {
 const char *sb_last_error(void) { return g_err.c_str(); }
 int sb_abi_version(void) { return SB_ABI_VERSION; }
 
+int sb_runtime_info(sb_runtime_info_t *out) {
+    if (!out) return fail(SB_ERR_INVALID_ARG, "sb_runtime_info: null argument");
+    std::memset(out, 0, sizeof(*out));
+    return guarded([&]() -> int {
+        out->hip_runtime_version = hip_runtime_version();
+        int drv = 0;
+        if (hipDriverGetVersion(&drv) == hipSuccess) out->hip_driver_version = drv;
+        Dl_info di;
+        if (dladdr(reinterpret_cast<void *>(&hipRuntimeGetVersion), &di) && di.dli_fname) std::snprintf(out->hip_library, sizeof out->hip_library, "%s", di.dli_fname);
+        out->rccl_header_version = NCCL_VERSION_CODE;
+        RcclApi &R = rccl(false);
+        if (R.ok()) {
+            out->rccl_version = R.version;
+            out->rccl_was_resident = R.was_resident ? 1 : 0;
+            std::snprintf(out->rccl_library, sizeof out->rccl_library, "%s", R.path.c_str());
+            out->capture_serial_ok = R.version >= 22606 ? 1 : 0;
+            out->capture_overlap_ok = (R.version >= 22606 && capture_overlap_ok()) ? 1 : 0;
+        }
+        return SB_OK;
+    });
+}
+
 void sb_desc_default(sb_desc *d) {
     if (!d) return;
     std::memset(d, 0, sizeof(*d));
@@ -1099,6 +1253,12 @@ int sb_create(const sb_desc *desc, sb_solver **out) {
         if (d.rank < 0 || d.rank >= d.world) return fail(SB_ERR_INVALID_ARG, "sb_create: rank out of range");
         if (!(d.damping >= 0.0f)) return fail(SB_ERR_INVALID_ARG, "sb_create: damping must be >= 0");
         if (d.tile_particles > sbp::kMaxTileLocal) return fail(SB_ERR_INVALID_ARG, "sb_create: tile_particles too large");
+        if (d.partition < SB_PARTITION_AUTO || d.partition > SB_PARTITION_RCB) return fail(SB_ERR_INVALID_ARG, "sb_create: partition must be SB_PARTITION_AUTO, _BLOCKS or _RCB");
+        if (d.plan_flags & ~kPlanFlagsAll) return fail(SB_ERR_INVALID_ARG, "sb_create: unknown bit in plan_flags");
+        if (d.halo_transport != SB_TRANSPORT_RCCL && d.halo_transport != SB_TRANSPORT_PEER) return fail(SB_ERR_INVALID_ARG, "sb_create: halo_transport must be SB_TRANSPORT_RCCL or _PEER");
+        if (d.halo_schedule < SB_SCHEDULE_AUTO || d.halo_schedule > SB_SCHEDULE_OVERLAP_GRAPH) return fail(SB_ERR_INVALID_ARG, "sb_create: halo_schedule must be one of SB_SCHEDULE_*");
+        if (d.debug_flags & ~(SB_DEBUG_NO_COMM | SB_DEBUG_LOOPBACK)) return fail(SB_ERR_INVALID_ARG, "sb_create: unknown bit in debug_flags");
+        if (d.reserved[0] || d.reserved[1] || d.reserved[2]) return fail(SB_ERR_INVALID_ARG, "sb_create: reserved fields must be 0 (zero-initialise sb_desc or call sb_desc_default)");
         int ndev = 0;
         hipError_t e = hipGetDeviceCount(&ndev);
         if (e != hipSuccess || ndev <= 0)
@@ -1112,8 +1272,8 @@ int sb_create(const sb_desc *desc, sb_solver **out) {
         auto s = std::make_unique<sb_solver>();
         s->desc = d;
         s->lazy_tick = !std::getenv("SB_NO_LAZY_TICK");
-        s->graph_rccl = std::getenv("SB_GRAPH_RCCL") != nullptr;
-        if (const char *e = std::getenv("SB_HALO_TRANSPORT")) s->peer.enabled = std::strcmp(e, "peer") == 0;
+        s->peer.enabled = d.world > 1 && d.halo_transport == SB_TRANSPORT_PEER;
+        s->loopback = d.world > 1 && (d.debug_flags & SB_DEBUG_LOOPBACK) != 0;
         s->pack_tiles = !std::getenv("SB_NO_PACK");
         if (const char *e = std::getenv("SB_LDS_PAD")) s->lds_pad = (size_t)std::max(0, std::atoi(e));
         if (const char *e = std::getenv("SB_TILE_LANES")) s->tile_lanes = std::atoi(e) == 128 ? 128 : (std::atoi(e) == 256 ? 256 : 0);
@@ -1132,8 +1292,7 @@ int sb_create(const sb_desc *desc, sb_solver **out) {
 int sb_destroy(sb_solver *s) {
     if (!s) return fail(SB_ERR_INVALID_ARG, "sb_destroy: null handle");
     (void)hipSetDevice(s->desc.device);
-    if (s->stream) (void)hipStreamSynchronize(s->stream);
-    delete s;
+    delete s;          // (the destructor drains the solver's streams first)
     return SB_OK;
 }
 
@@ -1201,7 +1360,7 @@ int sb_comm_unique_id(uint8_t out_id[SB_UNIQUE_ID_BYTES]) {
     static_assert(sizeof(ncclUniqueId) <= SB_UNIQUE_ID_BYTES, "unique id size");
     return guarded([&]() -> int {
         ncclUniqueId id;
-        NCCL_CHECK(ncclGetUniqueId(&id));
+        NCCL_CHECK(rccl().GetUniqueId(&id));
         std::memset(out_id, 0, SB_UNIQUE_ID_BYTES);
         std::memcpy(out_id, &id, sizeof(id));
         return SB_OK;
@@ -1216,12 +1375,11 @@ int sb_comm_init(sb_solver *s, const uint8_t id_bytes[SB_UNIQUE_ID_BYTES]) {
         int rc = set_device(s); if (rc) return rc;
         ncclUniqueId id;
         std::memcpy(&id, id_bytes, sizeof(id));
-        if (std::getenv("SB_TEST_LOOPBACK")) {
-            // pipeline test on one GPU: a communicator of size 1, every peer replaced by this rank itself
-            s->loopback = true;
-            NCCL_CHECK(ncclCommInitRank(&s->comm, 1, id, 0));
+        if (s->loopback) {
+            // pipeline test on one GPU (SB_DEBUG_LOOPBACK): a communicator of size 1, every peer replaced by this rank itself
+            NCCL_CHECK(rccl().CommInitRank(&s->comm, 1, id, 0));
         } else {
-            NCCL_CHECK(ncclCommInitRank(&s->comm, s->desc.world, id, s->desc.rank));
+            NCCL_CHECK(rccl().CommInitRank(&s->comm, s->desc.world, id, s->desc.rank));
         }
         return SB_OK;
     });
@@ -1267,31 +1425,50 @@ int sb_finalize(sb_solver *s) {
     if (!s) return fail(SB_ERR_INVALID_ARG, "sb_finalize: null handle");
     if (s->finalized) return fail(SB_ERR_STATE, "sb_finalize called twice");
     if (s->n <= 0) return fail(SB_ERR_STATE, "sb_finalize before sb_set_particles");
-    // SB_TEST_NO_COMM: the hosted-halo test hooks (sb_debug_*) drive world > 1 without an RCCL communicator
-    if (s->desc.world > 1 && !s->comm && !s->peer.enabled && !std::getenv("SB_TEST_NO_COMM"))
-        return fail(SB_ERR_STATE, "sb_finalize: world > 1 needs sb_comm_init first (or SB_HALO_TRANSPORT=peer with sb_peer_connect)");
+    // SB_DEBUG_NO_COMM: the hosted-halo test hooks (sb_debug_*) drive world > 1 without any transport
+    const bool no_comm = (s->desc.debug_flags & SB_DEBUG_NO_COMM) != 0;
+    if (s->desc.world > 1 && !s->comm && !s->peer.enabled && !no_comm)
+        return fail(SB_ERR_STATE, "sb_finalize: world > 1 needs sb_comm_init first (or halo_transport = SB_TRANSPORT_PEER with sb_peer_connect)");
     return guarded([&]() -> int {
         int rc = set_device(s); if (rc) return rc;
+        // ---- which schedule (world > 1): decided before any work, from what the process is actually bound to ----
+        int sched = s->desc.world > 1 ? s->desc.halo_schedule : SB_SCHEDULE_SERIAL_EAGER;
+        if (sched == SB_SCHEDULE_AUTO) sched = SB_SCHEDULE_SERIAL_EAGER;
+        if (s->desc.world > 1 && !no_comm) {
+            const bool graph = sched == SB_SCHEDULE_SERIAL_GRAPH || sched == SB_SCHEDULE_OVERLAP_GRAPH;
+            if (graph && !s->desc.use_graph) return fail(SB_ERR_INVALID_ARG, "sb_finalize: a captured halo schedule needs use_graph = 1");
+            if (graph && !s->peer.enabled && rccl().version < 22606)
+                return fail(SB_ERR_UNSUPPORTED, "sb_finalize: capturing ncclSend/ncclRecv in a hipGraph is verified on RCCL >= 2.26.6 only; this process is bound to RCCL " +
+                            std::to_string(rccl().version) + " (" + rccl().path + "): use SB_SCHEDULE_SERIAL_EAGER");
+            if (sched == SB_SCHEDULE_OVERLAP_GRAPH && !capture_overlap_ok())
+                return fail(SB_ERR_UNSUPPORTED, "sb_finalize: SB_SCHEDULE_OVERLAP_GRAPH faults on HIP runtimes older than 7.2 (hipStreamEndCapture recurses over the forked "
+                            "exchange stream); this process is bound to HIP runtime " + std::to_string(hip_runtime_version()) +
+                            " (a host that loaded PyTorch first runs on PyTorch's bundled runtime): use SB_SCHEDULE_SERIAL_GRAPH or an eager schedule");
+        }
         const std::vector<float> &rest = s->rest.empty() ? s->pos : s->rest;
         sbp::Input in = make_input(rest.data(), s->n, s->dist_ij.data(), (int64_t)s->dist_rest.size(), s->vol_ijkl.data(),
                                    (int64_t)s->vol_rest.size(), s->bend_ijkl.data(), (int64_t)s->bend_rest.size() / 2);
-        sbp::Opts o;
-        o.rank = s->desc.rank; o.world = s->desc.world;
-        for (int a = 0; a < 3; ++a) o.dims[a] = s->desc.part_dims[a];
-        // automatic tile size: 512 particles for spring meshes (bandwidth-bound: the fewest rim tiles that still fill the chip),
-        // 256 when tets or hinges are present (latency-bound: shorter programs per tile, more tiles in flight)
-        o.tile_particles = s->desc.tile_particles != 0 ? s->desc.tile_particles : (s->vol_rest.empty() && s->bend_rest.empty() ? 512 : 256);
-        o.bank_aware_lanes = !std::getenv("SB_NO_BANK_ORDER");
-        o.third_tiling = !std::getenv("SB_NO_T2");
-        o.mixed_groups = !std::getenv("SB_NO_MIXED_GROUPS");
-        o.cluster_layers = !std::getenv("SB_NO_CLUSTER_LAYERS");
-        o.third_list = !std::getenv("SB_NO_THIRD_LIST");
+        sbp::Opts o = plan_opts(s->desc.rank, s->desc.world, s->desc.part_dims, s->desc.tile_particles, s->desc.partition, s->desc.plan_flags,
+                                in.m_v, in.m_b);
         s->plan = std::make_unique<sb_plan>();
         const bool timing = std::getenv("SB_PLAN_TIMING") != nullptr;
         auto t0 = std::chrono::steady_clock::now();
         sbp::build_plan(in, o, s->plan->plan);
         sbp::extract_local(s->plan->plan, in, o.rank, s->plan->local);
+        s->plan_hash = hash_plan(s->plan->plan);
         auto t1 = std::chrono::steady_clock::now();
+        {   // the overlapped schedules apply to plans whose only exchange is the one before the T1 kernels (lattices)
+            const sbp::Plan &P = s->plan->plan;
+            const sbp::LocalPlan &L = s->plan->local;
+            bool t1_halo = false;
+            if (L.halo.size() > 1) for (int r = 0; r < L.world; ++r) t1_halo |= !L.halo[1].send_idx[(size_t)r].empty() || !L.halo[1].recv_idx[(size_t)r].empty();
+            const bool want_overlap = sched == SB_SCHEDULE_OVERLAP_EAGER || sched == SB_SCHEDULE_OVERLAP_GRAPH;
+            s->overlap_halo = want_overlap && s->desc.world > 1 && s->comm && P.tiling && P.gcolours.empty() && P.t2_layers.empty() && t1_halo;
+            if (want_overlap && !s->overlap_halo)      // T2 layers / global colours (irregular mesh) or no T1 halo: the serialised form
+                sched = sched == SB_SCHEDULE_OVERLAP_GRAPH ? SB_SCHEDULE_SERIAL_GRAPH : SB_SCHEDULE_SERIAL_EAGER;
+        }
+        s->schedule = sched;
+        s->graph_rccl = sched == SB_SCHEDULE_SERIAL_GRAPH || sched == SB_SCHEDULE_OVERLAP_GRAPH;
         build_device(s);
         if (timing)
             std::fprintf(stderr, "[finalize] plan %.1f ms, build_device + upload %.1f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
@@ -1299,14 +1476,33 @@ int sb_finalize(sb_solver *s) {
         // opt in to the LDS size the largest tile needs
         for (int tl = 0; tl < 3; ++tl)
             if (s->tiling[tl].lds_bytes > 64 * 1024) throw std::runtime_error("internal: tile LDS budget exceeded");
-        if (s->desc.world > 1 && s->comm && s->plan->plan.tiling && s->gcolours.empty() && s->t2_layer_range.empty() && s->halos.size() > 1 &&
-            s->halos[1]->active() && std::getenv("SB_HALO_OVERLAP")) {
+        // Ranks plan independently: before the first exchange make sure they all arrived at the same plan (same published
+        // order, ownership, halo slots, plan options). One 8-byte all-gather over the communicator; the peer transport without
+        // a communicator compares the hashes when the mailboxes are linked (peer_link).
+        if (s->desc.world > 1 && s->comm && !s->loopback) {
+            const int W = s->desc.world;
+            DevBuf<uint64_t> d_all; int64_t acct = 0;
+            d_all.alloc((size_t)W, acct);
+            HIP_CHECK(hipMemcpy(d_all.p + s->desc.rank, &s->plan_hash, sizeof(uint64_t), hipMemcpyHostToDevice));
+            NCCL_CHECK(rccl().AllGather(d_all.p + s->desc.rank, d_all.p, sizeof(uint64_t), ncclUint8, s->comm, s->stream));
+            HIP_CHECK(hipStreamSynchronize(s->stream));
+            std::vector<uint64_t> all((size_t)W);
+            HIP_CHECK(hipMemcpy(all.data(), d_all.p, (size_t)W * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            for (int r = 0; r < W; ++r)
+                if (all[(size_t)r] != s->plan_hash) {
+                    char msg[256];
+                    std::snprintf(msg, sizeof msg, "sb_finalize: rank %d planned a different schedule than rank %d (plan hash %016llx vs %016llx): "
+                                  "every rank must pass the same mesh, tile_particles, partition and plan_flags", r, s->desc.rank,
+                                  (unsigned long long)all[(size_t)r], (unsigned long long)s->plan_hash);
+                    return fail(SB_ERR_STATE, msg);
+                }
+        }
+        if (s->overlap_halo) {
             // opt-in: on the one measurement available (RCCL loopback on one GPU, 8-rank share of 256^3) splitting the T0
-            // launch and running the exchange beside the interior tiles was 10 % SLOWER than the serialised schedule
+            // launch and running the exchange beside the interior tiles pays only inside a captured graph
             HIP_CHECK(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
             HIP_CHECK(hipEventCreateWithFlags(&s->ev_boundary, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&s->ev_halo, hipEventDisableTiming));
-            s->overlap_halo = true;
         }
         if (s->peer.enabled && s->desc.world > 1) {
             if (s->loopback) {
@@ -1319,7 +1515,7 @@ int sb_finalize(sb_solver *s) {
                 DevBuf<uint8_t> d_all; int64_t acct = 0;
                 d_all.alloc((size_t)W * sizeof(mine), acct);
                 HIP_CHECK(hipMemcpy(d_all.p + (size_t)s->desc.rank * sizeof(mine), &mine, sizeof(mine), hipMemcpyHostToDevice));
-                NCCL_CHECK(ncclAllGather(d_all.p + (size_t)s->desc.rank * sizeof(mine), d_all.p, sizeof(mine), ncclUint8, s->comm, s->stream));
+                NCCL_CHECK(rccl().AllGather(d_all.p + (size_t)s->desc.rank * sizeof(mine), d_all.p, sizeof(mine), ncclUint8, s->comm, s->stream));
                 HIP_CHECK(hipStreamSynchronize(s->stream));
                 std::vector<hipIpcMemHandle_t> all((size_t)W);
                 HIP_CHECK(hipMemcpy(all.data(), d_all.p, (size_t)W * sizeof(mine), hipMemcpyDeviceToHost));
@@ -1352,6 +1548,7 @@ int sb_step(sb_solver *s, float dt, int32_t substeps) {
     if (!(dt > 0.0f) || substeps <= 0) return fail(SB_ERR_INVALID_ARG, "sb_step: dt and substeps must be positive");
     return guarded([&]() -> int {
         int rc = set_device(s); if (rc) return rc;
+        check_peer_error(s);       // a halo wait of an earlier tick gave up: do not pile further ticks on stale ghosts
         if (s->peer.enabled && s->desc.world > 1 && !s->peer.linked) peer_link(s);     // (reads the neighbours' offset tables: not inside a capture)
         // lazy tick boundary: fuse with the previous tick's deferred last kernel when nothing changed
         const sbk::TickParams tp_new = tick_params(s, dt, substeps);
@@ -1360,7 +1557,7 @@ int sb_step(sb_solver *s, float dt, int32_t substeps) {
                           std::memcmp(&tp_new, &s->tp_host, sizeof(tp_new)) == 0;
         if (!fuse) flush_deferred(s);
         upload_tick_params(s, dt, substeps);
-        // world > 1: RCCL send/recv inside a captured graph is opt-in (SB_GRAPH_RCCL=1), see DESIGN.md §7
+        // world > 1: the exchange inside a captured graph is opt-in (SB_SCHEDULE_*_GRAPH), see DESIGN.md §7
         const bool graph_ok = s->desc.use_graph && (s->desc.world == 1 || s->graph_rccl);     // the overlapped schedule forks onto comm_stream inside the capture
         if (!graph_ok) {
             enqueue_substeps(s, substeps, nullptr, fuse, can_defer);
@@ -1513,7 +1710,6 @@ static int get_state(sb_solver *s, float *out, int32_t n, bool velocity) {
         int rc = set_device(s); if (rc) return rc;
         const sbp::LocalPlan &L = s->plan->local;
         flush_deferred(s);
-        check_peer_error(s);
         if (s->desc.world == 1) {
             // single rank: every entry is ours, so the permutation to caller numbering runs on the GPU and one copy
             // lands in the caller's array (the host-side scatter below costs 25 ms for 16.7 M particles)
@@ -1529,6 +1725,7 @@ static int get_state(sb_solver *s, float *out, int32_t n, bool velocity) {
             return SB_OK;
         }
         HIP_CHECK(hipStreamSynchronize(s->stream));
+        check_peer_error(s);
         // world > 1: only the entries this rank owns may be written (the caller merges the ranks' arrays)
         s->h_stage.resize((size_t)s->n_owned * 3);
         const float *src = velocity ? s->d_vel.p : s->d_pos3.p;
@@ -1657,6 +1854,7 @@ int sb_readback_end(sb_solver *s, const float **pos_xyz_out) {
         int rc = set_device(s); if (rc) return rc;
         const int k = s->snap_head;
         HIP_CHECK(hipEventSynchronize(s->ev_copied[k]));
+        check_peer_error(s);       // (the snapshot was taken behind every tick enqueued before it)
         *pos_xyz_out = s->snap_compact[k] ? s->h_cpos[k] : s->h_snap[k];
         s->snap_last_ended = k;
         s->snap_head = (s->snap_head + 1) % sb_solver::kSnapSlots; --s->snap_pending;
@@ -1770,6 +1968,21 @@ int sb_get_stats(sb_solver *s, sb_stats *out) {
         const DevTiling &D2 = s->tiling[2];
         if (D2.n_tiles) out->launch_bytes[4] = D2.staged_particles * (4 + 12 + mb + 12) + tables(D2);
     }
+    out->partition = P.partition;
+    out->halo_schedule = s->schedule;
+    out->plan_hash = s->plan_hash;
+    if (!P.rank_cost.empty()) {
+        out->partition_cost = P.rank_cost[(size_t)s->desc.rank];
+        for (int64_t c : P.rank_cost) { out->partition_cost_total += c; out->partition_cost_max = std::max(out->partition_cost_max, c); }
+    }
+    {
+        std::vector<uint8_t> is_peer((size_t)s->desc.world, 0);
+        for (const auto &H : s->halos) {
+            for (int pr : H->peers) is_peer[(size_t)pr] = 1;
+            out->halo_particles_recv += H->recv_off.back();
+        }
+        for (uint8_t b : is_peer) out->halo_peers += b;
+    }
     return SB_OK;
 }
 
@@ -1780,17 +1993,11 @@ int sb_plan_build(const float *rest, int32_t n, const int32_t *dist_ij, int32_t 
     if (!rest || !out || n <= 0 || m_d < 0 || m_v < 0 || m_b < 0) return fail(SB_ERR_INVALID_ARG, "sb_plan_build: bad argument");
     *out = nullptr;
     return guarded([&]() -> int {
-        sbp::Opts o;
-        if (opts) {
-            o.rank = opts->rank; o.world = opts->world <= 0 ? 1 : opts->world;
-            for (int a = 0; a < 3; ++a) o.dims[a] = opts->part_dims[a];
-            o.tile_particles = opts->tile_particles == 0 ? (m_v + m_b > 0 ? 256 : 512) : opts->tile_particles;
-        }
-        o.bank_aware_lanes = !std::getenv("SB_NO_BANK_ORDER");
-        o.third_tiling = !std::getenv("SB_NO_T2");
-        o.mixed_groups = !std::getenv("SB_NO_MIXED_GROUPS");
-        o.cluster_layers = !std::getenv("SB_NO_CLUSTER_LAYERS");
-        o.third_list = !std::getenv("SB_NO_THIRD_LIST");
+        if (opts && (opts->partition < SB_PARTITION_AUTO || opts->partition > SB_PARTITION_RCB)) return fail(SB_ERR_INVALID_ARG, "sb_plan_build: bad partition");
+        if (opts && (opts->plan_flags & ~kPlanFlagsAll)) return fail(SB_ERR_INVALID_ARG, "sb_plan_build: unknown bit in plan_flags");
+        // (opts == NULL: every field 0 -- one rank, automatic tile size by the same rule as sb_finalize)
+        const sbp::Opts o = opts ? plan_opts(opts->rank, opts->world, opts->part_dims, opts->tile_particles, opts->partition, opts->plan_flags, m_v, m_b)
+                                 : plan_opts(0, 1, nullptr, 0, SB_PARTITION_AUTO, 0u, m_v, m_b);
         sbp::Input in = make_input(rest, n, dist_ij, m_d, vol, m_v, bend, m_b);
         auto p = std::make_unique<sb_plan>();
         sbp::build_plan(in, o, p->plan);

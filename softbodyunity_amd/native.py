@@ -18,6 +18,11 @@ LIB_PATH = os.path.join(_HERE, f"libsoftbody_mi355x{'_' + _VARIANT if _VARIANT e
 SB_UNIQUE_ID_BYTES = 128
 SB_IPC_HANDLE_BYTES = 64
 SB_OK = 0
+SB_PARTITION_AUTO, SB_PARTITION_BLOCKS, SB_PARTITION_RCB = 0, 1, 2
+SB_PLAN_NO_T2, SB_PLAN_NO_THIRD_LIST, SB_PLAN_NO_CLUSTER_LAYERS, SB_PLAN_NO_MIXED_GROUPS, SB_PLAN_NO_BANK_ORDER = 1, 2, 4, 8, 16
+SB_TRANSPORT_RCCL, SB_TRANSPORT_PEER = 0, 1
+SB_SCHEDULE_AUTO, SB_SCHEDULE_SERIAL_EAGER, SB_SCHEDULE_SERIAL_GRAPH, SB_SCHEDULE_OVERLAP_EAGER, SB_SCHEDULE_OVERLAP_GRAPH = 0, 1, 2, 3, 4
+SB_DEBUG_NO_COMM, SB_DEBUG_LOOPBACK = 1, 2
 SB_ERR_INVALID_ARG, SB_ERR_STATE, SB_ERR_NO_DEVICE, SB_ERR_HIP, SB_ERR_RCCL, SB_ERR_NOMEM, SB_ERR_UNSUPPORTED = \
     -1, -2, -3, -4, -5, -6, -7
 
@@ -25,7 +30,9 @@ SB_ERR_INVALID_ARG, SB_ERR_STATE, SB_ERR_NO_DEVICE, SB_ERR_HIP, SB_ERR_RCCL, SB_
 class SbDesc(C.Structure):
     _fields_ = [("device", C.c_int32), ("rank", C.c_int32), ("world", C.c_int32), ("part_dims", C.c_int32 * 3),
                 ("gravity", C.c_float * 3), ("damping", C.c_float), ("tile_particles", C.c_int32),
-                ("use_graph", C.c_int32)]
+                ("use_graph", C.c_int32), ("partition", C.c_int32), ("plan_flags", C.c_uint32),
+                ("halo_transport", C.c_int32), ("halo_schedule", C.c_int32), ("debug_flags", C.c_uint32),
+                ("reserved", C.c_int32 * 3)]
 
 
 class SbStats(C.Structure):
@@ -35,7 +42,10 @@ class SbStats(C.Structure):
                 ("constraints_in_global", C.c_int64), ("halo_particles_t1", C.c_int64),
                 ("halo_particles_global", C.c_int64), ("device_bytes", C.c_int64),
                 ("n_t2_layers", C.c_int64), ("n_t2_tiles", C.c_int64), ("t2_constraints", C.c_int64),
-                ("launch_bytes", C.c_int64 * 5)]
+                ("launch_bytes", C.c_int64 * 5), ("partition", C.c_int32), ("halo_peers", C.c_int32),
+                ("partition_cost", C.c_int64), ("partition_cost_max", C.c_int64), ("partition_cost_total", C.c_int64),
+                ("halo_particles_recv", C.c_int64), ("plan_hash", C.c_uint64), ("halo_schedule", C.c_int32),
+                ("reserved", C.c_int32)]
 
     def as_dict(self):
         out = {}
@@ -46,7 +56,15 @@ class SbStats(C.Structure):
 
 
 class SbPlanOpts(C.Structure):
-    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("part_dims", C.c_int32 * 3), ("tile_particles", C.c_int32)]
+    _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("part_dims", C.c_int32 * 3), ("tile_particles", C.c_int32),
+                ("partition", C.c_int32), ("plan_flags", C.c_uint32)]
+
+
+class SbRuntimeInfo(C.Structure):
+    _fields_ = [("hip_runtime_version", C.c_int32), ("hip_driver_version", C.c_int32), ("rccl_version", C.c_int32),
+                ("rccl_header_version", C.c_int32), ("rccl_was_resident", C.c_int32), ("capture_serial_ok", C.c_int32),
+                ("capture_overlap_ok", C.c_int32), ("reserved", C.c_int32), ("hip_library", C.c_char * 256),
+                ("rccl_library", C.c_char * 256)]
 
 
 class SbPhaseInfo(C.Structure):
@@ -109,6 +127,7 @@ SIGNATURES = {
     "sb_plan_halo_counts": (C.c_int, [_P, C.c_int32, _P, _P]),
     "sb_plan_get_halo": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
     "sb_plan_get_local_order_mask": (C.c_int, [_P, C.c_int32, _P]),
+    "sb_runtime_info": (C.c_int, [C.POINTER(SbRuntimeInfo)]),
     "sb_last_error": (C.c_char_p, []),
     "sb_abi_version": (C.c_int, []),
 }
@@ -158,6 +177,43 @@ def i32(a, shape=None):
     return a if shape is None else a.reshape(shape)
 
 
+# ---- harness conveniences: the A/B switches of tools/ and tests/ as environment variables. The PLUGIN reads none of them;
+# they are translated here into the sb_desc / sb_plan_opts fields a host would set (include/softbody.h). --------------------
+_PLAN_FLAG_ENV = (("SB_NO_T2", SB_PLAN_NO_T2), ("SB_NO_THIRD_LIST", SB_PLAN_NO_THIRD_LIST),
+                  ("SB_NO_CLUSTER_LAYERS", SB_PLAN_NO_CLUSTER_LAYERS), ("SB_NO_MIXED_GROUPS", SB_PLAN_NO_MIXED_GROUPS),
+                  ("SB_NO_BANK_ORDER", SB_PLAN_NO_BANK_ORDER))
+
+
+def plan_flags_from_env():
+    return sum(bit for name, bit in _PLAN_FLAG_ENV if os.environ.get(name))
+
+
+def halo_transport_from_env():
+    return SB_TRANSPORT_PEER if os.environ.get("SB_HALO_TRANSPORT") == "peer" else SB_TRANSPORT_RCCL
+
+
+def halo_schedule_from_env():
+    overlap, graph = bool(os.environ.get("SB_HALO_OVERLAP")), bool(os.environ.get("SB_GRAPH_RCCL"))
+    if not overlap and not graph:
+        return SB_SCHEDULE_AUTO
+    return (SB_SCHEDULE_OVERLAP_GRAPH if graph else SB_SCHEDULE_OVERLAP_EAGER) if overlap else SB_SCHEDULE_SERIAL_GRAPH
+
+
+def debug_flags_from_env():
+    return (SB_DEBUG_NO_COMM if os.environ.get("SB_TEST_NO_COMM") else 0) | (SB_DEBUG_LOOPBACK if os.environ.get("SB_TEST_LOOPBACK") else 0)
+
+
+def runtime_info():
+    """What the plugin is bound to: HIP runtime + RCCL versions and library files, admitted captured schedules."""
+    ri = SbRuntimeInfo()
+    check(lib().sb_runtime_info(C.byref(ri)))
+    return {"hip_runtime_version": ri.hip_runtime_version, "hip_driver_version": ri.hip_driver_version,
+            "rccl_version": ri.rccl_version, "rccl_header_version": ri.rccl_header_version,
+            "rccl_was_resident": bool(ri.rccl_was_resident), "capture_serial_ok": bool(ri.capture_serial_ok),
+            "capture_overlap_ok": bool(ri.capture_overlap_ok), "hip_library": ri.hip_library.decode(),
+            "rccl_library": ri.rccl_library.decode()}
+
+
 class Plan:
     """Read-only view of a planner result (sb_plan_*). Owns the handle unless borrowed from a solver."""
 
@@ -167,13 +223,14 @@ class Plan:
 
     @classmethod
     def build(cls, rest_pos, dist_ij=None, vol_ijkl=None, bend_ijkl=None, rank=0, world=1, part_dims=(0, 0, 0),
-              tile_particles=0):
+              tile_particles=0, partition=SB_PARTITION_AUTO, plan_flags=None):
         L = lib()
         rest = f32(rest_pos, (-1, 3))
         d = i32(dist_ij if dist_ij is not None else np.zeros((0, 2)), (-1, 2))
         v = i32(vol_ijkl if vol_ijkl is not None else np.zeros((0, 4)), (-1, 4))
         b = i32(bend_ijkl if bend_ijkl is not None else np.zeros((0, 4)), (-1, 4))
-        o = SbPlanOpts(rank, world, (C.c_int32 * 3)(*part_dims), tile_particles)
+        o = SbPlanOpts(rank, world, (C.c_int32 * 3)(*part_dims), tile_particles, partition,
+                       plan_flags_from_env() if plan_flags is None else plan_flags)
         h = C.c_void_p()
         check(L.sb_plan_build(ptr(rest), rest.shape[0], ptr(d), d.shape[0], ptr(v), v.shape[0], ptr(b), b.shape[0],
                               C.byref(o), C.byref(h)))

@@ -18,7 +18,8 @@ class Softbody:
     # [SerializeField] block of csharp/Softbody.cs
     def __init__(self, mesh, substeps=20, fixed_delta_time=0.02, gravity=(0.0, -9.81, 0.0), damping=0.0,
                  distance_compliance=0.0, volume_compliance=0.0, bending_compliance=0.0, device=0, rank=0, world=1,
-                 part_dims=(0, 0, 0), tile_particles=0, use_graph=True, unique_id=None, ground_plane=None, use_gpu=True):
+                 part_dims=(0, 0, 0), tile_particles=0, use_graph=True, unique_id=None, ground_plane=None, use_gpu=True,
+                 partition=native.SB_PARTITION_AUTO, plan_flags=None, halo_transport=None, halo_schedule=None, debug_flags=None):
         self.mesh = mesh
         self.substeps = int(substeps)
         self.fixed_delta_time = float(fixed_delta_time)
@@ -29,6 +30,13 @@ class Softbody:
         self.part_dims = tuple(int(d) for d in part_dims)
         self.tile_particles = int(tile_particles)
         self.use_graph = bool(use_graph)
+        # sb_desc fields a host sets explicitly; None = taken from the harness' environment switches (native.*_from_env:
+        # the plugin itself reads no environment variable that changes the plan, the transport or the schedule)
+        self.partition = int(partition)
+        self.plan_flags = native.plan_flags_from_env() if plan_flags is None else int(plan_flags)
+        self.halo_transport = native.halo_transport_from_env() if halo_transport is None else int(halo_transport)
+        self.halo_schedule = native.halo_schedule_from_env() if halo_schedule is None else int(halo_schedule)
+        self.debug_flags = native.debug_flags_from_env() if debug_flags is None else int(debug_flags)
         self.unique_id = unique_id
         self.ground_plane = ground_plane   # None or (nx, ny, nz, d): n.x >= d
         # use_gpu=False mirrors the C# component's CPU branch (csharp/Softbody.cs): no solver handle, no device; Start()
@@ -47,7 +55,7 @@ class Softbody:
             m = self.mesh
             rest = m.rest_pos if m.rest_pos is not None else m.pos
             self._cpu_plan = native.Plan.build(rest, m.dist_ij, m.vol_ijkl, m.bend_ijkl, rank=0, world=1,
-                                               tile_particles=self.tile_particles)     # sb_plan_build: host only
+                                               tile_particles=self.tile_particles, plan_flags=self.plan_flags)     # sb_plan_build: host only
             self.n = f32(m.pos, (-1, 3)).shape[0]
             self.vertices = f32(m.pos, (-1, 3)).copy()
             return self
@@ -59,6 +67,8 @@ class Softbody:
         d.damping = self.damping
         d.tile_particles = self.tile_particles
         d.use_graph = 1 if self.use_graph else 0
+        d.partition, d.plan_flags = self.partition, self.plan_flags
+        d.halo_transport, d.halo_schedule, d.debug_flags = self.halo_transport, self.halo_schedule, self.debug_flags
         h = C.c_void_p()
         check(L.sb_create(C.byref(d), C.byref(h)))
         self._h = h
@@ -86,8 +96,8 @@ class Softbody:
         if len(m.bend_rest):
             q = i32(m.bend_ijkl, (-1, 4)); r = f32(m.bend_rest, (-1, 2))
             check(L.sb_set_bending_constraints(h, ptr(q), ptr(r), r.shape[0], self.compliance[2]))
-        peer_only = os.environ.get("SB_HALO_TRANSPORT") == "peer" and self.unique_id is None    # the host connects the mailboxes itself
-        if self.world > 1 and not os.environ.get("SB_TEST_NO_COMM") and not peer_only:
+        peer_only = self.halo_transport == native.SB_TRANSPORT_PEER and self.unique_id is None    # the host connects the mailboxes itself
+        if self.world > 1 and not (self.debug_flags & native.SB_DEBUG_NO_COMM) and not peer_only:
             assert self.unique_id is not None and len(self.unique_id) == native.SB_UNIQUE_ID_BYTES
             buf = (C.c_uint8 * native.SB_UNIQUE_ID_BYTES)(*self.unique_id)
             check(L.sb_comm_init(h, buf))

@@ -34,8 +34,8 @@ class RankSim:
     substep s follow (first the T2 tile kernel, which touches owned particles only). Ghosts are refreshed before every T1 kernel (slot 1: x and xprev) and before every
     cut global colour (slot 2+c: x)."""
 
-    def __init__(self, oracle_mod, mesh, rank, world, dims, tile, gravity, damping, compliance):
-        self.plan = build_plan(mesh, rank=rank, world=world, part_dims=dims, tile_particles=tile)
+    def __init__(self, oracle_mod, mesh, rank, world, dims, tile, gravity, damping, compliance, partition=0):
+        self.plan = build_plan(mesh, rank=rank, world=world, part_dims=dims, tile_particles=tile, partition=partition)
         self.rank, self.world = rank, world
         self.o = make_oracle(oracle_mod, mesh, None, gravity, damping, compliance)
         self.local = []      # per parity: (type, id) of executed entries + phase offsets into them
@@ -124,9 +124,9 @@ def run_tick(ranks, s, substeps, tiling_on, exchange):
 
 
 def run_partitioned(oracle_mod, mesh, world, dims=(0, 0, 0), ticks=1, substeps=10, dt=0.02, tile=512,
-                    gravity=(0.0, -9.81, 0.0), damping=0.0, compliance=(0.0, 0.0, 0.0)):
+                    gravity=(0.0, -9.81, 0.0), damping=0.0, compliance=(0.0, 0.0, 0.0), partition=0):
     """Partitioned oracle with memcpy halo. Returns merged positions/velocities."""
-    ranks = [RankSim(oracle_mod, mesh, r, world, dims, tile, gravity, damping, compliance) for r in range(world)]
+    ranks = [RankSim(oracle_mod, mesh, r, world, dims, tile, gravity, damping, compliance, partition) for r in range(world)]
     for _ in range(ticks):
         s = ranks[0].o.scalars(dt, substeps)
         run_tick(ranks, s, substeps, tile > 0, lambda slot, wp: _exchange_memcpy(ranks, slot, wp))

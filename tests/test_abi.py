@@ -40,16 +40,42 @@ def test_csharp_binding_lists_the_same_entry_points():
 
 
 def test_struct_layouts_match_header():
-    # sb_desc: 3 + 3 ints, 3 + 1 floats, 2 ints = 48 bytes; sb_phase_info has int64 alignment
-    assert C.sizeof(native.SbDesc) == 48
-    assert C.sizeof(native.SbPlanOpts) == 24
+    # sb_desc: 3 + 3 ints, 3 + 1 floats, 2 ints (ABI 5) + partition, plan_flags, transport, schedule, debug_flags, 3 reserved = 80
+    # bytes; sb_phase_info has int64 alignment
+    assert C.sizeof(native.SbDesc) == 80
+    assert C.sizeof(native.SbPlanOpts) == 32
     assert C.sizeof(native.SbPhaseInfo) == 48
-    assert C.sizeof(native.SbStats) == 8 * 2 + 8 * 3 + 4 * 2 + 8 * 4 + 8 * 5 + 8 * 3 + 8 * 5
+    assert C.sizeof(native.SbStats) == 8 * 2 + 8 * 3 + 4 * 2 + 8 * 4 + 8 * 5 + 8 * 3 + 8 * 5 + (4 * 2 + 8 * 3 + 8 + 8 + 4 * 2)
+    assert C.sizeof(native.SbRuntimeInfo) == 8 * 4 + 2 * 256
+
+
+def test_header_structs_compile_to_the_same_sizes(tmp_path):
+    # the ctypes twin against the header itself, through the C compiler
+    src = tmp_path / "sizes.c"
+    src.write_text('#include <stdio.h>\n#include "softbody.h"\nint main(void){printf("%zu %zu %zu %zu %zu\\n", sizeof(sb_desc), sizeof(sb_plan_opts), '
+                   'sizeof(sb_phase_info), sizeof(sb_stats), sizeof(sb_runtime_info_t)); return 0;}\n')
+    exe = tmp_path / "sizes"
+    subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
+    got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
+    assert got == [C.sizeof(native.SbDesc), C.sizeof(native.SbPlanOpts), C.sizeof(native.SbPhaseInfo), C.sizeof(native.SbStats),
+                   C.sizeof(native.SbRuntimeInfo)]
+
+
+def test_runtime_info_names_the_bound_libraries():
+    # no GPU needed: which HIP runtime / RCCL the plugin resolved to in THIS process (pytest imported torch first when a test
+    # module needed torch.multiprocessing: then both are PyTorch's bundled ones, else the system's)
+    ri = native.runtime_info()
+    assert ri["hip_runtime_version"] >= 70000000 and os.path.exists(ri["hip_library"])
+    assert ri["rccl_version"] >= 22606 and os.path.exists(ri["rccl_library"])
+    assert ri["capture_overlap_ok"] == (ri["hip_runtime_version"] >= 70200000)
+    import sys
+    if "torch" in sys.modules:
+        assert ri["rccl_was_resident"] and "torch" in ri["rccl_library"] and "torch" in ri["hip_library"]
 
 
 def test_loads_without_gpu_and_fails_loudly():
     L = native.lib()
-    assert L.sb_abi_version() == 5
+    assert L.sb_abi_version() == 6
     d = native.SbDesc()
     L.sb_desc_default(C.byref(d))
     assert d.world == 1 and d.tile_particles == 0 and d.use_graph == 1 and abs(d.gravity[1] + 9.81) < 1e-6

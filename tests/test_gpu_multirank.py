@@ -171,15 +171,77 @@ def test_multirank_device_path_with_hosted_halo(tmp_path, oracle_mod, monkeypatc
 # ---- the real RCCL pipeline on one GPU: loopback communicator (every peer = this rank) -----------------------
 
 def test_rccl_pipeline_loopback_and_overlap_equivalence():
-    """SB_TEST_LOOPBACK makes rank 0 of a 2-rank split exchange its ghosts with ITSELF through a size-1 RCCL
+    """SB_DEBUG_LOOPBACK makes rank 0 of a 2-rank split exchange its ghosts with ITSELF through a size-1 RCCL
     communicator: physically meaningless, but pack -> ncclSend/ncclRecv -> unpack, the comm stream and the event
     wiring all run for real. Four schedules -- serialised or overlapped (exchange beside the T0 interior and the T1
-    interior tiles), launched eagerly or captured in the hipGraph -- must give the same bits. Each runs in its own
-    process (tools/lb_combo_test.py): several RCCL communicators with captured graphs in ONE process crashed inside
-    the runtime on this image, which has nothing to do with the schedule under test."""
+    interior tiles), launched eagerly or captured in the hipGraph -- must give the same bits. The children do not import
+    torch, so the plugin is bound to the system's HIP 7.2 runtime + RCCL 2.27, which admits all four."""
     import subprocess
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lb_combo_test.py")], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lb_combo_check.py")], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-1500:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("rccl overlap=")]
-    assert len(lines) == 4 and all("rc=0 HASH" in l and l.endswith("True") for l in lines), out.stdout[-1500:]
-    assert "rccl all equal: True" in out.stdout, out.stdout[-1500:]
+    assert len(lines) == 4 and all("rc=0 HASH" in l and "True" in l for l in lines), out.stdout[-1500:]
+    assert "rccl all equal: True refused: []" in out.stdout, out.stdout[-1500:]
+
+
+def test_schedules_admitted_with_torch_imported_first():
+    """bench.py and the driver's N > 1 launch import torch before the plugin: the plugin is then bound to PyTorch's bundled HIP
+    7.0 runtime + RCCL 2.26.6 (sb_runtime_info). Every schedule the plugin ADMITS there must run and give the same bits; the
+    overlapped + captured schedule -- which recursed without bound inside hipStreamEndCapture of that runtime
+    (profiles/r03a_overlap_capture_backtrace.txt) -- must be refused with SB_ERR_UNSUPPORTED instead of crashing."""
+    import subprocess
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lb_combo_check.py"), "--torch-first"], capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-1500:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("rccl overlap=")]
+    assert len(lines) == 4 and all("rc=0" in l for l in lines), out.stdout[-1500:]
+    bound_old_hip = "BOUND hip 700" in out.stdout
+    if bound_old_hip:
+        assert "torch/lib/librccl.so" in out.stdout
+        assert [l for l in lines if "REFUSED -7" in l] == [l for l in lines if "overlap=1 graph=1" in l], out.stdout[-1500:]
+        assert "rccl all equal: True refused: [('1', '1')]" in out.stdout, out.stdout[-1500:]
+    else:       # a torch build that ships HIP >= 7.2: everything is admitted
+        assert "rccl all equal: True refused: []" in out.stdout, out.stdout[-1500:]
+
+
+def test_several_solvers_with_captured_exchanges_in_one_process():
+    """The Unity-player scenario: Softbody components created, stepped and destroyed in ONE process, their ticks (RCCL calls
+    included) captured in hipGraphs -- one after the other and several alive at once. (Round 2 saw a crash here: its in-process
+    test also ran the overlapped + captured schedule, in a pytest process that had imported torch -- the HIP 7.0 recursion above,
+    not a teardown-order problem; sb_destroy now also drains every stream before the graphs and the communicator go.)"""
+    import hashlib
+    from softbodyunity_amd import Softbody, comm_unique_id, native
+    from softbodyunity_amd.mesh import jelly_cube
+    mesh = jelly_cube(32)
+
+    def make(schedule):
+        return Softbody(mesh, substeps=8, device=0, rank=0, world=2, tile_particles=64, unique_id=comm_unique_id(),
+                        halo_schedule=schedule, debug_flags=native.SB_DEBUG_LOOPBACK).Start()
+
+    def run(sb, ticks=5):
+        for _ in range(ticks):
+            sb.step()
+        sb.synchronize()
+        return hashlib.sha256(sb.get_positions()[sb.owner() == 0].tobytes()).hexdigest()
+
+    scheds = [native.SB_SCHEDULE_SERIAL_EAGER, native.SB_SCHEDULE_SERIAL_GRAPH, native.SB_SCHEDULE_OVERLAP_EAGER]
+    if native.runtime_info()["capture_overlap_ok"]:
+        scheds.append(native.SB_SCHEDULE_OVERLAP_GRAPH)
+    else:
+        with pytest.raises(native.SoftbodyError) as e:
+            make(native.SB_SCHEDULE_OVERLAP_GRAPH)
+        assert e.value.code == native.SB_ERR_UNSUPPORTED
+    hashes = set()
+    for sc in scheds:                       # one after the other: create, step, destroy
+        sb = make(sc)
+        assert sb.stats()["halo_schedule"] == sc
+        hashes.add(run(sb))
+        sb.OnDestroy()
+    alive = [make(sc) for sc in scheds]     # all alive at once, stepped in turn
+    for _ in range(5):
+        for sb in alive:
+            sb.step()
+    for sb in alive:
+        hashes.add(run(sb, 0))
+    for sb in reversed(alive):
+        sb.OnDestroy()
+    assert len(hashes) == 1

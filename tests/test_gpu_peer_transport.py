@@ -74,7 +74,7 @@ def test_ranks_as_processes_through_the_peer_transport(tmp_path, oracle_mod, wor
 
 def test_peer_transport_loopback_schedules_agree():
     # rank 0's share with every neighbour replaced by itself: serialised / overlapped x eager / captured, one process each
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lb_combo_test.py"), "peer"], capture_output=True, text=True, timeout=900)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lb_combo_check.py"), "peer"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-1500:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("peer overlap=")]
     assert len(lines) == 4 and all("rc=0 HASH" in l and l.endswith("True") for l in lines), out.stdout[-1500:]

@@ -131,14 +131,60 @@ def test_kat9_partition_invariance_cube(oracle_mod, world, dims, tile):
             assert np.array_equal(t0, t1) and np.array_equal(i0, i1)
 
 
-def test_kat9_partition_invariance_irregular(oracle_mod, small_bunny):
+@pytest.mark.parametrize("partition", [0, 1, 2])
+def test_kat9_partition_invariance_irregular(oracle_mod, small_bunny, partition):
+    # partition 0 = automatic (RCB on this mesh: the block grid leaves it unbalanced), 1 = block grid, 2 = RCB
     mesh = small_bunny
     for tile in (128, -1):
         plan = build_plan(mesh, tile_particles=tile)
         ref = make_oracle(oracle_mod, mesh, plan, compliance=(1e-7, 1e-7, 1e-5))
         ref.step(0.02, 4)
-        x, v, _ = run_partitioned(oracle_mod, mesh, 4, (0, 0, 0), ticks=1, substeps=4, tile=tile, compliance=(1e-7, 1e-7, 1e-5))
+        x, v, ranks = run_partitioned(oracle_mod, mesh, 4, (0, 0, 0), ticks=1, substeps=4, tile=tile, compliance=(1e-7, 1e-7, 1e-5),
+                                      partition=partition)
         assert np.array_equal(x.view(np.uint32), ref.x.view(np.uint32))
+        assert np.array_equal(v.view(np.uint32), ref.v.view(np.uint32))
+        assert np.all(np.stack([r.owned for r in ranks]).sum(0) == 1)
+
+
+@pytest.mark.parametrize("world", [3, 8])
+def test_kat9_partition_invariance_cube_rcb(oracle_mod, world):
+    # RCB forced on a lattice (3 ranks: a 1:2 first cut; 8 ranks: three levels), pinned top layer
+    mesh = jelly_cube(16, pin_top=True)
+    ref = make_oracle(oracle_mod, mesh, build_plan(mesh, tile_particles=64))
+    ref.step(0.02, 5)
+    x, v, ranks = run_partitioned(oracle_mod, mesh, world, (0, 0, 0), ticks=1, substeps=5, tile=64, partition=2)
+    assert np.array_equal(x.view(np.uint32), ref.x.view(np.uint32)) and np.array_equal(v.view(np.uint32), ref.v.view(np.uint32))
+    owned = np.stack([r.owned for r in ranks]).sum(1)
+    assert owned.min() > 0 and owned.max() / owned.mean() < 1.35      # 64 cells of 64 particles over 3 or 8 ranks
+
+
+def test_rcb_balances_the_100k_surrogate_on_8_ranks():
+    """BASELINE.json:11 (config 5 on 8 GPUs). The block grid gives ranks 38 320 ... 1 particles (max / mean 3.06); recursive
+    coordinate bisection over whole T0 cells weighted by constraint cost must bring BOTH the owned particles and the constraint
+    cost every rank executes (redundant copies of cut tiles included; spring 1, tet 2, hinge 4) within 15 % of the mean."""
+    from softbodyunity_amd import native
+    mesh = bunny_surrogate(target_verts=100000)
+    W = 8
+    owned, cost, cost_est = [], [], None
+    wt = np.array([1, 2, 4])
+    for r in range(W):
+        p = build_plan(mesh, rank=r, world=W)            # automatic partition and tile size, as sb_finalize
+        o = p.owner(mesh.n)
+        t, _ = p.order(0)
+        cost.append(int(wt[t][p.local_order_mask(0).astype(bool)].sum()))
+        owned.append(int((o == r).sum()))
+        if r == 0:
+            own0 = o
+        else:
+            assert np.array_equal(o, own0)                # every rank computes the same ownership
+        p.close()
+    owned, cost = np.array(owned), np.array(cost)
+    assert owned.sum() == mesh.n and owned.min() > 0
+    assert owned.max() / owned.mean() <= 1.15, owned
+    assert cost.max() / cost.mean() <= 1.15, cost
+    blocks = build_plan(mesh, rank=0, world=W, partition=native.SB_PARTITION_BLOCKS).owner(mesh.n)
+    nb = np.bincount(blocks, minlength=W)
+    assert nb.max() / nb.mean() > 2.5                     # what the automatic choice avoided
 
 
 def test_plan_rejects_bad_input():

@@ -1,5 +1,7 @@
+#!/usr/bin/env python3
+"""Loopback check that capturing the RCCL calls in the hipGraph gives the eager bits (run as a script on the GPU box)."""
 import os, sys, numpy as np
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 os.environ["SB_TEST_LOOPBACK"] = "1"
 from softbodyunity_amd import Softbody, comm_unique_id
 from softbodyunity_amd.mesh import jelly_cube
