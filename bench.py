@@ -46,11 +46,11 @@ def b_alg(n_particles, n_constraints):
     return 52.0 * n_particles + 68.0 * n_constraints + 36.0 * n_particles
 
 
-def _golden_entry(n, substeps, tile):
+def _golden_entry(n, substeps, tile, het=False):
     path = os.path.join(ROOT, "tests", "golden", "state_checksums.json")
     if not os.path.exists(path):
         return None
-    return json.load(open(path)).get(f"cube{n}_s{substeps}_tile{tile}")
+    return json.load(open(path)).get(f"cube{n}{'het' if het else ''}_s{substeps}_tile{tile}")
 
 
 def main():
@@ -66,11 +66,18 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the self-verification legs (profiling runs)")
     ap.add_argument("--cpu-sample-n", type=int, default=0, help="cube edge for the CPU baseline sample (0 = the workload itself)")
-    ap.add_argument("--allow-stale-traffic", action="store_true",
-                    help="do not fail when profiles/hbm_traffic.json disagrees with the compulsory-bytes model (used while re-measuring it)")
+    ap.add_argument("--strict-traffic", action="store_true",
+                    help="fail (instead of falling back to the compulsory-bytes model and saying so) when profiles/hbm_traffic.json is "
+                         "missing or disagrees with the model of this build's tables by more than 3 %%")
+    ap.add_argument("--allow-stale-traffic", action="store_true", help="(accepted for old scripts; stale entries never fail without --strict-traffic)")
+    ap.add_argument("--heterogeneous", action="store_true",
+                    help="the data-layout worst case beside the headline's best case: per-particle masses and per-spring rest lengths "
+                         "(4-byte inverse masses, 8-byte constraint slots; mesh.jelly_cube(heterogeneous=True))")
     ap.add_argument("--transport", choices=["rccl", "peer"], default="rccl",
                     help="ghost exchange for --gpus N > 1: RCCL send/recv (default) or the opt-in peer-store mailboxes (DESIGN.md 7; "
                          "never run between two devices)")
+    ap.add_argument("--schedule", choices=["auto", "serial-eager", "serial-graph", "overlap-eager", "overlap-graph"], default="auto",
+                    help="halo schedule for N > 1 (sb_desc.halo_schedule); auto = serialised eager launches")
     ap.add_argument("--loopback-world", type=int, default=0,
                     help="diagnostic: run as rank 0 of this many ranks with SB_TEST_LOOPBACK (RCCL self-exchange on one GPU); "
                          "the reported value counts only the particles this rank owns")
@@ -82,8 +89,6 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    if args.transport == "peer":
-        os.environ["SB_HALO_TRANSPORT"] = "peer"          # read by sb_create
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -103,11 +108,14 @@ def main():
     n_dev = torch.cuda.device_count()
     device = local_rank if (n_dev == 0 or local_rank < n_dev) else local_rank % n_dev
 
-    from softbodyunity_amd import Softbody, comm_unique_id, jelly_cube
+    # torch is imported BEFORE the plugin on purpose and always: the plugin then binds the HIP runtime and the RCCL torch brought
+    # (one ROCm stack per process); which ones is recorded in the line (config.runtime, from sb_runtime_info)
+    from softbodyunity_amd import Softbody, comm_unique_id, jelly_cube, native
     from softbodyunity_amd.verify import add_checksums, schedule_hash, state_checksum
+    runtime = native.runtime_info() if (world > 1 or args.loopback_world > 1) else None
 
     t_setup = time.time()
-    mesh = jelly_cube(args.n)
+    mesh = jelly_cube(args.n, heterogeneous=args.heterogeneous)
     mesh_s = time.time() - t_setup
     N = mesh.n
     M = len(mesh.dist_rest)
@@ -121,204 +129,224 @@ def main():
         uid = bytes(buf.tolist())
     dt = 0.02
     sb_world = world
+    debug_flags = 0
     if args.loopback_world > 1:
         assert world == 1, "--loopback-world is a single-process diagnostic"
-        os.environ["SB_TEST_LOOPBACK"] = "1"
+        debug_flags = native.SB_DEBUG_LOOPBACK
         sb_world = args.loopback_world
         uid = comm_unique_id()
+    schedule = {"auto": native.SB_SCHEDULE_AUTO, "serial-eager": native.SB_SCHEDULE_SERIAL_EAGER, "serial-graph": native.SB_SCHEDULE_SERIAL_GRAPH,
+                "overlap-eager": native.SB_SCHEDULE_OVERLAP_EAGER, "overlap-graph": native.SB_SCHEDULE_OVERLAP_GRAPH}[args.schedule]
     sb = Softbody(mesh, substeps=args.substeps, fixed_delta_time=dt, device=device, rank=rank, world=sb_world,
-                  tile_particles=args.tile, use_graph=not args.no_graph, unique_id=uid).Start()
-    if world > 1 and peer:
-        handles = [torch.zeros(64, dtype=torch.uint8) for _ in range(world)]
-        dist.all_gather(handles, torch.from_numpy(sb.peer_mailbox_handle().copy()))
-        for r in range(world):
-            if r != rank:
-                sb.peer_connect(r, handles[r].numpy())
-        dist.barrier()
-    stats = sb.stats()
-    setup_s = time.time() - t_setup
+                  tile_particles=args.tile, use_graph=not args.no_graph, unique_id=uid, plan_flags=0, debug_flags=debug_flags,
+                  halo_transport=native.SB_TRANSPORT_PEER if peer else native.SB_TRANSPORT_RCCL, halo_schedule=schedule).Start()
+    try:
+        if world > 1 and peer:
+            handles = [torch.zeros(64, dtype=torch.uint8) for _ in range(world)]
+            dist.all_gather(handles, torch.from_numpy(sb.peer_mailbox_handle().copy()))
+            for r in range(world):
+                if r != rank:
+                    sb.peer_connect(r, handles[r].numpy())
+            dist.barrier()
+        stats = sb.stats()
+        setup_s = time.time() - t_setup
 
-    def barrier():
-        sb.synchronize()
-        if torch.cuda.is_available():
-            torch.cuda.synchronize()
+        def barrier():
+            sb.synchronize()
+            if torch.cuda.is_available():
+                torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+
+        for _ in range(args.warmup):
+            sb.step()
+        barrier()
+        t0 = time.perf_counter()
+        sb.profile_begin()
+        for _ in range(args.steps):
+            sb.step()
+        ev_ms = sb.profile_end()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        # ---- self-verification, leg 1: the state the timed run ended with, against the oracle's golden checksum ------
+        total_ticks = args.warmup + args.steps
+        parity = {"ticks": total_ticks}
+        loopback = args.loopback_world > 1
+        if not args.no_parity and not loopback:
+            owned_mask = sb.owner() == rank
+            ids = np.nonzero(owned_mask)[0]
+            x_end = sb.get_positions(); v_end = sb.get_velocities()
+            finite = bool(np.isfinite(x_end[ids]).all())
+            part = state_checksum(x_end[ids], v_end[ids], ids)
+            if dist is not None:
+                parts = [None] * world
+                dist.all_gather_object(parts, part)
+                fin = [None] * world
+                dist.all_gather_object(fin, finite)
+                finite = all(fin)
+            else:
+                parts = [part]
+            checksum = add_checksums(parts)
+            golden = _golden_entry(args.n, args.substeps, args.tile, args.heterogeneous)
+            want = golden["ticks"].get(str(total_ticks)) if golden else None
+            parity["golden"] = {"n": N, "checksum": f"0x{checksum:016x}", "expected": want,
+                                "bitwise": (int(want, 16) == checksum) if want else None,
+                                "source": "tests/golden/state_checksums.json (CPU oracle, tests/golden/make_checksums.py)"}
+            if golden and world == 1 and rank == 0:
+                parity["golden"]["schedule_matches"] = schedule_hash(sb.plan()) == golden["schedule"]
+            del x_end, v_end
+        else:
+            finite = bool(np.isfinite(sb.get_positions()[sb.owner() == rank]).all())
+
+        # per-kernel HIP-event timing on the solver's stream: a few extra eager ticks, outside the timed region
+        prof_ticks = 2
+        slot_ms = None
+        for _ in range(prof_ticks):
+            ms, cnt = sb.step_profiled()
+            slot_ms = ms.astype(np.float64) if slot_ms is None else slot_ms + ms
+            slot_cnt = cnt
+        slot_ms /= prof_ticks
+
+        if loopback:
+            N = int(stats["n_particles_owned"])      # diagnostic mode: only this rank's share is simulated
+        value = N * args.substeps * args.steps / elapsed
+        ms_per_step = 1e3 * elapsed / args.steps
+        out = None
+        if rank == 0:
+            G = stats["n_global_colours"]
+            owned = stats["n_particles_owned"]
+            names = ["tile_kernel<1> on T0 (rounds + collide/velocity/integrate + rounds)",
+                     "tile_kernel<1> on T1 (rounds + collide/velocity/integrate + rounds)"]
+            names += [f"global colour {c}" for c in range(G)]
+            names += ["tile_kernel<0> (first kernel of a tick)", "tile_kernel<2> (last kernel of a tick)",
+                      "tile_kernel<3> on the T2 layers (constraints inside neither T0 nor T1)"]
+            # ALGORITHMIC bytes per launch: a mid-tick tile kernel does one velocity update (36 B)
+            # + one integrate (52 B) per particle and projects every constraint it stores TWICE (before and after
+            # the MARK step: the tail of one substep and the head of the next), 68 B each time
+            alg_bytes = [88.0 * owned + 2 * 68.0 * stats["tile_constraints"][t] for t in (0, 1)]
+            # compulsory HBM bytes per launch from the tables actually uploaded (sb_get_stats): the model the PMC figure is checked against
+            lb = stats["launch_bytes"]
+            model_bytes = [float(lb[0]), float(lb[1])]
+            mask0 = None
+            for c in range(G):
+                if mask0 is None:
+                    plan = sb.plan(); mask0 = plan.local_order_mask(0).astype(bool); ph0 = [p for p in plan.phases(0) if p["kind"] == 0]
+                cnt_c = int(mask0[ph0[c]["order_begin"]:ph0[c]["order_end"]].sum())
+                alg_bytes.append(68.0 * cnt_c)
+                model_bytes.append(68.0 * cnt_c)      # global colours gather/scatter straight on HBM: no on-chip reuse to model
+            last = (args.substeps & 1) if stats["n_tilings"] == 2 else 0
+            alg_bytes += [52.0 * owned + 68.0 * stats["tile_constraints"][0], 36.0 * owned + 68.0 * stats["tile_constraints"][last]]
+            alg_bytes.append(68.0 * stats["t2_constraints"])
+            model_bytes += [float(lb[2]), float(lb[3]) if last == 0 else float(lb[1] - (lb[0] - lb[3])), float(lb[4])]
+            k_dom = int(np.argmax(slot_ms))
+            launches = max(int(slot_cnt[k_dom]), 1)
+            dom_ms = float(slot_ms[k_dom]) / launches          # HIP-event pair around every launch of an eager tick
+            dom_ms_pairs = dom_ms
+            # When the timed region consists of launches of ONE kernel only -- the lattice workloads: tile_kernel<1>, T0 and T1
+            # launches alternating, `substeps` of them per tick once the lazy tick boundary has fused the first and last kernels --
+            # its average launch duration is the HIP-event time of the timed region itself divided by the launches in it (the
+            # event pairs of the eager ticks add ~4 % of dispatch gap per launch).
+            region_avg = (world == 1 and not loopback and not args.no_graph and G == 0 and stats["n_t2_layers"] == 0
+                          and stats["n_tilings"] == 2 and args.substeps % 2 == 0 and k_dom in (0, 1) and args.steps >= 2)
+            if region_avg:
+                dom_ms = ev_ms / (args.steps * args.substeps)
+                launches = args.substeps
+                for arr in (alg_bytes, model_bytes):
+                    arr[0] = arr[1] = 0.5 * (arr[0] + arr[1])
+                dom_name = "tile_kernel<1>, mid-tick (rounds + collide/velocity/integrate + rounds), T0 and T1 launches alternating"
+            else:
+                dom_name = names[k_dom]
+            # HBM traffic per launch of the dominant kernel: PMC counters (profiles/hbm_traffic.json, produced by
+            # tools/prof_summary.py from separate FETCH_SIZE / WRITE_SIZE passes) -- accepted only when within 3 % of the
+            # compulsory-bytes model of THIS build's tables, so the file cannot go stale unnoticed
+            traffic, traffic_src, traffic_meta = None, None, None
+            key = f"n{args.n}{'het' if args.heterogeneous else ''}_tile{args.tile}_gpus{world}"
+            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+            tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+            problem = None
+            if not loopback and key in tj and str(k_dom) in tj[key]:
+                traffic = float(tj[key][str(k_dom)])
+                if region_avg and "0" in tj[key] and "1" in tj[key]:
+                    traffic = 0.5 * (float(tj[key]["0"]) + float(tj[key]["1"]))     # the two launch shapes alternate
+                traffic_meta = tj[key].get("meta")
+                dev = abs(traffic - model_bytes[k_dom]) / model_bytes[k_dom]
+                if dev > 0.03:    # the entry was measured on another kernel / data layout: say so, use the model
+                    problem = (f"profiles/hbm_traffic.json[{key}][{k_dom}] = {traffic:.4g} B disagrees with the compulsory-bytes model "
+                               f"{model_bytes[k_dom]:.4g} B of this build by {100 * dev:.1f} %: re-measure (tools/profile_round.sh)")
+                    traffic_src = f"stale ({100 * dev:.1f} % off the model of this build's tables): achieved/frac use the compulsory-bytes model"
+                    traffic = None
+                else:
+                    traffic_src = "pmc"
+            elif args.n == 256 and args.tile == 512 and world == 1 and not loopback:
+                problem = f"profiles/hbm_traffic.json has no PMC entry for {key} slot {k_dom}"
+            if problem:
+                if args.strict_traffic:
+                    raise RuntimeError("bench.py: " + problem)
+                print("WARNING: " + problem, file=sys.stderr)
+            hbm_bytes = traffic if traffic is not None else model_bytes[k_dom]
+            achieved = hbm_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+            alg_rate = alg_bytes[k_dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+            job_alg = b_alg(N, M) * value / N   # algorithmic B/s of the whole job
+            parity["finite"] = finite
+            out = {
+                "metric": "particle-substeps/sec", "value": value, "unit": "particle-substeps/s",
+                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                "config": {"workload": f"{args.n}^3 jelly cube, structural springs (N={N}, M={M}), {args.substeps} substeps/tick, "
+                                       f"dt=0.02, explicit index-array graph, tile_particles={args.tile}" +
+                                       (", HETEROGENEOUS masses and rest lengths (4-byte inverse masses, 8-byte constraint slots)" if args.heterogeneous else ""),
+                           "partition": "x".join(str(d) for d in _dims(world)), "graph_replay": (not args.no_graph) and world == 1,
+                           "halo_transport": args.transport if (world > 1 or loopback) else None,
+                           "halo_schedule": {1: "serial-eager", 2: "serial-graph", 3: "overlap-eager", 4: "overlap-graph"}.get(stats["halo_schedule"]) if (world > 1 or loopback) else None,
+                           "runtime": runtime,
+                           "finite": finite, "parity": parity},
+                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                             "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
+                             "traffic_source": traffic_src or "none for this configuration: achieved/frac use the compulsory-bytes model",
+                             "traffic_measured_on": traffic_meta,
+                             "model_bytes_per_launch": model_bytes[k_dom],
+                             "traffic_over_model": (traffic / model_bytes[k_dom]) if traffic else None,
+                             "kernel": dom_name, "kernel_avg_ms": dom_ms, "kernel_launches_per_tick": launches,
+                             "kernel_avg_ms_source": ("HIP events over the timed region / launches in it" if region_avg
+                                                      else "HIP-event pair around every launch of an eager tick"),
+                             "kernel_avg_ms_event_pairs": dom_ms_pairs,
+                             "algorithmic_bytes_per_launch": alg_bytes[k_dom],
+                             "algorithmic_GBps": alg_rate, "frac_algorithmic": alg_rate / (HBM_PEAK / 1e9),
+                             "reuse_factor": alg_bytes[k_dom] / hbm_bytes,
+                             "note": "achieved/frac = HBM bytes per launch (PMC FETCH_SIZE/WRITE_SIZE where measured for this "
+                                     "configuration, else the compulsory-bytes model of the uploaded tables) / kernel time, against "
+                                     "8 TB/s. frac_algorithmic uses the SURVEY 8d figure (88 B/particle + 68 B per projected "
+                                     "constraint per mid-tick launch); it exceeds 1 because the tile kernel serves those accesses "
+                                     "from LDS (reuse_factor = algorithmic / HBM bytes)",
+                             "job_algorithmic_GBps": job_alg / 1e9, "job_frac_algorithmic": job_alg / (HBM_PEAK * world),
+                             "B_alg_per_particle_substep": b_alg(N, M) / N,
+                             "tick_ms_hip_events": ev_ms / args.steps,
+                             "per_slot_ms_per_tick": {names[k]: float(slot_ms[k]) for k in range(len(names))},
+                             "per_slot_launches_per_tick": {names[k]: int(slot_cnt[k]) for k in range(len(names))}},
+                "setup_seconds": setup_s, "setup_breakdown": {"mesh_generation": mesh_s, "Start (author + plan + upload)": setup_s - mesh_s},
+                "plan": stats,
+            }
+            if world == 1 and not loopback and not args.no_parity:
+                parity["small"] = small_parity(total_ticks, args, device)
+            if world == 1 and not loopback and not args.no_cpu_baseline:
+                out["cpu_baseline"], live = cpu_baseline(mesh, sb, args)
+                if live is not None:
+                    parity["live"] = live
+    finally:
+        # teardown order: every rank drains its own stream, then all ranks meet, THEN the solvers go -- under the peer transport
+        # sb_destroy frees the mailbox the neighbours' kernels store into (include/softbody.h)
+        try:
+            sb.synchronize()
+        except Exception as e:      # (report, but still meet the other ranks and free the solver)
+            print(f"bench.py: sb_synchronize at teardown: {e}", file=sys.stderr)
         if dist is not None:
             dist.barrier()
-
-    for _ in range(args.warmup):
-        sb.step()
-    barrier()
-    t0 = time.perf_counter()
-    sb.profile_begin()
-    for _ in range(args.steps):
-        sb.step()
-    ev_ms = sb.profile_end()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    # ---- self-verification, leg 1: the state the timed run ended with, against the oracle's golden checksum ------
-    total_ticks = args.warmup + args.steps
-    parity = {"ticks": total_ticks}
-    loopback = args.loopback_world > 1
-    if not args.no_parity and not loopback:
-        owned_mask = sb.owner() == rank
-        ids = np.nonzero(owned_mask)[0]
-        x_end = sb.get_positions(); v_end = sb.get_velocities()
-        finite = bool(np.isfinite(x_end[ids]).all())
-        part = state_checksum(x_end[ids], v_end[ids], ids)
-        if dist is not None:
-            parts = [None] * world
-            dist.all_gather_object(parts, part)
-            fin = [None] * world
-            dist.all_gather_object(fin, finite)
-            finite = all(fin)
-        else:
-            parts = [part]
-        checksum = add_checksums(parts)
-        golden = _golden_entry(args.n, args.substeps, args.tile)
-        want = golden["ticks"].get(str(total_ticks)) if golden else None
-        parity["golden"] = {"n": N, "checksum": f"0x{checksum:016x}", "expected": want,
-                            "bitwise": (int(want, 16) == checksum) if want else None,
-                            "source": "tests/golden/state_checksums.json (CPU oracle, tests/golden/make_checksums.py)"}
-        if golden and world == 1 and rank == 0:
-            parity["golden"]["schedule_matches"] = schedule_hash(sb.plan()) == golden["schedule"]
-        del x_end, v_end
-    else:
-        finite = bool(np.isfinite(sb.get_positions()[sb.owner() == rank]).all())
-
-    # per-kernel HIP-event timing on the solver's stream: a few extra eager ticks, outside the timed region
-    prof_ticks = 2
-    slot_ms = None
-    for _ in range(prof_ticks):
-        ms, cnt = sb.step_profiled()
-        slot_ms = ms.astype(np.float64) if slot_ms is None else slot_ms + ms
-        slot_cnt = cnt
-    slot_ms /= prof_ticks
-
-    if loopback:
-        N = int(stats["n_particles_owned"])      # diagnostic mode: only this rank's share is simulated
-    value = N * args.substeps * args.steps / elapsed
-    ms_per_step = 1e3 * elapsed / args.steps
-    out = None
-    if rank == 0:
-        G = stats["n_global_colours"]
-        owned = stats["n_particles_owned"]
-        names = ["tile_kernel<1> on T0 (rounds + collide/velocity/integrate + rounds)",
-                 "tile_kernel<1> on T1 (rounds + collide/velocity/integrate + rounds)"]
-        names += [f"global colour {c}" for c in range(G)]
-        names += ["tile_kernel<0> (first kernel of a tick)", "tile_kernel<2> (last kernel of a tick)",
-                  "tile_kernel<3> on the T2 layers (constraints inside neither T0 nor T1)"]
-        # ALGORITHMIC bytes per launch: a mid-tick tile kernel does one velocity update (36 B)
-        # + one integrate (52 B) per particle and projects every constraint it stores TWICE (before and after
-        # the MARK step: the tail of one substep and the head of the next), 68 B each time
-        alg_bytes = [88.0 * owned + 2 * 68.0 * stats["tile_constraints"][t] for t in (0, 1)]
-        # compulsory HBM bytes per launch from the tables actually uploaded (sb_get_stats): the model the PMC figure is checked against
-        lb = stats["launch_bytes"]
-        model_bytes = [float(lb[0]), float(lb[1])]
-        mask0 = None
-        for c in range(G):
-            if mask0 is None:
-                plan = sb.plan(); mask0 = plan.local_order_mask(0).astype(bool); ph0 = [p for p in plan.phases(0) if p["kind"] == 0]
-            cnt_c = int(mask0[ph0[c]["order_begin"]:ph0[c]["order_end"]].sum())
-            alg_bytes.append(68.0 * cnt_c)
-            model_bytes.append(68.0 * cnt_c)      # global colours gather/scatter straight on HBM: no on-chip reuse to model
-        last = (args.substeps & 1) if stats["n_tilings"] == 2 else 0
-        alg_bytes += [52.0 * owned + 68.0 * stats["tile_constraints"][0], 36.0 * owned + 68.0 * stats["tile_constraints"][last]]
-        alg_bytes.append(68.0 * stats["t2_constraints"])
-        model_bytes += [float(lb[2]), float(lb[3]) if last == 0 else float(lb[1] - (lb[0] - lb[3])), float(lb[4])]
-        k_dom = int(np.argmax(slot_ms))
-        launches = max(int(slot_cnt[k_dom]), 1)
-        dom_ms = float(slot_ms[k_dom]) / launches          # HIP-event pair around every launch of an eager tick
-        dom_ms_pairs = dom_ms
-        # When the timed region consists of launches of ONE kernel only -- the lattice workloads: tile_kernel<1>, T0 and T1
-        # launches alternating, `substeps` of them per tick once the lazy tick boundary has fused the first and last kernels --
-        # its average launch duration is the HIP-event time of the timed region itself divided by the launches in it (the
-        # event pairs of the eager ticks add ~4 % of dispatch gap per launch).
-        region_avg = (world == 1 and not loopback and not args.no_graph and G == 0 and stats["n_t2_layers"] == 0
-                      and stats["n_tilings"] == 2 and args.substeps % 2 == 0 and k_dom in (0, 1) and args.steps >= 2)
-        if region_avg:
-            dom_ms = ev_ms / (args.steps * args.substeps)
-            launches = args.substeps
-            for arr in (alg_bytes, model_bytes):
-                arr[0] = arr[1] = 0.5 * (arr[0] + arr[1])
-            dom_name = "tile_kernel<1>, mid-tick (rounds + collide/velocity/integrate + rounds), T0 and T1 launches alternating"
-        else:
-            dom_name = names[k_dom]
-        # HBM traffic per launch of the dominant kernel: PMC counters (profiles/hbm_traffic.json, produced by
-        # tools/prof_summary.py from separate FETCH_SIZE / WRITE_SIZE passes) -- accepted only when within 3 % of the
-        # compulsory-bytes model of THIS build's tables, so the file cannot go stale unnoticed
-        traffic, traffic_src, traffic_meta = None, None, None
-        key = f"n{args.n}_tile{args.tile}_gpus{world}"
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
-        if not loopback and key in tj and str(k_dom) in tj[key]:
-            traffic = float(tj[key][str(k_dom)])
-            if region_avg and "0" in tj[key] and "1" in tj[key]:
-                traffic = 0.5 * (float(tj[key]["0"]) + float(tj[key]["1"]))     # the two launch shapes alternate
-            traffic_meta = tj[key].get("meta")
-            dev = abs(traffic - model_bytes[k_dom]) / model_bytes[k_dom]
-            if dev > 0.03:    # the entry was measured on another kernel / data layout
-                msg = (f"profiles/hbm_traffic.json[{key}][{k_dom}] = {traffic:.4g} B disagrees with the compulsory-bytes model "
-                       f"{model_bytes[k_dom]:.4g} B of this build by {100 * dev:.1f} %: re-measure (tools/profile_round.sh)")
-                if not args.allow_stale_traffic:
-                    raise SystemExit("bench.py: " + msg)
-                print("WARNING: " + msg, file=sys.stderr)
-                traffic = None
-            else:
-                traffic_src = "pmc"
-        elif args.n == 256 and args.tile == 512 and world == 1 and not loopback and not args.allow_stale_traffic:
-            raise SystemExit(f"bench.py: profiles/hbm_traffic.json has no PMC entry for {key} slot {k_dom}")
-        hbm_bytes = traffic if traffic is not None else model_bytes[k_dom]
-        achieved = hbm_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        alg_rate = alg_bytes[k_dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-        job_alg = b_alg(N, M) * value / N   # algorithmic B/s of the whole job
-        parity["finite"] = finite
-        out = {
-            "metric": "particle-substeps/sec", "value": value, "unit": "particle-substeps/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"{args.n}^3 jelly cube, structural springs (N={N}, M={M}), {args.substeps} substeps/tick, "
-                                   f"dt=0.02, explicit index-array graph, tile_particles={args.tile}",
-                       "partition": "x".join(str(d) for d in _dims(world)), "graph_replay": (not args.no_graph) and world == 1,
-                       "halo_transport": (os.environ.get("SB_HALO_TRANSPORT") or "rccl") if (world > 1 or loopback) else None,
-                       "finite": finite, "parity": parity},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
-                         "traffic_source": traffic_src or "none for this configuration: achieved/frac use the compulsory-bytes model",
-                         "traffic_measured_on": traffic_meta,
-                         "model_bytes_per_launch": model_bytes[k_dom],
-                         "traffic_over_model": (traffic / model_bytes[k_dom]) if traffic else None,
-                         "kernel": dom_name, "kernel_avg_ms": dom_ms, "kernel_launches_per_tick": launches,
-                         "kernel_avg_ms_source": ("HIP events over the timed region / launches in it" if region_avg
-                                                  else "HIP-event pair around every launch of an eager tick"),
-                         "kernel_avg_ms_event_pairs": dom_ms_pairs,
-                         "algorithmic_bytes_per_launch": alg_bytes[k_dom],
-                         "algorithmic_GBps": alg_rate, "frac_algorithmic": alg_rate / (HBM_PEAK / 1e9),
-                         "reuse_factor": alg_bytes[k_dom] / hbm_bytes,
-                         "note": "achieved/frac = HBM bytes per launch (PMC FETCH_SIZE/WRITE_SIZE where measured for this "
-                                 "configuration, else the compulsory-bytes model of the uploaded tables) / kernel time, against "
-                                 "8 TB/s. frac_algorithmic uses the SURVEY 8d figure (88 B/particle + 68 B per projected "
-                                 "constraint per mid-tick launch); it exceeds 1 because the tile kernel serves those accesses "
-                                 "from LDS (reuse_factor = algorithmic / HBM bytes)",
-                         "job_algorithmic_GBps": job_alg / 1e9, "job_frac_algorithmic": job_alg / (HBM_PEAK * world),
-                         "B_alg_per_particle_substep": b_alg(N, M) / N,
-                         "tick_ms_hip_events": ev_ms / args.steps,
-                         "per_slot_ms_per_tick": {names[k]: float(slot_ms[k]) for k in range(len(names))},
-                         "per_slot_launches_per_tick": {names[k]: int(slot_cnt[k]) for k in range(len(names))}},
-            "setup_seconds": setup_s, "setup_breakdown": {"mesh_generation": mesh_s, "Start (author + plan + upload)": setup_s - mesh_s},
-            "plan": stats,
-        }
-        if world == 1 and not loopback and not args.no_parity:
-            parity["small"] = small_parity(total_ticks, args, device)
-        if world == 1 and not loopback and not args.no_cpu_baseline:
-            out["cpu_baseline"], live = cpu_baseline(mesh, sb, args)
-            if live is not None:
-                parity["live"] = live
-    sb.OnDestroy()
+        sb.OnDestroy()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

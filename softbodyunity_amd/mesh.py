@@ -29,8 +29,12 @@ class SoftbodyMesh:
         return self.pos.shape[0]
 
 
-def jelly_cube(n, spacing=1.0, perturb=0.05, seed=1234, pin_top=False, stencil="structural"):
-    """n^3 lattice, index (iz*n+iy)*n+ix, structural springs x-dir then y then z (SPEC.md §7)."""
+def jelly_cube(n, spacing=1.0, perturb=0.05, seed=1234, pin_top=False, stencil="structural", heterogeneous=False):
+    """n^3 lattice, index (iz*n+iy)*n+ix, structural springs x-dir then y then z (SPEC.md §7).
+
+    heterogeneous=True is the data-layout WORST case beside the benchmark's best case (SPEC.md §7): every particle its own mass
+    (m ~ U(0.5, 2) from the seed, so the inverse mass travels as a 4-byte float instead of not at all) and every spring its own
+    rest length (the perturbed pose's length x U(0.95, 1.05), so no tile can dictionary-code its slots: 8 bytes instead of 4)."""
     assert n >= 2
     N = n ** 3
     ax = np.arange(n, dtype=np.float32) * np.float32(spacing)
@@ -75,10 +79,17 @@ def jelly_cube(n, spacing=1.0, perturb=0.05, seed=1234, pin_top=False, stencil="
     else:
         rest_len = np.full(ij.shape[0], spacing, np.float32)   # axis springs: L0 = spacing (SPEC.md §7)
     w = np.ones(N, np.float32)
+    if heterogeneous:
+        hrng = np.random.default_rng(seed + 1)
+        w = (1.0 / hrng.uniform(0.5, 2.0, size=N)).astype(np.float32)
+        d = pos[ij[:, 0]].astype(np.float64)
+        d -= pos[ij[:, 1]]
+        rest_len = (np.sqrt(np.einsum("ij,ij->i", d, d)) * hrng.uniform(0.95, 1.05, size=ij.shape[0])).astype(np.float32)
+        del d
     if pin_top:
         w.reshape(n, n, n)[:, n - 1, :] = 0.0
     return SoftbodyMesh(rest_pos=rest, pos=pos, vel=np.zeros_like(pos), inv_mass=w, dist_ij=ij,
-                        dist_rest=rest_len, label=f"jelly_cube_{n}^3_{stencil}")
+                        dist_rest=rest_len, label=f"jelly_cube_{n}^3_{stencil}" + ("_heterogeneous" if heterogeneous else ""))
 
 
 def _blob_inside(p):

@@ -9,6 +9,7 @@ must be re-run:
 
     python tests/golden/make_checksums.py            # all configurations (256^3 takes a few minutes on 8 cores)
     python tests/golden/make_checksums.py 64         # one cube edge only
+    python tests/golden/make_checksums.py het 256    # only the heterogeneous variant of one edge
 """
 import json
 import os
@@ -25,22 +26,24 @@ from helpers import build_plan, make_oracle  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 OUT = os.path.join(HERE, "state_checksums.json")
 # (cube edge, substeps, tile_particles, ticks): BASELINE.json:8 (64^3) and :9/:10 (256^3), bench.py defaults
-CONFIGS = [(64, 20, 512, 40), (256, 20, 512, 40)]
+# the last field: heterogeneous masses / rest lengths (bench.py --heterogeneous, the worst-case data layout; fewer ticks)
+CONFIGS = [(64, 20, 512, 40, False), (256, 20, 512, 40, False), (64, 20, 512, 30, True), (256, 20, 512, 25, True)]
 
 
-def key(n, substeps, tile):
-    return f"cube{n}_s{substeps}_tile{tile}"
+def key(n, substeps, tile, het=False):
+    return f"cube{n}{'het' if het else ''}_s{substeps}_tile{tile}"
 
 
 def main():
-    only = [int(a) for a in sys.argv[1:]]
+    only = [int(a) for a in sys.argv[1:] if a.isdigit()]
+    het_only = "het" in sys.argv[1:]
     table = json.load(open(OUT)) if os.path.exists(OUT) else {}
     os.environ.setdefault("OMP_NUM_THREADS", str(len(os.sched_getaffinity(0))))
-    for n, S, tile, ticks in CONFIGS:
-        if only and n not in only:
+    for n, S, tile, ticks, het in CONFIGS:
+        if (only and n not in only) or (het_only and not het):
             continue
         t0 = time.time()
-        mesh = jelly_cube(n)
+        mesh = jelly_cube(n, heterogeneous=het)
         plan = build_plan(mesh, tile_particles=tile)
         o = make_oracle(oracle, mesh, plan)
         entry = {"n_particles": mesh.n, "substeps": S, "dt": 0.02, "tile_particles": tile, "schedule": schedule_hash(plan),
@@ -49,8 +52,8 @@ def main():
         for t in range(1, ticks + 1):
             o.step(0.02, S, parallel=True)
             entry["ticks"][str(t)] = f"0x{state_checksum(o.x, o.v):016x}"
-            print(f"{key(n, S, tile)} tick {t}: {entry['ticks'][str(t)]}  ({time.time() - t0:.0f} s)", flush=True)
-        table[key(n, S, tile)] = entry
+            print(f"{key(n, S, tile, het)} tick {t}: {entry['ticks'][str(t)]}  ({time.time() - t0:.0f} s)", flush=True)
+        table[key(n, S, tile, het)] = entry
         with open(OUT, "w") as f:
             json.dump(table, f, indent=1, sort_keys=True)
             f.write("\n")

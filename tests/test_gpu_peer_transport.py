@@ -77,7 +77,7 @@ def test_peer_transport_loopback_schedules_agree():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lb_combo_check.py"), "peer"], capture_output=True, text=True, timeout=900)
     assert out.returncode == 0, out.stderr[-1500:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("peer overlap=")]
-    assert len(lines) == 4 and all("rc=0 HASH" in l and l.endswith("True") for l in lines), out.stdout[-1500:]
+    assert len(lines) == 4 and all("rc=0 HASH" in l and " True " in l for l in lines), out.stdout[-1500:]
     assert "peer all equal: True" in out.stdout, out.stdout[-1500:]
 
 
