@@ -76,6 +76,7 @@ def main():
     ap.add_argument("--transport", choices=["rccl", "peer"], default="rccl",
                     help="ghost exchange for --gpus N > 1: RCCL send/recv (default) or the opt-in peer-store mailboxes (DESIGN.md 7; "
                          "never run between two devices)")
+    ap.add_argument("--whole-mesh", action="store_true", help="N > 1: every rank generates and plans the whole mesh (round-2 behaviour) instead of its window")
     ap.add_argument("--schedule", choices=["auto", "serial-eager", "serial-graph", "overlap-eager", "overlap-graph"], default="auto",
                     help="halo schedule for N > 1 (sb_desc.halo_schedule); auto = serialised eager launches")
     ap.add_argument("--loopback-world", type=int, default=0,
@@ -115,10 +116,19 @@ def main():
     runtime = native.runtime_info() if (world > 1 or args.loopback_world > 1) else None
 
     t_setup = time.time()
-    mesh = jelly_cube(args.n, heterogeneous=args.heterogeneous)
+    # N > 1: sharded authoring -- every rank generates, hands over and plans only ITS WINDOW of the cube (its block + two cells
+    # of margin, include/softbody.h sb_domain); the whole 256^3 mesh exists nowhere. (--heterogeneous and --tile -1 keep the
+    # whole mesh on every rank.)
+    sharded = world > 1 and args.loopback_world <= 1 and not args.heterogeneous and args.tile > 0 and not args.whole_mesh
+    if sharded:
+        from softbodyunity_amd.mesh import jelly_cube_window
+        mesh = jelly_cube_window(args.n, rank, world, _dims(world), args.tile)
+    else:
+        mesh = jelly_cube(args.n, heterogeneous=args.heterogeneous)
     mesh_s = time.time() - t_setup
-    N = mesh.n
-    M = len(mesh.dist_rest)
+    N = args.n ** 3
+    M = 3 * args.n * args.n * (args.n - 1)
+    gid = mesh.global_id if sharded else None        # whole-cube id of every particle this rank handed over
     uid = None
     peer = args.transport == "peer"
     if world > 1 and not peer:       # (the peer transport needs no RCCL communicator: the mailbox handles travel over gloo below)
@@ -182,7 +192,7 @@ def main():
             ids = np.nonzero(owned_mask)[0]
             x_end = sb.get_positions(); v_end = sb.get_velocities()
             finite = bool(np.isfinite(x_end[ids]).all())
-            part = state_checksum(x_end[ids], v_end[ids], ids)
+            part = state_checksum(x_end[ids], v_end[ids], ids if gid is None else gid[ids])
             if dist is not None:
                 parts = [None] * world
                 dist.all_gather_object(parts, part)
@@ -301,6 +311,7 @@ def main():
                                        f"dt=0.02, explicit index-array graph, tile_particles={args.tile}" +
                                        (", HETEROGENEOUS masses and rest lengths (4-byte inverse masses, 8-byte constraint slots)" if args.heterogeneous else ""),
                            "partition": "x".join(str(d) for d in _dims(world)), "graph_replay": (not args.no_graph) and world == 1,
+                       "authoring": ("sharded: each rank hands over and plans its window only (sb_set_domain)" if sharded else "whole mesh on every rank"),
                            "halo_transport": args.transport if (world > 1 or loopback) else None,
                            "halo_schedule": {1: "serial-eager", 2: "serial-graph", 3: "overlap-eager", 4: "overlap-graph"}.get(stats["halo_schedule"]) if (world > 1 or loopback) else None,
                            "runtime": runtime,

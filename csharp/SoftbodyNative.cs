@@ -68,6 +68,17 @@ namespace SoftbodyMI355X
         public int tileParticles;
         public int partition;
         public uint planFlags;
+        public IntPtr domain;        // SbDomain* (sharded authoring: the input is this rank's window of a larger mesh) or IntPtr.Zero
+        public IntPtr globalId;      // int* ids of the window's particles in the whole mesh, ascending, or IntPtr.Zero
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct SbDomain
+    {
+        public long nGlobal;
+        public double loX, loY, loZ, hiX, hiY, hiZ;
+        public double spacing;
+        public int fourVertexConstraints, reserved;
     }
 
     [StructLayout(LayoutKind.Sequential)]
@@ -96,6 +107,9 @@ namespace SoftbodyMI355X
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_volume_constraints(IntPtr s, IntPtr ijkl, IntPtr restVol, int m, float compliance);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_bending_constraints(IntPtr s, IntPtr ijkl, IntPtr restCosSin, int m, float compliance);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_ground_plane(IntPtr s, float nx, float ny, float nz, float d, int enabled);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_domain(IntPtr s, ref SbDomain domain, IntPtr globalId, int n);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_domain_from_mesh(IntPtr restXyz, int n, IntPtr distIj, int mD, IntPtr volIjkl, int mV, IntPtr bendIjkl, int mB, out SbDomain domain);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_domain_window(ref SbDomain domain, ref SbPlanOpts opts, double[] lo3, double[] hi3);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_finalize(IntPtr s);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_comm_unique_id(IntPtr outId128);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_comm_init(IntPtr s, IntPtr id128);
@@ -139,6 +153,7 @@ namespace SoftbodyMI355X
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_halo_slot_count(IntPtr plan);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_halo_counts(IntPtr plan, int slot, IntPtr sendCountPerRank, IntPtr recvCountPerRank);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_halo(IntPtr plan, int slot, int peer, IntPtr sendIds, IntPtr recvIds);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_pair_hashes(IntPtr plan, IntPtr outPerRank);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_local_order_mask(IntPtr plan, int parity, IntPtr maskOut);
         [DllImport(Lib, CallingConvention = CC)] public static extern IntPtr sb_last_error();
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_abi_version();

@@ -112,6 +112,22 @@ int sb_set_bending_constraints(sb_solver *s, const int32_t *ijkl, const float *r
 /* Optional frictionless ground plane n.x >= d applied at the end of every substep (SPEC.md §2 step 2b);
  * n should be unit length. May be called before or after sb_finalize; takes effect at the next sb_step. */
 int sb_set_ground_plane(sb_solver *s, float nx, float ny, float nz, float d, int32_t enabled);
+/* Sharded authoring (world > 1, block partition): a rank may hand over only ITS WINDOW of the mesh -- the particles whose rest
+ * position lies in the box sb_domain_window returns for it (its block of cells plus two cells of margin), the constraints among
+ * them, in the order of the whole mesh -- instead of the whole mesh on every rank. sb_domain is the frame all ranks agree on:
+ * every window is cut from the one grid made from it, so the ranks' tiles, ghost lists and shared-tile programs fit together
+ * exactly as when every rank plans the whole mesh (sb_finalize verifies it pair by pair). A whole-mesh host never needs this. */
+typedef struct {
+    int64_t n_global;                 /* particles of the whole mesh */
+    double  lo[3], hi[3];             /* bounding box of the whole rest pose */
+    double  spacing;                  /* mean rest length of the whole mesh's distance constraints */
+    int32_t four_vertex_constraints;  /* the whole mesh has volume or bending constraints (automatic tile size: 256 instead of 512) */
+    int32_t reserved;
+} sb_domain;
+/* Declare, before sb_finalize, that the arrays given to sb_set_particles / sb_set_*_constraints are this rank's window of a
+ * larger mesh. global_id: the n particles' ids in the whole mesh, strictly ascending. Every later n (sb_get_positions,
+ * sb_get_owner, ...) is the window's n, in the window's numbering. */
+int sb_set_domain(sb_solver *s, const sb_domain *domain, const int32_t *global_id, int32_t n);
 /* Plan (colour + tile + partition), upload, capture. After this the authoring calls are rejected. */
 int sb_finalize(sb_solver *s);
 
@@ -240,7 +256,16 @@ typedef struct {
     int32_t tile_particles;  /* as sb_desc.tile_particles (0 = automatic by the same rule); opts == NULL: all fields 0 */
     int32_t partition;       /* SB_PARTITION_* */
     uint32_t plan_flags;     /* SB_PLAN_* */
+    const sb_domain *domain;    /* NULL = the input is the whole mesh; else the input is this rank's window of it ... */
+    const int32_t *global_id;   /* ... and these are its particles' ids in the whole mesh, strictly ascending (n of them) */
 } sb_plan_opts;
+/* The frame of a whole mesh, measured exactly as a whole-mesh plan measures it (a lattice generator can also fill sb_domain in
+ * closed form: lo / hi = the lattice's corners, spacing = the spring length). */
+int sb_domain_from_mesh(const float *rest_xyz, int32_t n, const int32_t *dist_ij, int32_t m_d, const int32_t *vol_ijkl, int32_t m_v,
+                        const int32_t *bend_ijkl, int32_t m_b, sb_domain *out);
+/* The box (rest coordinates, lo inclusive, hi exclusive; +-1e300 where the window reaches the rim of the grid) whose particles rank
+ * opts->rank must hand over. Only rank, world, part_dims and tile_particles of opts are read. */
+int sb_domain_window(const sb_domain *domain, const sb_plan_opts *opts, double lo_out[3], double hi_out[3]);
 typedef struct {
     int32_t kind;               /* 0 = global colour, 1 = a tiling's tiles, first phase of the substep, 2 = the other tiling's tiles,
                                    last phase, 3 = the sparse tiles of one T2 layer (after kind 1, before the global colours) */
@@ -283,6 +308,11 @@ int32_t sb_plan_halo_slot_count(const sb_plan *p);
 int sb_plan_halo_counts(const sb_plan *p, int32_t slot, int32_t *send_count_per_rank /* world */,
                         int32_t *recv_count_per_rank /* world */);
 int sb_plan_get_halo(const sb_plan *p, int32_t slot, int32_t peer, int32_t *send_ids, int32_t *recv_ids);
+/* Per peer rank: a hash of everything this rank and that peer must agree on -- the ghost lists between them (whole-mesh particle
+ * ids, both directions, every slot) and the programs of the tiles both run (constraint sequences as whole-mesh particle ids).
+ * Symmetric: rank a's entry for b equals rank b's entry for a exactly when the two planned consistently; sb_finalize (RCCL) and the
+ * peer transport's link step compare them. out_per_rank: world entries, the own rank's is 0. */
+int sb_plan_get_pair_hashes(const sb_plan *p, uint64_t *out_per_rank);
 /* Which order entries this rank executes (1) or skips (0) — cut constraints run on every rank that owns
  * one of their particles. */
 int sb_plan_get_local_order_mask(const sb_plan *p, int32_t parity, uint8_t *mask_out);

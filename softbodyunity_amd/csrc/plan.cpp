@@ -221,6 +221,113 @@ void parallel_for_chunks(int64_t n, int64_t chunk_size, const std::function<void
     parallel_chunks(n, chunk_size, f);
 }
 
+void compute_domain(const Input &in, Domain &dom) {
+    const int32_t n = in.n;
+    if (n <= 0) throw std::runtime_error("no particles");
+    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
+    {
+        constexpr int64_t kChunk = 1 << 20;
+        const int64_t nch = ((int64_t)n + kChunk - 1) / kChunk;
+        std::vector<double> plo((size_t)nch * 3, 1e300), phi((size_t)nch * 3, -1e300);
+        parallel_chunks(n, kChunk, [&](int64_t c, int64_t pb, int64_t pe) {
+            double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
+            for (int64_t p = pb; p < pe; ++p)
+                for (int a = 0; a < 3; ++a) {
+                    double v = in.rest[3 * p + a];
+                    if (!(v == v) || std::fabs(v) > 1e30) throw std::runtime_error("non-finite rest position");
+                    l[a] = std::min(l[a], v); h[a] = std::max(h[a], v);
+                }
+            for (int a = 0; a < 3; ++a) { plo[(size_t)c * 3 + a] = l[a]; phi[(size_t)c * 3 + a] = h[a]; }
+        });
+        for (int64_t c = 0; c < nch; ++c)
+            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], plo[(size_t)c * 3 + a]); hi[a] = std::max(hi[a], phi[(size_t)c * 3 + a]); }
+    }
+    double ell = 0;
+    {
+        // mean spring length: partial sums over fixed chunks of the constraint list, added in chunk order (the same
+        // value whatever the thread count)
+        double acc = 0; int64_t cnt = 0;
+        auto mean_edges = [&](const int32_t *idx, int nv, int64_t m_all) {
+            if (m_all <= 0 || !idx) return;
+            // a sample of about a million evenly spaced constraints is plenty for a length scale (every one below 2^21)
+            const int64_t stride = std::max<int64_t>(1, m_all >> 20), m = (m_all + stride - 1) / stride;
+            constexpr int64_t kChunk = 1 << 16;
+            const int64_t nch = (m + kChunk - 1) / kChunk;
+            std::vector<double> part((size_t)nch, 0.0);
+            parallel_chunks(m, kChunk, [&](int64_t c, int64_t kb, int64_t ke) {
+                double a2 = 0;
+                for (int64_t ks = kb; ks < ke; ++ks) {
+                    const int64_t k = ks * stride;
+                    const int32_t i = idx[nv * k], j = idx[nv * k + 1];
+                    if (i < 0 || i >= n || j < 0 || j >= n) throw std::runtime_error("constraint index out of range");
+                    double s = 0;
+                    for (int a = 0; a < 3; ++a) { double d = (double)in.rest[3 * (int64_t)i + a] - in.rest[3 * (int64_t)j + a]; s += d * d; }
+                    a2 += std::sqrt(s);
+                }
+                part[(size_t)c] = a2;
+            });
+            for (double v : part) acc += v;
+            cnt += m;
+        };
+        mean_edges(in.dist_ij, 2, in.m_d);
+        if (cnt == 0) mean_edges(in.vol, 4, in.m_v);
+        if (cnt == 0) mean_edges(in.bend, 4, in.m_b);
+        if (cnt > 0) ell = acc / cnt;
+        if (!(ell > 0)) {
+            double vol = 1; for (int a = 0; a < 3; ++a) vol *= std::max(hi[a] - lo[a], 1e-6);
+            ell = std::cbrt(vol / n);
+        }
+    }
+    dom.set = false;            // (measured, not imposed)
+    dom.n_global = n;
+    for (int a = 0; a < 3; ++a) { dom.lo[a] = lo[a]; dom.hi[a] = hi[a]; }
+    dom.ell = ell;
+}
+
+Grid make_grid(const Domain &dom, int target) {
+    Grid G;
+    const double ell = dom.ell;
+    for (int a = 0; a < 3; ++a) G.ext[a] = (float)(dom.hi[a] - dom.lo[a] + ell);
+    {
+        double density = (double)dom.n_global / ((double)G.ext[0] * G.ext[1] * G.ext[2]);
+        double per = density * ell * ell * ell;  // particles per ell^3
+        G.kk = (int)std::lround(std::cbrt(target / std::max(per, 1e-9)));
+        G.kk = std::max(G.kk, 2);
+        if (G.kk & 1) ++G.kk;
+    }
+    G.cs = G.kk * ell;
+    for (int a = 0; a < 3; ++a) {
+        G.org[a] = dom.lo[a] - 0.5 * ell;
+        G.nc[a] = (int)std::floor((dom.hi[a] - G.org[a]) / G.cs) + 1;
+    }
+    if ((int64_t)G.nc[0] * G.nc[1] * G.nc[2] > (int64_t)1 << 40) throw std::runtime_error("grid too large");
+    // T1 = T0 shifted by an ODD number of mean spring lengths close to half a cell (kk is even): on a lattice the
+    // springs that cross a T0 boundary and those that cross a T1 boundary then belong to different parity classes,
+    // so each class is a complete matching inside one of the two tilings (see the static split in build_plan)
+    G.shift_units = ((G.kk / 2) & 1) ? G.kk / 2 : std::max(G.kk / 2 - 1, 1);
+    G.shift_frac = (double)G.shift_units / G.kk;
+    G.first_t2_frac = G.shift_frac + 0.5 * (1.0 - G.shift_frac);     // grid of the first T2 layer: the middle of the widest gap between the T0 and T1 planes
+    return G;
+}
+
+void rank_window(const Domain &dom, const Opts &opts, int cell_lo[3], int cell_hi[3], double box_lo[3], double box_hi[3]) {
+    const int target = opts.tile_particles > 0 ? opts.tile_particles : 512;
+    const Grid G = make_grid(dom, target);
+    int dims[3];
+    resolve_dims(opts.world, G.ext, opts.dims, dims);
+    int b[3] = {opts.rank % dims[0], (opts.rank / dims[0]) % dims[1], opts.rank / (dims[0] * dims[1])};
+    for (int a = 0; a < 3; ++a) {
+        // cells c with floor(c * dims / nc) == b[a]
+        const int64_t nc = G.nc[a], d = dims[a];
+        const int c_lo = (int)(((int64_t)b[a] * nc + d - 1) / d), c_hi = (int)((((int64_t)b[a] + 1) * nc + d - 1) / d);
+        cell_lo[a] = std::max(0, c_lo - kWindowMarginCells);
+        cell_hi[a] = std::min((int)nc, c_hi + kWindowMarginCells);
+        // the box in rest coordinates; the outermost cells reach to infinity (positions are clamped into the grid)
+        box_lo[a] = cell_lo[a] == 0 ? -1e300 : G.org[a] + cell_lo[a] * G.cs;
+        box_hi[a] = cell_hi[a] == (int)nc ? 1e300 : G.org[a] + cell_hi[a] * G.cs;
+    }
+}
+
 void build_plan(const Input &in, const Opts &opts, Plan &P) {
     P = Plan();
     P.opts = opts;
@@ -248,89 +355,43 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         });
     }
     timer.lap("validate");
-    // ---- geometry: spacing estimate, bounding box --------------------------------------------
-    double lo[3] = {1e300, 1e300, 1e300}, hi[3] = {-1e300, -1e300, -1e300};
-    {
-        constexpr int64_t kChunk = 1 << 20;
-        const int64_t nch = ((int64_t)n + kChunk - 1) / kChunk;
-        std::vector<double> plo((size_t)nch * 3, 1e300), phi((size_t)nch * 3, -1e300);
-        parallel_chunks(n, kChunk, [&](int64_t c, int64_t pb, int64_t pe) {
-            double l[3] = {1e300, 1e300, 1e300}, h[3] = {-1e300, -1e300, -1e300};
-            for (int64_t p = pb; p < pe; ++p)
-                for (int a = 0; a < 3; ++a) {
-                    double v = in.rest[3 * p + a];
-                    if (!(v == v) || std::fabs(v) > 1e30) throw std::runtime_error("non-finite rest position");
-                    l[a] = std::min(l[a], v); h[a] = std::max(h[a], v);
-                }
-            for (int a = 0; a < 3; ++a) { plo[(size_t)c * 3 + a] = l[a]; phi[(size_t)c * 3 + a] = h[a]; }
+    // ---- geometry: the frame (bounding box, length scale, particle count) and the grid made from it -----------
+    // A whole-mesh plan measures the frame on its input; a sharded plan (the input is one rank's window of a larger mesh)
+    // takes the frame every rank agrees on from the caller, so that all windows are cut from ONE grid.
+    Domain dom = opts.domain;
+    const bool sharded = dom.set;
+    if (sharded) {
+        if (!in.global_id) throw std::runtime_error("a sharded plan needs the global ids of its particles");
+        if (dom.n_global < n || !(dom.ell > 0)) throw std::runtime_error("bad domain (n_global < n, or spacing <= 0)");
+        for (int a = 0; a < 3; ++a) if (!(dom.hi[a] >= dom.lo[a])) throw std::runtime_error("bad domain (hi < lo)");
+        parallel_chunks(n, 1 << 20, [&](int64_t, int64_t pb, int64_t pe) {
+            for (int64_t q = pb; q < pe; ++q) {
+                if (in.global_id[q] < 0 || in.global_id[q] >= dom.n_global) throw std::runtime_error("global particle id out of range");
+                if (q > 0 && in.global_id[q - 1] >= in.global_id[q]) throw std::runtime_error("global particle ids must be strictly ascending");
+                for (int a = 0; a < 3; ++a) { double v = in.rest[3 * q + a]; if (!(v == v) || std::fabs(v) > 1e30) throw std::runtime_error("non-finite rest position"); }
+            }
         });
-        for (int64_t c = 0; c < nch; ++c)
-            for (int a = 0; a < 3; ++a) { lo[a] = std::min(lo[a], plo[(size_t)c * 3 + a]); hi[a] = std::max(hi[a], phi[(size_t)c * 3 + a]); }
+    } else {
+        compute_domain(in, dom);
     }
-    double ell = 0;
-    {
-        // mean spring length: partial sums over fixed chunks of the constraint list, added in chunk order (the same
-        // value whatever the thread count)
-        double acc = 0; int64_t cnt = 0;
-        auto mean_edges = [&](const int32_t *idx, int nv, int64_t m_all) {
-            // a sample of about a million evenly spaced constraints is plenty for a length scale (every one below 2^21)
-            const int64_t stride = std::max<int64_t>(1, m_all >> 20), m = (m_all + stride - 1) / stride;
-            constexpr int64_t kChunk = 1 << 16;
-            const int64_t nch = (m + kChunk - 1) / kChunk;
-            std::vector<double> part((size_t)nch, 0.0);
-            parallel_chunks(m, kChunk, [&](int64_t c, int64_t kb, int64_t ke) {
-                double a2 = 0;
-                for (int64_t ks = kb; ks < ke; ++ks) {
-                    const int64_t k = ks * stride;
-                    const int32_t i = idx[nv * k], j = idx[nv * k + 1];
-                    double s = 0;
-                    for (int a = 0; a < 3; ++a) { double d = (double)in.rest[3 * (int64_t)i + a] - in.rest[3 * (int64_t)j + a]; s += d * d; }
-                    a2 += std::sqrt(s);
-                }
-                part[(size_t)c] = a2;
-            });
-            for (double v : part) acc += v;
-            cnt += m;
-        };
-        mean_edges(in.dist_ij, 2, in.m_d);
-        if (cnt == 0) mean_edges(in.vol, 4, in.m_v);
-        if (cnt == 0) mean_edges(in.bend, 4, in.m_b);
-        if (cnt > 0) ell = acc / cnt;
-        if (!(ell > 0)) {
-            double vol = 1; for (int a = 0; a < 3; ++a) vol *= std::max(hi[a] - lo[a], 1e-6);
-            ell = std::cbrt(vol / n);
-        }
-    }
-    float ext[3];
-    for (int a = 0; a < 3; ++a) ext[a] = (float)(hi[a] - lo[a] + ell);
-    resolve_dims(opts.world, ext, opts.dims, P.dims);
-
+    P.domain = dom;
     const bool tiling = opts.tile_particles > 0;
     P.tiling = tiling;
     const int target = tiling ? opts.tile_particles : 512;
     if (target > kMaxTileLocal) throw std::runtime_error("tile_particles too large");
-    int kk;
-    {
-        double density = n / ((double)ext[0] * ext[1] * ext[2]);
-        double per = density * ell * ell * ell;  // particles per ell^3
-        kk = (int)std::lround(std::cbrt(target / std::max(per, 1e-9)));
-        kk = std::max(kk, 2);
-        if (kk & 1) ++kk;
+    const Grid G = make_grid(dom, target);
+    resolve_dims(opts.world, G.ext, opts.dims, P.dims);
+    const int kk = G.kk; (void)kk;
+    const double cs = G.cs;
+    const double *org = G.org;
+    const int *nc = G.nc;
+    const double shift_frac = G.shift_frac, first_t2_frac = G.first_t2_frac;
+    int win_lo[3] = {0, 0, 0}, win_hi[3] = {nc[0], nc[1], nc[2]};     // sharded: the cells this rank's window must cover
+    if (sharded) {
+        if (opts.partition == 2) throw std::runtime_error("a sharded plan cannot use the RCB partition (it needs the whole mesh): pass the whole mesh");
+        double blo[3], bhi[3];
+        rank_window(dom, opts, win_lo, win_hi, blo, bhi);
     }
-    const double cs = kk * ell;
-    double org[3];
-    int nc[3];
-    for (int a = 0; a < 3; ++a) {
-        org[a] = lo[a] - 0.5 * ell;
-        nc[a] = (int)std::floor((hi[a] - org[a]) / cs) + 1;
-    }
-    if ((int64_t)nc[0] * nc[1] * nc[2] > (int64_t)1 << 40) throw std::runtime_error("grid too large");
-    // T1 = T0 shifted by an ODD number of mean spring lengths close to half a cell (kk is even): on a lattice the
-    // springs that cross a T0 boundary and those that cross a T1 boundary then belong to different parity classes,
-    // so each class is a complete matching inside one of the two tilings (see the static split below)
-    const int shift_units = ((kk / 2) & 1) ? kk / 2 : std::max(kk / 2 - 1, 1);
-    const double shift_frac = (double)shift_units / kk;
-    const double first_t2_frac = shift_frac + 0.5 * (1.0 - shift_frac);     // grid of the first T2 layer: the middle of the widest gap between the T0 and T1 planes
     std::vector<int64_t> cell(n), scell(n);
     P.owner_of_old.resize(n);
     parallel_chunks(n, 1 << 18, [&](int64_t, int64_t pb, int64_t pe) {
@@ -342,6 +403,9 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
                 s[a] = std::min(std::max((int)std::floor(r - shift_frac) + 1, 0), nc[a]);
                 blk[a] = (int)((int64_t)c[a] * P.dims[a] / nc[a]);
             }
+            if (sharded)
+                for (int a = 0; a < 3; ++a)
+                    if (c[a] < win_lo[a] || c[a] >= win_hi[a]) throw std::runtime_error("a particle lies outside this rank's window (sb_domain_window)");
             cell[p] = ((int64_t)c[2] * nc[1] + c[1]) * nc[0] + c[0];
             scell[p] = ((int64_t)s[2] * (nc[1] + 1) + s[1]) * (nc[0] + 1) + s[0];
             P.owner_of_old[p] = (blk[2] * P.dims[1] + blk[1]) * P.dims[0] + blk[0];
@@ -378,9 +442,9 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
                     add(part);
                 });
         };
-        rank_costs(P.owner_of_old, P.rank_cost);
+        rank_costs(P.owner_of_old, P.rank_cost);     // (sharded: the costs of the window's particles only)
         bool rcb = opts.partition == 2;
-        if (opts.partition == 0 && !(opts.dims[0] > 0 && opts.dims[1] > 0 && opts.dims[2] > 0)) {
+        if (opts.partition == 0 && !sharded && !(opts.dims[0] > 0 && opts.dims[1] > 0 && opts.dims[2] > 0)) {
             int64_t total = 0, worst = 0;
             for (int64_t c : P.rank_cost) { total += c; worst = std::max(worst, c); }
             rcb = worst * opts.world * 10 > total * 11;      // the block grid leaves a rank more than 10 % above the mean
@@ -1385,6 +1449,50 @@ void extract_local(const Plan &P, const Input &in, int rank, LocalPlan &L) {
                 LT.runs.push_back({ls, rn.len});
             }
             LT.run_begin.push_back((int32_t)LT.runs.size());
+        }
+    }
+    // ---- pair hashes: what this rank and each peer must agree on (see LocalPlan::pair_hash) ---------------------
+    {
+        auto gid = [&](int32_t old) { return (uint64_t)(uint32_t)(in.global_id ? in.global_id[old] : old); };
+        auto mix = [](uint64_t &h, uint64_t v) { h = (h ^ v) * 1099511628211ull; h ^= h >> 29; };
+        const uint64_t kSeed = 1469598103934665603ull;
+        std::vector<uint64_t> h_send((size_t)world, kSeed), h_recv((size_t)world, kSeed), h_tiles((size_t)world, kSeed);
+        for (size_t slot = 0; slot < L.halo.size(); ++slot)
+            for (int pr = 0; pr < world; ++pr) {
+                const auto &sv = L.halo[slot].send_idx[(size_t)pr], &rv = L.halo[slot].recv_idx[(size_t)pr];
+                if (sv.empty() && rv.empty()) continue;
+                mix(h_send[(size_t)pr], 0x5e4d0000ull + slot); mix(h_recv[(size_t)pr], 0x5e4d0000ull + slot);
+                for (int32_t li : sv) mix(h_send[(size_t)pr], gid(L.local_to_old[(size_t)li]));
+                for (int32_t li : rv) mix(h_recv[(size_t)pr], gid(L.local_to_old[(size_t)li]));
+            }
+        // programs of the tiles this rank shares with a peer (T1 / T2 tiles that span ranks), in tile order
+        for (int tl = 1; tl < 3; ++tl)
+            for (int32_t c : L.T[tl].tile_ids) {
+                const Tile &tile = P.T[tl].tiles[(size_t)c];
+                if (tile.owner >= 0) continue;
+                owners.clear();
+                if (tl == 2) for (int32_t q = 0; q < tile.n_local; ++q) owners.push_back(owner_new(P.T[2].gather[(size_t)tile.gather_begin + q]));
+                else for (int r = 0; r < tile.run_count; ++r) owners.push_back(owner_new(P.T[tl].runs[(size_t)tile.run_begin + r].start));
+                std::sort(owners.begin(), owners.end());
+                owners.erase(std::unique(owners.begin(), owners.end()), owners.end());
+                uint64_t ht = kSeed;
+                for (int64_t k = tile.order_begin[0]; k < tile.order_end[0]; ++k) {
+                    const int t = P.order_type[0][(size_t)k];
+                    const int32_t *v = C.idx(t, P.order_id[0][(size_t)k]);
+                    mix(ht, (uint64_t)t);
+                    for (int a = 0; a < kVerts[t]; ++a) mix(ht, gid(v[a]));
+                }
+                for (int ow : owners) if (ow != rank) mix(h_tiles[(size_t)ow], ht);
+            }
+        L.pair_hash.assign((size_t)world, 0);
+        for (int pr = 0; pr < world; ++pr) {
+            if (pr == rank) continue;
+            uint64_t h = kSeed;
+            // the lower rank's send lists first: rank a's (send, recv) must be rank b's (recv, send)
+            mix(h, rank < pr ? h_send[(size_t)pr] : h_recv[(size_t)pr]);
+            mix(h, rank < pr ? h_recv[(size_t)pr] : h_send[(size_t)pr]);
+            mix(h, h_tiles[(size_t)pr]);
+            L.pair_hash[(size_t)pr] = h;
         }
     }
     timer.lap("extract_local: tiles + halo");

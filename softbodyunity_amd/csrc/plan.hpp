@@ -28,6 +28,27 @@
 
 namespace sbp {
 
+// The frame a plan's grid is made from: bounding box of the rest pose, mean rest length, particle count. A whole-mesh plan
+// measures it (compute_domain); the ranks of a SHARDED solver -- each plans only its window of the mesh -- are all given the
+// same one, so that every window is cut from one grid (set = true).
+struct Domain {
+    bool set = false;
+    int64_t n_global = 0;
+    double lo[3] = {0, 0, 0}, hi[3] = {0, 0, 0};
+    double ell = 0;
+};
+struct Grid {
+    int kk = 2;                 // cell edge in mean rest lengths (even)
+    double cs = 0, org[3] = {0, 0, 0};
+    int nc[3] = {1, 1, 1};
+    int shift_units = 1;
+    double shift_frac = 0.5, first_t2_frac = 0.75;
+    float ext[3] = {0, 0, 0};
+};
+// cells of margin around a rank's block that its window must cover: the T1 tiles it runs reach less than one cell beyond the
+// block, and the labels of the static split inside them depend on constraints less than one further cell away (plan.cpp)
+constexpr int kWindowMarginCells = 2;
+
 struct Opts {
     int rank = 0, world = 1;
     int dims[3] = {0, 0, 0};
@@ -39,6 +60,7 @@ struct Opts {
     bool cluster_layers = true;     // once few constraints are left, T2 layers are made of connected components instead of grid cells (SB_NO_CLUSTER_LAYERS: A/B runs)
     bool mixed_groups = true;       // colour the constraint types of a tile together (SB_NO_MIXED_GROUPS: one type per group, A/B runs)
     bool bank_aware_lanes = true;   // order the constraints of a round for conflict-free LDS gathers (SB_NO_BANK_ORDER: A/B runs)
+    Domain domain;                  // set: the input is this rank's window of a larger mesh (Input::global_id), block partition only
 };
 
 struct Run {            // a contiguous range of particles
@@ -106,6 +128,7 @@ struct Plan {
     int32_t n = 0;
     int64_t m[3] = {0, 0, 0};
     int dims[3] = {1, 1, 1};
+    Domain domain;              // the frame the grid was made from (measured, or imposed on a sharded plan)
     int partition = 1;          // what the ownership was made with: 1 = block grid (dims), 2 = RCB over T0 cells
     std::vector<int64_t> rank_cost;     // [world] cost units of the particles a rank owns (kCostParticle per particle + the vertex
                                         // shares of their constraints): what the partitioner balances
@@ -150,6 +173,10 @@ struct LocalPlan {
     std::vector<LocalGColour> gcolours;
     std::vector<HaloSlot> halo;             // slot 0 unused, 1 = before T1 kernels, 2+c = before global colour c
     std::vector<uint8_t> order_mask[2];     // which order entries this rank executes
+    // per peer: a hash of everything the two ranks must agree on -- the ghost lists between them (global particle ids, both
+    // directions) and the programs of the tiles both execute (constraint sequence as global particle ids). Symmetric: rank a's
+    // entry for b equals rank b's entry for a exactly when they planned consistently (checked at sb_finalize / peer_link).
+    std::vector<uint64_t> pair_hash;
 };
 
 struct Input {
@@ -158,12 +185,19 @@ struct Input {
     const int32_t *dist_ij; int64_t m_d;
     const int32_t *vol; int64_t m_v;
     const int32_t *bend; int64_t m_b;
+    const int32_t *global_id = nullptr;     // sharded plans: ids of the window's particles in the whole mesh, strictly ascending
 };
 
 // f(chunk, begin, end) for the chunks of [0, n) of `chunk_size` elements, on the planner's host threads (SB_PLAN_THREADS,
 // default min(hardware threads, 16)). The chunking never depends on the thread count. Re-throws the first exception.
 void parallel_for_chunks(int64_t n, int64_t chunk_size, const std::function<void(int64_t, int64_t, int64_t)> &f);
 
+// bounding box + mean rest length of a whole mesh, exactly as build_plan measures them
+void compute_domain(const Input &in, Domain &out);
+Grid make_grid(const Domain &dom, int tile_target);
+// the cells (and the box in rest coordinates, +-1e300 at the rim of the grid) opts.rank's window must cover: its block of the
+// block partition + kWindowMarginCells. opts.tile_particles must be the resolved target (> 0, or -1 for no tiling).
+void rank_window(const Domain &dom, const Opts &opts, int cell_lo[3], int cell_hi[3], double box_lo[3], double box_hi[3]);
 // Throws std::runtime_error on invalid input.
 void build_plan(const Input &in, const Opts &opts, Plan &out);
 void extract_local(const Plan &plan, const Input &in, int rank, LocalPlan &out);

@@ -180,6 +180,9 @@ struct sb_solver {
     // authoring copies
     int32_t n = 0;
     std::vector<float> pos, vel, invm, rest;
+    bool sharded = false;            // sb_set_domain: the authoring arrays are this rank's window of a larger mesh
+    sb_domain domain{};
+    std::vector<int32_t> global_id;  // [n] ids of the window's particles in the whole mesh (sharded only)
     std::vector<int32_t> dist_ij, vol_ijkl, bend_ijkl;
     std::vector<float> dist_rest, vol_rest, bend_rest;
     float compliance[3] = {0, 0, 0};
@@ -230,7 +233,7 @@ struct sb_solver {
     // peer-store halo transport (SB_HALO_TRANSPORT=peer; kernels.hip.hpp): one mailbox per rank = [header words | ghost segments]
     struct PeerState {
         bool enabled = false, linked = false, fine_grained = false;
-        uint32_t *mailbox = nullptr;            // header: words 0-1 = the rank's plan hash; per slot: data flags[world], ack flags[world], epoch, 2 counters; then the offset table
+        uint32_t *mailbox = nullptr;            // header: words 0-1 = the rank's plan hash, 2 = sharded?, 4 .. 4+2W = its pair hashes; per slot: data flags[world], ack flags[world], epoch, 2 counters; then the offset table
         size_t bytes = 0, data_off_words = 0, off_table = 0;
         int n_slots = 0;
         std::vector<uint32_t *> remote;         // [world]: the ranks' mailboxes as this process sees them (own pointer for itself)
@@ -239,7 +242,7 @@ struct sb_solver {
         std::vector<sbk::PeerSlot> slots;
         uint32_t *local = nullptr;              // 8 ordinary (cached) words per slot: epoch, workgroup counters, go words
         uint32_t *h_error = nullptr;            // pinned host word the kernels set when a wait gives up: the host reads it without a copy
-        size_t slot_base(int slot, int world) const { return 2 + (size_t)slot * (2 * (size_t)world + 3); }
+        size_t slot_base(int slot, int world) const { return 4 + 2 * (size_t)world + (size_t)slot * (2 * (size_t)world + 3); }
     } peer;
     // asynchronous render readback (sb_readback_begin / sb_readback_end): two snapshot slots
     hipStream_t copy_stream = nullptr;
@@ -309,9 +312,19 @@ sbp::Input make_input(const float *rest, int32_t n, const int32_t *d, int64_t md
 
 // The planner options behind the ABI's fields: ONE rule for sb_finalize and sb_plan_build, so the CPU schedule a host builds
 // with sb_plan_build is the one the GPU solver of the same mesh runs.
+sbp::Domain to_domain(const sb_domain &d) {
+    sbp::Domain D;
+    D.set = true; D.n_global = d.n_global; D.ell = d.spacing;
+    for (int a = 0; a < 3; ++a) { D.lo[a] = d.lo[a]; D.hi[a] = d.hi[a]; }
+    return D;
+}
 sbp::Opts plan_opts(int rank, int world, const int32_t dims[3], int32_t tile_particles, int32_t partition, uint32_t plan_flags,
-                    int64_t m_v, int64_t m_b) {
+                    int64_t m_v, int64_t m_b, const sb_domain *domain = nullptr) {
     sbp::Opts o;
+    if (domain) {       // sharded: the automatic tile size follows the WHOLE mesh, which only the domain knows
+        o.domain = to_domain(*domain);
+        if (domain->four_vertex_constraints) m_v += 1;
+    }
     o.rank = rank; o.world = world <= 0 ? 1 : world;
     for (int a = 0; a < 3; ++a) o.dims[a] = dims ? dims[a] : 0;
     // automatic tile size: 512 particles for spring meshes (bandwidth-bound: the fewest rim tiles that still fill the chip),
@@ -872,6 +885,8 @@ void build_device(sb_solver *s) {
         PS.data_off_words = (hdr_words + 63) & ~(size_t)63;
         std::vector<uint32_t> header(PS.data_off_words, 0u);
         header[0] = (uint32_t)s->plan_hash; header[1] = (uint32_t)(s->plan_hash >> 32);      // compared by the neighbours (peer_link)
+        header[2] = s->sharded ? 1u : 0u;
+        for (int r = 0; r < W; ++r) { const uint64_t ph = L.pair_hash[(size_t)r]; header[4 + 2 * (size_t)r] = (uint32_t)ph; header[5 + 2 * (size_t)r] = (uint32_t)(ph >> 32); }
         PS.my_off.assign((size_t)PS.n_slots, std::vector<uint32_t>((size_t)W, 0u));
         size_t words = PS.data_off_words;
         for (int slot = 0; slot < PS.n_slots; ++slot) {
@@ -922,14 +937,21 @@ void peer_link(sb_solver *s) {
             if (s->loopback && (cs == 0 || cr == 0)) cs = cr = 0;       // a self-exchange needs both directions
             uint32_t *rm = PS.remote[(size_t)r];
             if ((cs || cr) && !rm) throw HipError(SB_ERR_STATE, "peer transport: the mailbox of rank " + std::to_string(r) + " is not connected (sb_peer_connect)");
-            if ((cs || cr) && !s->loopback) {       // ranks plan independently: the neighbour must have arrived at the same plan
-                uint32_t hw[2] = {0, 0};
-                HIP_CHECK(hipMemcpy(hw, rm, sizeof(hw), hipMemcpyDeviceToHost));
-                const uint64_t theirs = (uint64_t)hw[0] | ((uint64_t)hw[1] << 32);
-                if (theirs != s->plan_hash) {
-                    char msg[256];
+            if ((cs || cr) && !s->loopback) {       // ranks plan independently: the neighbour must have arrived at a matching plan
+                std::vector<uint32_t> hw(4 + 2 * (size_t)W, 0u);
+                HIP_CHECK(hipMemcpy(hw.data(), rm, hw.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+                const uint64_t their_plan = (uint64_t)hw[0] | ((uint64_t)hw[1] << 32);
+                const uint64_t their_pair = (uint64_t)hw[4 + 2 * (size_t)me] | ((uint64_t)hw[5 + 2 * (size_t)me] << 32);
+                const uint64_t my_pair = s->plan->local.pair_hash[(size_t)r];
+                char msg[320];
+                if (!s->sharded && !hw[2] && their_plan != s->plan_hash) {
                     std::snprintf(msg, sizeof msg, "peer transport: rank %d planned a different schedule than rank %d (plan hash %016llx vs %016llx): every rank "
-                                  "must pass the same mesh, tile_particles, partition and plan_flags", r, me, (unsigned long long)theirs, (unsigned long long)s->plan_hash);
+                                  "must pass the same mesh, tile_particles, partition and plan_flags", r, me, (unsigned long long)their_plan, (unsigned long long)s->plan_hash);
+                    throw HipError(SB_ERR_STATE, msg);
+                }
+                if (their_pair != my_pair) {
+                    std::snprintf(msg, sizeof msg, "peer transport: ranks %d and %d disagree on what they share (ghost lists / programs of the tiles both run: pair hash "
+                                  "%016llx vs %016llx)", me, r, (unsigned long long)my_pair, (unsigned long long)their_pair);
                     throw HipError(SB_ERR_STATE, msg);
                 }
             }
@@ -1421,6 +1443,44 @@ int sb_peer_connect(sb_solver *s, int32_t rank, const uint8_t handle[SB_IPC_HAND
     });
 }
 
+int sb_set_domain(sb_solver *s, const sb_domain *domain, const int32_t *global_id, int32_t n) {
+    if (!s || !domain || !global_id) return fail(SB_ERR_INVALID_ARG, "sb_set_domain: null argument");
+    if (s->finalized) return fail(SB_ERR_STATE, "sb_set_domain after sb_finalize");
+    if (n != s->n || n <= 0) return fail(SB_ERR_INVALID_ARG, "sb_set_domain: n differs from sb_set_particles");
+    if (domain->n_global < n || !(domain->spacing > 0) || domain->reserved != 0) return fail(SB_ERR_INVALID_ARG, "sb_set_domain: bad domain");
+    return guarded([&]() -> int {
+        s->domain = *domain;
+        s->global_id.assign(global_id, global_id + n);
+        s->sharded = true;
+        return SB_OK;
+    });
+}
+
+int sb_domain_from_mesh(const float *rest, int32_t n, const int32_t *dist_ij, int32_t m_d, const int32_t *vol, int32_t m_v,
+                        const int32_t *bend, int32_t m_b, sb_domain *out) {
+    if (!rest || !out || n <= 0 || m_d < 0 || m_v < 0 || m_b < 0) return fail(SB_ERR_INVALID_ARG, "sb_domain_from_mesh: bad argument");
+    return guarded([&]() -> int {
+        sbp::Domain D;
+        sbp::compute_domain(make_input(rest, n, dist_ij, m_d, vol, m_v, bend, m_b), D);
+        std::memset(out, 0, sizeof(*out));
+        out->n_global = D.n_global; out->spacing = D.ell;
+        for (int a = 0; a < 3; ++a) { out->lo[a] = D.lo[a]; out->hi[a] = D.hi[a]; }
+        out->four_vertex_constraints = (m_v + m_b > 0) ? 1 : 0;
+        return SB_OK;
+    });
+}
+
+int sb_domain_window(const sb_domain *domain, const sb_plan_opts *opts, double lo_out[3], double hi_out[3]) {
+    if (!domain || !opts || !lo_out || !hi_out) return fail(SB_ERR_INVALID_ARG, "sb_domain_window: null argument");
+    if (opts->world < 1 || opts->rank < 0 || opts->rank >= opts->world) return fail(SB_ERR_INVALID_ARG, "sb_domain_window: bad rank / world");
+    return guarded([&]() -> int {
+        const sbp::Opts o = plan_opts(opts->rank, opts->world, opts->part_dims, opts->tile_particles, SB_PARTITION_BLOCKS, 0u, 0, 0, domain);
+        int clo[3], chi[3];
+        sbp::rank_window(o.domain, o, clo, chi, lo_out, hi_out);
+        return SB_OK;
+    });
+}
+
 int sb_finalize(sb_solver *s) {
     if (!s) return fail(SB_ERR_INVALID_ARG, "sb_finalize: null handle");
     if (s->finalized) return fail(SB_ERR_STATE, "sb_finalize called twice");
@@ -1448,8 +1508,13 @@ int sb_finalize(sb_solver *s) {
         const std::vector<float> &rest = s->rest.empty() ? s->pos : s->rest;
         sbp::Input in = make_input(rest.data(), s->n, s->dist_ij.data(), (int64_t)s->dist_rest.size(), s->vol_ijkl.data(),
                                    (int64_t)s->vol_rest.size(), s->bend_ijkl.data(), (int64_t)s->bend_rest.size() / 2);
+        if (s->sharded) {
+            if (s->desc.world < 2) return fail(SB_ERR_INVALID_ARG, "sb_finalize: sharded authoring (sb_set_domain) is for world > 1");
+            if (s->desc.partition == SB_PARTITION_RCB) return fail(SB_ERR_UNSUPPORTED, "sb_finalize: the RCB partition needs the whole mesh on every rank (no sb_set_domain)");
+            in.global_id = s->global_id.data();
+        }
         sbp::Opts o = plan_opts(s->desc.rank, s->desc.world, s->desc.part_dims, s->desc.tile_particles, s->desc.partition, s->desc.plan_flags,
-                                in.m_v, in.m_b);
+                                in.m_v, in.m_b, s->sharded ? &s->domain : nullptr);
         s->plan = std::make_unique<sb_plan>();
         const bool timing = std::getenv("SB_PLAN_TIMING") != nullptr;
         auto t0 = std::chrono::steady_clock::now();
@@ -1480,22 +1545,38 @@ int sb_finalize(sb_solver *s) {
         // order, ownership, halo slots, plan options). One 8-byte all-gather over the communicator; the peer transport without
         // a communicator compares the hashes when the mailboxes are linked (peer_link).
         if (s->desc.world > 1 && s->comm && !s->loopback) {
+            // per rank: [sharded?, plan hash, pair hash with rank 0 .. W-1]
             const int W = s->desc.world;
+            const size_t rec = (size_t)W + 2;
+            std::vector<uint64_t> mine(rec, 0);
+            mine[0] = s->sharded ? 1 : 0; mine[1] = s->plan_hash;
+            for (int r = 0; r < W; ++r) mine[2 + (size_t)r] = s->plan->local.pair_hash[(size_t)r];
             DevBuf<uint64_t> d_all; int64_t acct = 0;
-            d_all.alloc((size_t)W, acct);
-            HIP_CHECK(hipMemcpy(d_all.p + s->desc.rank, &s->plan_hash, sizeof(uint64_t), hipMemcpyHostToDevice));
-            NCCL_CHECK(rccl().AllGather(d_all.p + s->desc.rank, d_all.p, sizeof(uint64_t), ncclUint8, s->comm, s->stream));
+            d_all.alloc((size_t)W * rec, acct);
+            HIP_CHECK(hipMemcpy(d_all.p + (size_t)s->desc.rank * rec, mine.data(), rec * sizeof(uint64_t), hipMemcpyHostToDevice));
+            NCCL_CHECK(rccl().AllGather(d_all.p + (size_t)s->desc.rank * rec, d_all.p, rec * sizeof(uint64_t), ncclUint8, s->comm, s->stream));
             HIP_CHECK(hipStreamSynchronize(s->stream));
-            std::vector<uint64_t> all((size_t)W);
-            HIP_CHECK(hipMemcpy(all.data(), d_all.p, (size_t)W * sizeof(uint64_t), hipMemcpyDeviceToHost));
-            for (int r = 0; r < W; ++r)
-                if (all[(size_t)r] != s->plan_hash) {
-                    char msg[256];
+            std::vector<uint64_t> all((size_t)W * rec);
+            HIP_CHECK(hipMemcpy(all.data(), d_all.p, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
+            for (int r = 0; r < W; ++r) {
+                if (r == s->desc.rank) continue;
+                const uint64_t *theirs = all.data() + (size_t)r * rec;
+                char msg[320];
+                // whole-mesh ranks must hold the identical plan; any two ranks must agree on what they share (ghost lists both ways,
+                // programs of the tiles both run) -- the only check a sharded rank, which sees just its window, can make
+                if (!s->sharded && !theirs[0] && theirs[1] != s->plan_hash) {
                     std::snprintf(msg, sizeof msg, "sb_finalize: rank %d planned a different schedule than rank %d (plan hash %016llx vs %016llx): "
                                   "every rank must pass the same mesh, tile_particles, partition and plan_flags", r, s->desc.rank,
-                                  (unsigned long long)all[(size_t)r], (unsigned long long)s->plan_hash);
+                                  (unsigned long long)theirs[1], (unsigned long long)s->plan_hash);
                     return fail(SB_ERR_STATE, msg);
                 }
+                if (theirs[2 + (size_t)s->desc.rank] != mine[2 + (size_t)r]) {
+                    std::snprintf(msg, sizeof msg, "sb_finalize: ranks %d and %d disagree on what they share (ghost lists / programs of the tiles both run: pair hash "
+                                  "%016llx vs %016llx): same mesh, domain, tile_particles, partition and plan_flags on every rank? window complete (sb_domain_window)?",
+                                  s->desc.rank, r, (unsigned long long)mine[2 + (size_t)r], (unsigned long long)theirs[2 + (size_t)s->desc.rank]);
+                    return fail(SB_ERR_STATE, msg);
+                }
+            }
         }
         if (s->overlap_halo) {
             // opt-in: on the one measurement available (RCCL loopback on one GPU, 8-rank share of 256^3) splitting the T0
@@ -1996,9 +2077,11 @@ int sb_plan_build(const float *rest, int32_t n, const int32_t *dist_ij, int32_t 
         if (opts && (opts->partition < SB_PARTITION_AUTO || opts->partition > SB_PARTITION_RCB)) return fail(SB_ERR_INVALID_ARG, "sb_plan_build: bad partition");
         if (opts && (opts->plan_flags & ~kPlanFlagsAll)) return fail(SB_ERR_INVALID_ARG, "sb_plan_build: unknown bit in plan_flags");
         // (opts == NULL: every field 0 -- one rank, automatic tile size by the same rule as sb_finalize)
-        const sbp::Opts o = opts ? plan_opts(opts->rank, opts->world, opts->part_dims, opts->tile_particles, opts->partition, opts->plan_flags, m_v, m_b)
+        if (opts && ((opts->domain != nullptr) != (opts->global_id != nullptr))) return fail(SB_ERR_INVALID_ARG, "sb_plan_build: domain and global_id go together");
+        const sbp::Opts o = opts ? plan_opts(opts->rank, opts->world, opts->part_dims, opts->tile_particles, opts->partition, opts->plan_flags, m_v, m_b, opts->domain)
                                  : plan_opts(0, 1, nullptr, 0, SB_PARTITION_AUTO, 0u, m_v, m_b);
         sbp::Input in = make_input(rest, n, dist_ij, m_d, vol, m_v, bend, m_b);
+        if (opts && opts->domain) in.global_id = opts->global_id;
         auto p = std::make_unique<sb_plan>();
         sbp::build_plan(in, o, p->plan);
         sbp::extract_local(p->plan, in, o.rank, p->local);
@@ -2095,6 +2178,11 @@ int sb_plan_get_halo(const sb_plan *p, int32_t slot, int32_t peer, int32_t *send
     // published as caller-numbering (global) particle ids
     if (send_ids) for (size_t k = 0; k < H.send_idx[peer].size(); ++k) send_ids[k] = p->local.local_to_old[H.send_idx[peer][k]];
     if (recv_ids) for (size_t k = 0; k < H.recv_idx[peer].size(); ++k) recv_ids[k] = p->local.local_to_old[H.recv_idx[peer][k]];
+    return SB_OK;
+}
+int sb_plan_get_pair_hashes(const sb_plan *p, uint64_t *out) {
+    if (!p || !out) return fail(SB_ERR_INVALID_ARG, "sb_plan_get_pair_hashes: null");
+    for (int r = 0; r < p->local.world; ++r) out[r] = p->local.pair_hash.empty() ? 0 : p->local.pair_hash[(size_t)r];
     return SB_OK;
 }
 int sb_plan_get_local_order_mask(const sb_plan *p, int32_t parity, uint8_t *out) {

@@ -23,6 +23,9 @@ class SoftbodyMesh:
     bend_ijkl: np.ndarray = field(default_factory=lambda: np.zeros((0, 4), np.int32))
     bend_rest: np.ndarray = field(default_factory=lambda: np.zeros((0, 2), np.float32))  # (cos,sin) of rest dihedral
     label: str = ""
+    # sharded authoring (include/softbody.h sb_domain): this mesh is one rank's WINDOW of a larger mesh
+    domain: object = None           # native.SbDomain of the whole mesh
+    global_id: np.ndarray = None    # (N,) i32 ids of the window's particles in the whole mesh, ascending
 
     @property
     def n(self):
@@ -90,6 +93,54 @@ def jelly_cube(n, spacing=1.0, perturb=0.05, seed=1234, pin_top=False, stencil="
         w.reshape(n, n, n)[:, n - 1, :] = 0.0
     return SoftbodyMesh(rest_pos=rest, pos=pos, vel=np.zeros_like(pos), inv_mass=w, dist_ij=ij,
                         dist_rest=rest_len, label=f"jelly_cube_{n}^3_{stencil}" + ("_heterogeneous" if heterogeneous else ""))
+
+
+def jelly_cube_window(n, rank, world, part_dims=(0, 0, 0), tile_particles=512, spacing=1.0, perturb=0.05, seed=1234, pin_top=False):
+    """The part of jelly_cube(n) rank `rank` of `world` hands over under sharded authoring: the lattice points inside the box
+    sb_domain_window gives for it, the structural springs among them (x, then y, then z, each in ascending order of the lower end
+    point: the whole cube's order restricted to the window), ids of the whole cube in `global_id`. Positions are the whole cube's
+    (the jitter stream is drawn for the window's planes only: O(window) memory, identical values)."""
+    from . import native
+    N = n ** 3
+    hi_c = float(np.float32(n - 1) * np.float32(spacing))
+    dom = native.make_domain(N, (0.0, 0.0, 0.0), (hi_c, hi_c, hi_c), float(np.float32(spacing)))
+    lo, hi = native.domain_window(dom, rank, world, part_dims, tile_particles)
+    ax = (np.arange(n, dtype=np.float32) * np.float32(spacing)).astype(np.float64)
+    rng_idx = []
+    for a in range(3):
+        inside = np.nonzero((ax >= lo[a]) & (ax < hi[a]))[0]
+        rng_idx.append((int(inside[0]), int(inside[-1]) + 1))
+    (x0, x1), (y0, y1), (z0, z1) = rng_idx
+    wx, wy, wz = x1 - x0, y1 - y0, z1 - z0
+    gz, gy, gx = np.meshgrid(np.arange(z0, z1), np.arange(y0, y1), np.arange(x0, x1), indexing="ij")
+    gid = ((gz.astype(np.int64) * n + gy) * n + gx).reshape(-1)
+    axf = np.arange(n, dtype=np.float32) * np.float32(spacing)
+    rest = np.stack([axf[gx.reshape(-1)], axf[gy.reshape(-1)], axf[gz.reshape(-1)]], axis=1)
+    # the whole cube draws rng.uniform(size=(N, 3)) row by row: plane iz of the cube is rows [iz n^2, (iz+1) n^2) of that stream
+    rng = np.random.default_rng(seed)
+    jit = np.empty((wz, wy, wx, 3), np.float64)
+    bg = rng.bit_generator
+    plane_doubles = n * n * 3
+    bg.advance(z0 * plane_doubles)                 # PCG64: one 64-bit draw per double
+    for k in range(wz):
+        pl = rng.uniform(-perturb, perturb, size=(n, n, 3))
+        jit[k] = pl[y0:y1, x0:x1]
+    jit *= spacing
+    pos = (jit.reshape(-1, 3) + rest).astype(np.float32)
+    lidx = np.arange(wx * wy * wz, dtype=np.int32).reshape(wz, wy, wx)
+    edges = []
+    for lo_s, off in ((lidx[:, :, :-1], 1), (lidx[:, :-1, :], wx), (lidx[:-1, :, :], wx * wy)):
+        a = lo_s.reshape(-1)
+        edges.append(np.stack([a, a + off], axis=1))
+    ij = np.concatenate(edges).astype(np.int32)
+    w = np.ones(len(gid), np.float32)
+    if pin_top:
+        w[gy.reshape(-1) == n - 1] = 0.0
+    m = SoftbodyMesh(rest_pos=rest, pos=pos, vel=np.zeros_like(pos), inv_mass=w, dist_ij=ij,
+                     dist_rest=np.full(ij.shape[0], spacing, np.float32), label=f"jelly_cube_{n}^3_window_of_rank_{rank}/{world}")
+    m.domain = dom
+    m.global_id = gid.astype(np.int32)
+    return m
 
 
 def _blob_inside(p):

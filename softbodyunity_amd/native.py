@@ -55,9 +55,14 @@ class SbStats(C.Structure):
         return out
 
 
+class SbDomain(C.Structure):
+    _fields_ = [("n_global", C.c_int64), ("lo", C.c_double * 3), ("hi", C.c_double * 3), ("spacing", C.c_double),
+                ("four_vertex_constraints", C.c_int32), ("reserved", C.c_int32)]
+
+
 class SbPlanOpts(C.Structure):
     _fields_ = [("rank", C.c_int32), ("world", C.c_int32), ("part_dims", C.c_int32 * 3), ("tile_particles", C.c_int32),
-                ("partition", C.c_int32), ("plan_flags", C.c_uint32)]
+                ("partition", C.c_int32), ("plan_flags", C.c_uint32), ("domain", C.POINTER(SbDomain)), ("global_id", C.c_void_p)]
 
 
 class SbRuntimeInfo(C.Structure):
@@ -84,6 +89,9 @@ SIGNATURES = {
     "sb_set_volume_constraints": (C.c_int, [_P, _P, _P, C.c_int32, C.c_float]),
     "sb_set_bending_constraints": (C.c_int, [_P, _P, _P, C.c_int32, C.c_float]),
     "sb_set_ground_plane": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32]),
+    "sb_set_domain": (C.c_int, [_P, C.POINTER(SbDomain), _P, C.c_int32]),
+    "sb_domain_from_mesh": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, C.c_int32, C.POINTER(SbDomain)]),
+    "sb_domain_window": (C.c_int, [C.POINTER(SbDomain), C.POINTER(SbPlanOpts), C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "sb_finalize": (C.c_int, [_P]),
     "sb_comm_unique_id": (C.c_int, [_P]),
     "sb_comm_init": (C.c_int, [_P, _P]),
@@ -126,6 +134,7 @@ SIGNATURES = {
     "sb_plan_halo_slot_count": (C.c_int32, [_P]),
     "sb_plan_halo_counts": (C.c_int, [_P, C.c_int32, _P, _P]),
     "sb_plan_get_halo": (C.c_int, [_P, C.c_int32, C.c_int32, _P, _P]),
+    "sb_plan_get_pair_hashes": (C.c_int, [_P, _P]),
     "sb_plan_get_local_order_mask": (C.c_int, [_P, C.c_int32, _P]),
     "sb_runtime_info": (C.c_int, [C.POINTER(SbRuntimeInfo)]),
     "sb_last_error": (C.c_char_p, []),
@@ -214,6 +223,32 @@ def runtime_info():
             "rccl_library": ri.rccl_library.decode()}
 
 
+def domain_from_mesh(rest_pos, dist_ij=None, vol_ijkl=None, bend_ijkl=None):
+    """sb_domain of a whole mesh (the frame a sharded solver's ranks all pass)."""
+    rest = f32(rest_pos, (-1, 3))
+    d = i32(dist_ij if dist_ij is not None else np.zeros((0, 2)), (-1, 2))
+    v = i32(vol_ijkl if vol_ijkl is not None else np.zeros((0, 4)), (-1, 4))
+    b = i32(bend_ijkl if bend_ijkl is not None else np.zeros((0, 4)), (-1, 4))
+    out = SbDomain()
+    check(lib().sb_domain_from_mesh(ptr(rest), rest.shape[0], ptr(d), d.shape[0], ptr(v), v.shape[0], ptr(b), b.shape[0], C.byref(out)))
+    return out
+
+
+def make_domain(n_global, lo, hi, spacing, four_vertex_constraints=False):
+    d = SbDomain()
+    d.n_global = int(n_global); d.lo[:] = [float(c) for c in lo]; d.hi[:] = [float(c) for c in hi]
+    d.spacing = float(spacing); d.four_vertex_constraints = 1 if four_vertex_constraints else 0
+    return d
+
+
+def domain_window(domain, rank, world, part_dims=(0, 0, 0), tile_particles=0):
+    """(lo, hi) of the box of rest positions rank must hand over under sharded authoring (lo inclusive, hi exclusive)."""
+    o = SbPlanOpts(rank, world, (C.c_int32 * 3)(*part_dims), tile_particles, SB_PARTITION_BLOCKS, 0, None, None)
+    lo = (C.c_double * 3)(); hi = (C.c_double * 3)()
+    check(lib().sb_domain_window(C.byref(domain), C.byref(o), lo, hi))
+    return np.array(lo[:]), np.array(hi[:])
+
+
 class Plan:
     """Read-only view of a planner result (sb_plan_*). Owns the handle unless borrowed from a solver."""
 
@@ -223,14 +258,16 @@ class Plan:
 
     @classmethod
     def build(cls, rest_pos, dist_ij=None, vol_ijkl=None, bend_ijkl=None, rank=0, world=1, part_dims=(0, 0, 0),
-              tile_particles=0, partition=SB_PARTITION_AUTO, plan_flags=None):
+              tile_particles=0, partition=SB_PARTITION_AUTO, plan_flags=None, domain=None, global_id=None):
         L = lib()
         rest = f32(rest_pos, (-1, 3))
         d = i32(dist_ij if dist_ij is not None else np.zeros((0, 2)), (-1, 2))
         v = i32(vol_ijkl if vol_ijkl is not None else np.zeros((0, 4)), (-1, 4))
         b = i32(bend_ijkl if bend_ijkl is not None else np.zeros((0, 4)), (-1, 4))
+        gid = None if global_id is None else i32(global_id, (-1,))
         o = SbPlanOpts(rank, world, (C.c_int32 * 3)(*part_dims), tile_particles, partition,
-                       plan_flags_from_env() if plan_flags is None else plan_flags)
+                       plan_flags_from_env() if plan_flags is None else plan_flags,
+                       C.pointer(domain) if domain is not None else None, ptr(gid))
         h = C.c_void_p()
         check(L.sb_plan_build(ptr(rest), rest.shape[0], ptr(d), d.shape[0], ptr(v), v.shape[0], ptr(b), b.shape[0],
                               C.byref(o), C.byref(h)))
@@ -313,6 +350,12 @@ class Plan:
             s = np.zeros(sc[peer], np.int32); r = np.zeros(rc[peer], np.int32)
             check(L.sb_plan_get_halo(self._h, slot, peer, ptr(s), ptr(r)))
             out[peer] = (s, r)
+        return out
+
+    def pair_hashes(self):
+        """(world,) uint64: what this rank and each peer must agree on (sb_plan_get_pair_hashes)."""
+        out = np.zeros(self.world, np.uint64)
+        check(lib().sb_plan_get_pair_hashes(self._h, ptr(out)))
         return out
 
     def local_order_mask(self, parity=0):

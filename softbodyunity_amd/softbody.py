@@ -103,6 +103,9 @@ class Softbody:
             check(L.sb_comm_init(h, buf))
         if self.ground_plane is not None:
             check(L.sb_set_ground_plane(h, *[float(c) for c in self.ground_plane], 1))
+        if getattr(m, "domain", None) is not None:      # sharded authoring: `m` is this rank's window of a larger mesh
+            gid = i32(m.global_id, (-1,))
+            check(L.sb_set_domain(h, C.byref(m.domain), ptr(gid), self.n))
         check(L.sb_finalize(h))
         self.vertices = pos.copy()
 

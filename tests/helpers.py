@@ -73,6 +73,31 @@ class RankSim:
         return [(ph, be) for ph, be in zip(phases, off) if ph["kind"] == 0]
 
 
+class WindowRankSim(RankSim):
+    """RankSim on a window mesh: same machinery, plan built from the window + domain."""
+
+    def __init__(self, oracle_mod, win, rank, world, dims, tile):
+        self.plan = native.Plan.build(win.rest_pos, win.dist_ij, rank=rank, world=world, part_dims=dims, tile_particles=tile,
+                                      domain=win.domain, global_id=win.global_id)
+        self.rank, self.world = rank, world
+        self.gid = win.global_id.astype(np.int64)
+        self.o = make_oracle(oracle_mod, win, None)
+        self.local = []
+        for parity in (0, 1):
+            t, ids = self.plan.order(parity)
+            mask = self.plan.local_order_mask(parity).astype(bool)
+            csum = np.concatenate([[0], np.cumsum(mask)])
+            phases = self.plan.phases(parity)
+            off = [(int(csum[p["order_begin"]]), int(csum[p["order_end"]])) for p in phases]
+            self.local.append((np.ascontiguousarray(t[mask]), np.ascontiguousarray(ids[mask]), phases, off))
+        self.owner = self.plan.owner(win.n)
+        self.owned = self.owner == rank
+        self.halos = [self.plan.halo(k, world) for k in range(self.plan.halo_slot_count())]
+        loc, _ = self.plan.local_particles()
+        held = np.zeros(win.n, bool); held[loc] = True
+        self.o.x[~held] = np.nan
+
+
 def _exchange_memcpy(ranks, slot, with_prev):
     staged = []
     for R in ranks:

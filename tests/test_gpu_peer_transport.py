@@ -27,10 +27,13 @@ def _worker(rank, world, port, mesh_kind, graph, out_dir):
         os.environ["SB_GRAPH_RCCL"] = "1"          # capture the tick (exchange kernels included) in the hipGraph
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from softbodyunity_amd import Softbody, native
-    from softbodyunity_amd.mesh import bunny_surrogate, jelly_cube
-    mesh = jelly_cube(24, pin_top=True) if mesh_kind == "cube" else bunny_surrogate(target_verts=3000, seed=9)
-    comp = (0.0, 0.0, 0.0) if mesh_kind == "cube" else (1e-7, 1e-7, 1e-4)
-    sb = Softbody(mesh, substeps=6, device=0, rank=rank, world=world, tile_particles=64 if mesh_kind == "cube" else 128,
+    from softbodyunity_amd.mesh import bunny_surrogate, jelly_cube, jelly_cube_window
+    if mesh_kind == "window":       # sharded authoring: this process hands over only its window of the 32^3 cube (sb_set_domain)
+        mesh = jelly_cube_window(32, rank, world, (0, 0, 0), 64, pin_top=True)
+    else:
+        mesh = jelly_cube(24, pin_top=True) if mesh_kind == "cube" else bunny_surrogate(target_verts=3000, seed=9)
+    comp = (1e-7, 1e-7, 1e-4) if mesh_kind == "bunny" else (0.0, 0.0, 0.0)
+    sb = Softbody(mesh, substeps=6, device=0, rank=rank, world=world, tile_particles=128 if mesh_kind == "bunny" else 64,
                   distance_compliance=comp[0], volume_compliance=comp[1], bending_compliance=comp[2]).Start()   # no communicator: the host connects
     L = native.lib()
     mine = np.zeros(native.SB_IPC_HANDLE_BYTES, np.uint8)
@@ -46,27 +49,31 @@ def _worker(rank, world, port, mesh_kind, graph, out_dir):
         sb.step()
     x = sb.get_positions(); v = sb.get_velocities()
     np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=x, v=v, owned=sb.owner() == rank,
+             gid=mesh.global_id if mesh_kind == "window" else np.arange(mesh.n),
              ghosts=np.array(sb.stats()["n_particles_local"] - sb.stats()["n_particles_owned"]))
+    sb.synchronize()
     dist.barrier()              # nobody unmaps a mailbox a neighbour may still be writing to
     sb.OnDestroy()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world,mesh_kind,graph", [(2, "cube", False), (4, "cube", True), (3, "bunny", False), (2, "bunny", True)])
+@pytest.mark.parametrize("world,mesh_kind,graph", [(2, "cube", False), (4, "cube", True), (3, "bunny", False), (2, "bunny", True),
+                                                   (4, "window", False), (2, "window", True)])
 def test_ranks_as_processes_through_the_peer_transport(tmp_path, oracle_mod, world, mesh_kind, graph):
     from softbodyunity_amd.mesh import bunny_surrogate, jelly_cube
     from helpers import build_plan, make_oracle
     port = 29300 + (os.getpid() % 1500) + world * 11 + (5 if graph else 0)
     mp.spawn(_worker, args=(world, port, mesh_kind, graph, str(tmp_path)), nprocs=world, join=True)
-    mesh = jelly_cube(24, pin_top=True) if mesh_kind == "cube" else bunny_surrogate(target_verts=3000, seed=9)
-    comp = (0.0, 0.0, 0.0) if mesh_kind == "cube" else (1e-7, 1e-7, 1e-4)
-    ref = make_oracle(oracle_mod, mesh, build_plan(mesh, tile_particles=64 if mesh_kind == "cube" else 128), compliance=comp)
+    mesh = (jelly_cube(32, pin_top=True) if mesh_kind == "window" else jelly_cube(24, pin_top=True)) if mesh_kind != "bunny" else bunny_surrogate(target_verts=3000, seed=9)
+    comp = (1e-7, 1e-7, 1e-4) if mesh_kind == "bunny" else (0.0, 0.0, 0.0)
+    ref = make_oracle(oracle_mod, mesh, build_plan(mesh, tile_particles=128 if mesh_kind == "bunny" else 64), compliance=comp)
     for _ in range(3):
         ref.step(0.02, 6)
     x = np.zeros_like(ref.x); v = np.zeros_like(ref.v); cover = np.zeros(mesh.n, int); ghosts = 0
     for r in range(world):
         d = np.load(tmp_path / f"rank{r}.npz")
-        x[d["owned"]] = d["x"][d["owned"]]; v[d["owned"]] = d["v"][d["owned"]]; cover += d["owned"]; ghosts += int(d["ghosts"])
+        g = d["gid"][d["owned"]]
+        x[g] = d["x"][d["owned"]]; v[g] = d["v"][d["owned"]]; cover[g] += 1; ghosts += int(d["ghosts"])
     assert np.all(cover == 1) and ghosts > 0
     assert np.array_equal(x.view(np.uint32), ref.x.view(np.uint32))
     assert np.array_equal(v.view(np.uint32), ref.v.view(np.uint32))

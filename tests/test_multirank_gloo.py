@@ -13,15 +13,20 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, tile, out_dir):
+def _worker(rank, world, port, tile, out_dir, sharded=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from oracle import oracle
-    from softbodyunity_amd.mesh import jelly_cube
-    from helpers import RankSim, run_tick
-    mesh = jelly_cube(16, pin_top=True)
-    R = RankSim(oracle, mesh, rank, world, (0, 0, 0), tile, (0.0, -9.81, 0.0), 0.0, (1e-7, 0.0, 0.0))
+    from softbodyunity_amd.mesh import jelly_cube, jelly_cube_window
+    from helpers import RankSim, WindowRankSim, run_tick
+    if sharded:      # sharded authoring: this process only ever sees its window of the 32^3 cube
+        win = jelly_cube_window(32, rank, world, (0, 0, 0), tile, pin_top=True)
+        R = WindowRankSim(oracle, win, rank, world, (0, 0, 0), tile)
+        R.o.params.compliance[0] = 1e-7
+    else:
+        mesh = jelly_cube(16, pin_top=True)
+        R = RankSim(oracle, mesh, rank, world, (0, 0, 0), tile, (0.0, -9.81, 0.0), 0.0, (1e-7, 0.0, 0.0))
     S, dt = 6, 0.02
 
     def exchange(slot, with_prev):
@@ -46,7 +51,7 @@ def _worker(rank, world, port, tile, out_dir):
     for _ in range(2):
         s = R.o.scalars(dt, S)
         run_tick([R], s, S, tile > 0, exchange)
-    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=R.o.x, v=R.o.v, owned=R.owned)
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=R.o.x, v=R.o.v, owned=R.owned, gid=getattr(R, "gid", np.arange(len(R.owned))))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -69,3 +74,23 @@ def test_two_ranks_gloo_equals_single(tmp_path, oracle_mod, tile):
     assert np.all(cover == 1)
     assert np.array_equal(x.view(np.uint32), ref.x.view(np.uint32))
     assert np.array_equal(v.view(np.uint32), ref.v.view(np.uint32))
+
+
+def test_four_ranks_gloo_on_their_windows_equal_single(tmp_path, oracle_mod):
+    # sharded authoring end to end over a real process boundary: no process holds the whole 32^3 cube
+    from softbodyunity_amd.mesh import jelly_cube
+    from helpers import build_plan, make_oracle
+    world, tile = 4, 64
+    port = 29500 + (os.getpid() % 2000) + 7
+    mp.spawn(_worker, args=(world, port, tile, str(tmp_path), True), nprocs=world, join=True)
+    mesh = jelly_cube(32, pin_top=True)
+    ref = make_oracle(oracle_mod, mesh, build_plan(mesh, tile_particles=tile), compliance=(1e-7, 0.0, 0.0))
+    for _ in range(2):
+        ref.step(0.02, 6)
+    x = np.zeros_like(ref.x); v = np.zeros_like(ref.v); cover = np.zeros(mesh.n, int)
+    for r in range(world):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        g = d["gid"][d["owned"]]
+        x[g] = d["x"][d["owned"]]; v[g] = d["v"][d["owned"]]; cover[g] += 1
+    assert np.all(cover == 1)
+    assert np.array_equal(x.view(np.uint32), ref.x.view(np.uint32)) and np.array_equal(v.view(np.uint32), ref.v.view(np.uint32))
