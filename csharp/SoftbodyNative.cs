@@ -48,7 +48,7 @@ namespace SoftbodyMI355X
         public long partitionCost, partitionCostMax, partitionCostTotal;
         public long haloParticlesRecv;
         public ulong planHash;
-        public int haloSchedule, reserved;
+        public int haloSchedule, haloUnpackFused;
     }
 
     [StructLayout(LayoutKind.Sequential, CharSet = CharSet.Ansi)]
@@ -78,6 +78,7 @@ namespace SoftbodyMI355X
         public long nGlobal;
         public double loX, loY, loZ, hiX, hiY, hiZ;
         public double spacing;
+        public double fill;          // fraction of the bounding box the mesh occupies (1 for a lattice)
         public int fourVertexConstraints, reserved;
     }
 
@@ -95,6 +96,7 @@ namespace SoftbodyMI355X
         public const int UniqueIdBytes = 128;
         public const int PartitionAuto = 0, PartitionBlocks = 1, PartitionRcb = 2;
         public const uint PlanNoT2 = 1, PlanNoThirdList = 2, PlanNoClusterLayers = 4, PlanNoMixedGroups = 8, PlanNoBankOrder = 16;
+        public static uint PlanBalancedLists(int n) => (uint)n << 8;   // irregular meshes: 1..3 balanced extra lists; 0 = default (2)
         public const int TransportRccl = 0, TransportPeer = 1;
         public const int ScheduleAuto = 0, ScheduleSerialEager = 1, ScheduleSerialGraph = 2, ScheduleOverlapEager = 3, ScheduleOverlapGraph = 4;
 

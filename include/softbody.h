@@ -59,6 +59,7 @@ typedef struct sb_plan sb_plan;     /* opaque, plugin-owned */
 #define SB_PLAN_NO_CLUSTER_LAYERS 4u   /* T2 layers from grids only */
 #define SB_PLAN_NO_MIXED_GROUPS   8u   /* one constraint type per group of a tile */
 #define SB_PLAN_NO_BANK_ORDER    16u   /* keep the colouring order inside a group (no LDS-bank-aware lane order) */
+#define SB_PLAN_BALANCED_LISTS(n) ((uint32_t)(n) << 8)   /* irregular meshes: 1..3 balanced extra lists (grids) beside T0 / T1; 0 = default (2) */
 
 /* Ghost exchange of a world > 1 solver. */
 #define SB_TRANSPORT_RCCL 0            /* pack -> grouped ncclSend/ncclRecv -> unpack (default) */
@@ -121,6 +122,7 @@ typedef struct {
     int64_t n_global;                 /* particles of the whole mesh */
     double  lo[3], hi[3];             /* bounding box of the whole rest pose */
     double  spacing;                  /* mean rest length of the whole mesh's distance constraints */
+    double  fill;                     /* fraction of the bounding box the mesh occupies, in (0, 1]; 1 for a lattice (0 is read as 1) */
     int32_t four_vertex_constraints;  /* the whole mesh has volume or bending constraints (automatic tile size: 256 instead of 512) */
     int32_t reserved;
 } sb_domain;
@@ -243,7 +245,7 @@ typedef struct {
     int64_t halo_particles_recv;                    /* ghosts received per refresh, all slots */
     uint64_t plan_hash;                             /* hash of the published orders, ownership and plan options: equal on every rank */
     int32_t halo_schedule;                          /* SB_SCHEDULE_* in force (what AUTO resolved to) */
-    int32_t reserved;
+    int32_t halo_unpack_fused;                      /* 1 = the T1 kernels read their ghosts straight from the receive buffer (no unpack launch) */
 } sb_stats;
 int sb_get_stats(sb_solver *s, sb_stats *out);
 

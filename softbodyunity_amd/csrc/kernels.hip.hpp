@@ -97,6 +97,11 @@ struct TileArgs {
     int32_t w_uniform;        // WPAL kernels: every particle has the same inverse mass -> all lanes read index 0 (one cache line, no per-particle byte)
     int32_t item_waves;       // waves per tile the wave items of this tiling were dealt for (0 = none)
     int32_t store_through;    // bit 0: previous positions, bit 1: positions are stored through the L2 (small launches, see store3_through)
+    // GHOSTS kernels (world > 1, T1 launches of a lattice-type plan): particle g >= n_owned is ghost g - n_owned and its position
+    // and previous position are read straight from the receive buffer of the exchange that just ended (6 floats per ghost, in
+    // ghost order) instead of from the arrays -- the unpack kernel between the exchange and this launch is gone
+    const float *ghost_src;
+    int32_t n_owned;
 };
 
 // Lanes per tile (template parameter THREADS of tile_kernel). A round holds up to kRoundSlots independent constraints,
@@ -414,7 +419,7 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // Register budget (HIP: second launch-bound = waves per SIMD). LDS allows ~14 tiles per CU, so aim for that many waves.
 template <bool QUADS, int THREADS> constexpr int kWavesPerSimd = QUADS ? (THREADS == 64 ? 3 : (THREADS == 512 ? 2 : 4)) : (THREADS == 256 ? 8 : (THREADS == 128 ? 6 : 4));   // 128 lanes: 7 waves (72 VGPRs) measured 1 % slower, 8 spill
 // WPAL = inverse masses are read as one-byte palette indices (the palette entry comes from another lane by ds_bpermute).
-template <int KIND, bool QUADS, int THREADS, int PPT, bool WPAL>
+template <int KIND, bool QUADS, int THREADS, int PPT, bool WPAL, bool GHOSTS = false>
 __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile_kernel(const TileDesc *tiles_at_base, int n_workgroups, TileArgs A) {
     // The first two arguments (3 dwords) are preloaded into SGPRs at dispatch (-mllvm -amdgpu-kernarg-preload-count=3, Makefile):
     // the descriptor fetch starts with the kernel instead of behind the kernel-argument load (one memory round trip less on the
@@ -516,10 +521,16 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
 #pragma unroll
     for (int m = 0; m < PPT; ++m) {
         const int gc = max(g[m], 0);
-        X[m].x = A.pos.xyz[3 * (size_t)gc + 0]; X[m].y = A.pos.xyz[3 * (size_t)gc + 1]; X[m].z = A.pos.xyz[3 * (size_t)gc + 2];
+        // (GHOSTS: a select of the address, not a branch around the load -- see above)
+        const bool ghost = GHOSTS && gc >= A.n_owned;
+        const float *px = ghost ? A.ghost_src + 6 * (size_t)(gc - A.n_owned) : A.pos.xyz + 3 * (size_t)gc;
+        X[m].x = px[0]; X[m].y = px[1]; X[m].z = px[2];
         if (WPAL) { wi[m] = A.w8[A.w_uniform ? 0 : gc]; X[m].w = 0.0f; } else { wi[m] = 0; X[m].w = A.pos.w[gc]; }
         pvx[m] = pvy[m] = pvz[m] = 0.0f;
-        if (KIND != 0 && KIND != 3) { pvx[m] = A.prev[3 * (size_t)gc + 0]; pvy[m] = A.prev[3 * (size_t)gc + 1]; pvz[m] = A.prev[3 * (size_t)gc + 2]; }
+        if (KIND != 0 && KIND != 3) {
+            const float *pp = ghost ? px + 3 : A.prev + 3 * (size_t)gc;
+            pvx[m] = pp[0]; pvy[m] = pp[1]; pvz[m] = pp[2];
+        }
     }
     const bool rounds_in_lds = n_rounds_all <= A.rounds_dwords;
     const uint32_t rw = tstream[max(min(tid, n_rounds_all - 1), 0)];        // (an empty program still has a 16-byte header)

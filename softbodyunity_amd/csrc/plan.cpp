@@ -282,6 +282,30 @@ void compute_domain(const Input &in, Domain &dom) {
     dom.n_global = n;
     for (int a = 0; a < 3; ++a) { dom.lo[a] = lo[a]; dom.hi[a] = hi[a]; }
     dom.ell = ell;
+    // Which fraction of the bounding box the mesh fills: a coarse occupancy count (cells of 4 mean rest lengths). A lattice fills
+    // its box (1.0, and anything above 0.8 is read as 1.0 so that no regular mesh's grid moves); a bunny fills 40 % of its box,
+    // and a grid sized for the box's average density would give it cells of 2.5 x the particles asked for, every one of them
+    // median-split along one axis -- whose split planes then coincide from grid to grid (plan.cpp static split).
+    dom.fill = 1.0;
+    {
+        double cell = 4.0 * ell;
+        int64_t nd[3];
+        for (;;) {
+            for (int a = 0; a < 3; ++a) nd[a] = std::max<int64_t>(1, (int64_t)std::ceil((hi[a] - lo[a] + ell) / cell));
+            if (nd[0] * nd[1] * nd[2] <= ((int64_t)1 << 24)) break;
+            cell *= 2.0;
+        }
+        std::vector<uint8_t> occ((size_t)(nd[0] * nd[1] * nd[2]), 0);
+        for (int64_t p = 0; p < n; ++p) {
+            int64_t c[3];
+            for (int a = 0; a < 3; ++a) c[a] = std::min<int64_t>(nd[a] - 1, std::max<int64_t>(0, (int64_t)std::floor((in.rest[3 * p + a] - (lo[a] - 0.5 * ell)) / cell)));
+            occ[(size_t)((c[2] * nd[1] + c[1]) * nd[0] + c[0])] = 1;
+        }
+        int64_t used = 0;
+        for (uint8_t o : occ) used += o;
+        const double f = (double)used / (double)occ.size();
+        if (f <= 0.8) dom.fill = f;
+    }
 }
 
 Grid make_grid(const Domain &dom, int target) {
@@ -289,7 +313,7 @@ Grid make_grid(const Domain &dom, int target) {
     const double ell = dom.ell;
     for (int a = 0; a < 3; ++a) G.ext[a] = (float)(dom.hi[a] - dom.lo[a] + ell);
     {
-        double density = (double)dom.n_global / ((double)G.ext[0] * G.ext[1] * G.ext[2]);
+        double density = (double)dom.n_global / ((double)G.ext[0] * G.ext[1] * G.ext[2] * dom.fill);
         double per = density * ell * ell * ell;  // particles per ell^3
         G.kk = (int)std::lround(std::cbrt(target / std::max(per, 1e-9)));
         G.kk = std::max(G.kk, 2);
@@ -709,7 +733,11 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
     // side is a set of complete matchings; on irregular meshes it halves the constraint degree of every particle
     // per side, i.e. the number of rounds per tile.
     std::vector<uint8_t> own[3];
-    std::vector<int64_t> layer0_key;       // third list: tile of the third grid per particle (empty: the first T2 layer uses plain grid cells)
+    // balanced extra lists (irregular meshes): per list the tile of its grid per particle, and the grid's shift; constraints assigned
+    // to list e carry own code kOwnBalanced + e until the T2 layer e is built from them
+    constexpr uint8_t kOwnBalanced = 20;
+    std::vector<std::vector<int64_t>> bal_key;
+    std::vector<double> bal_frac;
     {
         std::vector<std::vector<uint8_t>> bucket(3);
         std::vector<std::vector<int8_t>> label(3);      // -2: not tiled (global), -1: free, 0/1: assigned
@@ -782,76 +810,123 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
                 parallel_chunks(C.count(t), 1 << 20, [&](int64_t, int64_t kb, int64_t ke) {
                     for (int64_t k = kb; k < ke; ++k) if (label[t][k] >= 0) own[t][k] = (uint8_t)label[t][k];
                 });
-        // Third list. On an irregular mesh the constraints that cross the OTHER tiling's planes are forced into one list, so
-        // nearly every tile holds a particle with ~56 of the tile's constraints and needs that many groups. The first T2 layer
-        // is a third grid (shift first_t2_frac): a constraint inside one of its cells may join it instead -- it does whenever
-        // that strictly lowers the larger of the two per-list degrees among its particles. The layer then carries a balanced
-        // share of the mesh (a third list, walked between the other two in every substep) instead of the leftovers only.
+        // Balanced extra lists. On an irregular mesh the constraints that cross the OTHER tiling's planes are forced into one list:
+        // with two lists nearly every tile holds a particle with ~56 of the tile's constraints and needs that many groups; with a
+        // third grid 37 of a hub particle's ~70 constraints are still forced into one of three lists (they cross planes of the
+        // other two), and a tile's program is as long as its busiest particle's share. The first n_bal T2 layers are therefore
+        // further GRIDS (each in the middle of the widest gap between the planes already in use) that carry a balanced share of
+        // the mesh: a constraint may sit in any list whose tile holds all its particles, and moves wherever that strictly lowers
+        // the largest per-list degree among its particles. With four lists only one constraint in sixty is still forced.
         // Only meshes with leftovers are touched: a structural lattice (none) keeps its two perfect lists.
         if (tiling && opts.third_tiling && opts.third_list) {
             bool any_left = false;
             for (int t = 0; t < 3 && !any_left; ++t) for (int64_t k = 0; k < C.count(t); ++k) if (own[t][k] == 2) { any_left = true; break; }
             if (any_left) {
-                // the third grid's cells, over-full ones median-split like the cells of T0 and T1 (a mesh that fills only part
-                // of its bounding box has cells far above the average)
-                std::vector<int64_t> &cellm = layer0_key;
-                cellm.assign((size_t)n, 0);
-                parallel_chunks(n, 1 << 18, [&](int64_t, int64_t pb, int64_t pe) {
-                    for (int64_t q = pb; q < pe; ++q) {
-                        int64_t s3[3];
-                        for (int a = 0; a < 3; ++a) {
-                            double r = (in.rest[3 * q + a] - org[a]) / cs;
-                            s3[a] = std::min(std::max((int)std::floor(r - first_t2_frac) + 1, 0), nc[a]);
-                        }
-                        cellm[q] = (s3[2] * (nc[1] + 1) + s3[1]) * (nc[0] + 1) + s3[0];
-                    }
-                });
+                const int n_bal = std::min(std::max(opts.balanced_lists, 1), kMaxBalancedLists);
+                bal_key.assign((size_t)n_bal, {});
                 {
+                    std::vector<double> pl = {0.0, shift_frac, 1.0};
+                    for (int e = 0; e < n_bal; ++e) {
+                        size_t g = 0;
+                        for (size_t q = 1; q + 1 < pl.size(); ++q) if (pl[q + 1] - pl[q] > pl[g + 1] - pl[g] + 1e-12) g = q;
+                        const double frac = pl[g] + 0.5 * (pl[g + 1] - pl[g]);
+                        pl.insert(pl.begin() + (std::ptrdiff_t)g + 1, frac);
+                        bal_frac.push_back(frac);
+                    }
+                }
+                for (int e = 0; e < n_bal; ++e) {
+                    // the grid's cells, over-full ones median-split like the cells of T0 and T1 (a mesh that fills only part of its
+                    // bounding box has cells far above the average)
+                    std::vector<int64_t> &cellm = bal_key[(size_t)e];
+                    const double frac = bal_frac[(size_t)e];
+                    cellm.assign((size_t)n, 0);
+                    parallel_chunks(n, 1 << 18, [&](int64_t, int64_t pb, int64_t pe) {
+                        for (int64_t q = pb; q < pe; ++q) {
+                            int64_t s3[3];
+                            for (int a = 0; a < 3; ++a) {
+                                double r = (in.rest[3 * q + a] - org[a]) / cs;
+                                s3[a] = std::min(std::max((int)std::floor(r - frac) + 1, 0), nc[a]);
+                            }
+                            cellm[q] = (s3[2] * (nc[1] + 1) + s3[1]) * (nc[0] + 1) + s3[0];
+                        }
+                    });
                     std::vector<int32_t> bym(n);
                     std::iota(bym.begin(), bym.end(), 0);
                     std::sort(bym.begin(), bym.end(), [&](int32_t a, int32_t b2) { return cellm[a] != cellm[b2] ? cellm[a] < cellm[b2] : a < b2; });
                     std::vector<int32_t> begins;
                     for (int32_t b2 = 0; b2 < n;) {
-                        int32_t e = b2 + 1;
-                        while (e < n && cellm[bym[e]] == cellm[bym[b2]]) ++e;
-                        split_group(bym, b2, e, cap, true, in.rest, begins);
-                        b2 = e;
+                        int32_t e2 = b2 + 1;
+                        while (e2 < n && cellm[bym[e2]] == cellm[bym[b2]]) ++e2;
+                        split_group(bym, b2, e2, cap, true, in.rest, begins);
+                        b2 = e2;
                     }
                     begins.push_back(n);
                     for (size_t c = 0; c + 1 < begins.size(); ++c)
-                        for (int32_t q = begins[c]; q < begins[c + 1]; ++q) cellm[bym[q]] = (int64_t)c;      // tile id of the third grid
+                        for (int32_t q = begins[c]; q < begins[c + 1]; ++q) cellm[bym[q]] = (int64_t)c;      // tile id of this grid
                 }
-                std::vector<uint8_t> in_m[3];
-                std::vector<int32_t> deg[3];
-                for (auto &d : deg) d.assign((size_t)n, 0);
+                // lists: 0 = S0 (T0 tiles), 1 = S1 (T1 tiles), 2 + e = balanced list e. opt[t][k]: bit L set = the constraint's
+                // particles share a tile of list L; cur[t][k]: the list it sits in (-1: inside none -- left for the later layers)
+                const int n_lists = 2 + n_bal;
+                std::vector<uint8_t> opt[3];
+                std::vector<int8_t> cur[3];
+                std::vector<std::vector<int32_t>> deg((size_t)n_lists, std::vector<int32_t>((size_t)n, 0));
                 for (int t = 0; t < 3; ++t) {
-                    in_m[t].assign((size_t)C.count(t), 0);
-                    for (int64_t k = 0; k < C.count(t); ++k) {
-                        const int32_t *v = C.idx(t, k);
-                        bool same = true;
-                        for (int a = 1; a < kVerts[t]; ++a) same &= cellm[v[a]] == cellm[v[0]];
-                        in_m[t][k] = same;
-                        const int lst = own[t][k] == 2 ? (same ? 2 : -1) : own[t][k];
-                        if (lst >= 0) for (int a = 0; a < kVerts[t]; ++a) ++deg[lst][v[a]];
-                    }
+                    opt[t].assign((size_t)C.count(t), 0);
+                    cur[t].assign((size_t)C.count(t), -1);
+                    parallel_chunks(C.count(t), 1 << 18, [&](int64_t, int64_t kb, int64_t ke) {
+                        for (int64_t k = kb; k < ke; ++k) {
+                            const int32_t *v = C.idx(t, k);
+                            uint8_t o = cls[t][k];
+                            for (int e = 0; e < n_bal; ++e) {
+                                bool same = true;
+                                for (int a = 1; a < kVerts[t]; ++a) same &= bal_key[(size_t)e][v[a]] == bal_key[(size_t)e][v[0]];
+                                if (same) o |= (uint8_t)(4u << e);
+                            }
+                            opt[t][k] = o;
+                            int c = own[t][k] <= 1 ? own[t][k] : -1;
+                            if (c < 0) for (int e = 0; e < n_bal && c < 0; ++e) if (o & (4u << e)) c = 2 + e;
+                            cur[t][k] = (int8_t)c;
+                        }
+                    });
+                    for (int64_t k = 0; k < C.count(t); ++k)
+                        if (cur[t][k] >= 0) { const int32_t *v = C.idx(t, k); for (int a = 0; a < kVerts[t]; ++a) ++deg[(size_t)cur[t][k]][v[a]]; }
                 }
-                for (int pass = 0; pass < 8; ++pass) {
+                for (int pass = 0; pass < 12; ++pass) {
                     int64_t moved = 0;
                     for (int t = 0; t < 3; ++t)
                         for (int64_t k = 0; k < C.count(t); ++k) {
-                            const int a = own[t][k];
-                            if (a > 1 || !in_m[t][k]) continue;
+                            const int a = cur[t][k];
+                            if (a < 0) continue;
                             const int32_t *v = C.idx(t, k);
-                            int32_t here = 0, there = 0;
-                            for (int q = 0; q < kVerts[t]; ++q) { here = std::max(here, deg[a][v[q]]); there = std::max(there, deg[2][v[q]]); }
-                            if (there + 1 < here) {
-                                for (int q = 0; q < kVerts[t]; ++q) { --deg[a][v[q]]; ++deg[2][v[q]]; }
-                                own[t][k] = 2;
+                            int32_t here = 0;
+                            for (int q = 0; q < kVerts[t]; ++q) here = std::max(here, deg[(size_t)a][v[q]]);
+                            int best = -1; int32_t best_there = INT32_MAX;
+                            for (int L = 0; L < n_lists; ++L) {
+                                if (L == a || !((opt[t][k] >> L) & 1u)) continue;
+                                int32_t there = 0;
+                                for (int q = 0; q < kVerts[t]; ++q) there = std::max(there, deg[(size_t)L][v[q]]);
+                                if (there < best_there) { best_there = there; best = L; }
+                            }
+                            if (best >= 0 && best_there + 1 < here) {
+                                for (int q = 0; q < kVerts[t]; ++q) { --deg[(size_t)a][v[q]]; ++deg[(size_t)best][v[q]]; }
+                                cur[t][k] = (int8_t)best;
                                 ++moved;
                             }
                         }
                     if (!moved) break;
                 }
+                if (timer.on) {
+                    for (int L = 0; L < n_lists; ++L) {
+                        int32_t mx = 0; std::vector<int32_t> forced((size_t)n, 0);
+                        for (int32_t q = 0; q < n; ++q) mx = std::max(mx, deg[(size_t)L][q]);
+                        for (int t = 0; t < 3; ++t) for (int64_t k = 0; k < C.count(t); ++k)
+                            if (opt[t][k] == (1u << L)) { const int32_t *v = C.idx(t, k); for (int a = 0; a < kVerts[t]; ++a) ++forced[v[a]]; }
+                        int32_t fm = 0; for (int32_t q = 0; q < n; ++q) fm = std::max(fm, forced[q]);
+                        std::fprintf(stderr, "[plan] list %d: max degree %d, max forced degree %d\n", L, mx, fm);
+                    }
+                }
+                for (int t = 0; t < 3; ++t)
+                    for (int64_t k = 0; k < C.count(t); ++k) own[t][k] = cur[t][k] < 0 ? 2 : (cur[t][k] < 2 ? (uint8_t)cur[t][k] : (uint8_t)(kOwnBalanced + cur[t][k] - 2));
             }
         }
     }
@@ -1066,16 +1141,18 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
         // golden-ratio walk, skipping positions within 6 % of a cell of any plane already in use
         std::vector<double> planes = {0.0, shift_frac, 1.0};
         double next_frac = first_t2_frac;
+        const int n_bal = (int)bal_key.size();
         for (int layer = 0; layer < kMaxT2Layers; ++layer) {
-            double frac = next_frac;
-            for (int tries = 0; tries < 32; ++tries) {
+            const bool keyed = layer < n_bal;       // a balanced list: its grid and its constraints were chosen by the static split
+            double frac = keyed ? bal_frac[(size_t)layer] : next_frac;
+            for (int tries = 0; !keyed && tries < 32; ++tries) {
                 bool close = false;
                 for (double pl : planes) close |= std::fabs(frac - pl) < 0.06;
                 if (!close) break;
                 frac += 0.381966011250105; frac -= std::floor(frac);
             }
             planes.push_back(frac);
-            next_frac = frac + 0.381966011250105; next_frac -= std::floor(next_frac);
+            if (!keyed || layer + 1 == n_bal) { next_frac = frac + 0.381966011250105; next_frac -= std::floor(next_frac); }
             auto cell2 = [&](int32_t q) {
                 int64_t s3[3];
                 for (int a = 0; a < 3; ++a) {
@@ -1085,16 +1162,17 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
                 return (s3[2] * (nc[1] + 1) + s3[1]) * (nc[0] + 1) + s3[0];
             };
             cand.clear();
+            const uint8_t want = keyed ? (uint8_t)(kOwnBalanced + layer) : (uint8_t)2;
             int64_t left = 0;
             for (int t = 0; t < 3; ++t)
-                for (int64_t k = 0; k < C.count(t); ++k) left += own[t][k] == 2;
-            if (left == 0) break;
+                for (int64_t k = 0; k < C.count(t); ++k) left += own[t][k] == want;
+            if (left == 0) { if (keyed) continue; break; }
             // Few constraints left (they sit where the planes of the grids already tried cross): another grid would catch
             // only part of them and every further layer is one more launch per substep. Cluster layer instead: the
             // connected components of what is left become the sparse tiles -- a component shares no particle with any
             // other, so they all fit ONE layer; only a component of more than kMaxTileLocal particles is cut, and the
             // constraints across the cut wait for the next layer.
-            const bool cluster = opts.cluster_layers && layer > 0 && left <= std::max<int64_t>(4096, (P.m[0] + P.m[1] + P.m[2]) / 50);
+            const bool cluster = opts.cluster_layers && !keyed && layer > 0 && left <= std::max<int64_t>(4096, (P.m[0] + P.m[1] + P.m[2]) / 50);
             if (cluster) {
                 std::vector<int32_t> &parent = uf_parent;
                 if (parent.empty()) parent.assign((size_t)n, -1);        // -1: not touched in this layer
@@ -1148,12 +1226,11 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
             } else {
                 for (int t = 0; t < 3; ++t)
                     for (int64_t k = 0; k < C.count(t); ++k) {
-                        if (own[t][k] != 2) continue;
+                        if (own[t][k] != want) continue;
                         const int32_t *v = C.idx(t, k);
-                        const bool keyed = layer == 0 && !layer0_key.empty();
-                        const int64_t c0 = keyed ? layer0_key[v[0]] : cell2(v[0]);
+                        const int64_t c0 = keyed ? bal_key[(size_t)layer][v[0]] : cell2(v[0]);
                         bool same = true;
-                        for (int a = 1; a < kVerts[t]; ++a) same &= (keyed ? layer0_key[v[a]] : cell2(v[a])) == c0;
+                        for (int a = 1; a < kVerts[t]; ++a) same &= (keyed ? bal_key[(size_t)layer][v[a]] : cell2(v[a])) == c0;
                         if (same) cand.push_back({c0, (uint8_t)t, (int32_t)k});
                     }
             }
@@ -1190,6 +1267,8 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
                     T2.max_local = std::max(T2.max_local, t.n_local);
                     T2.tiles.push_back(t);
                     for (size_t q = b; q < e; ++q) own[cand[q].type][cand[q].id] = code;
+                } else if (keyed) {
+                    for (size_t q = b; q < e; ++q) own[cand[q].type][cand[q].id] = 2;       // (back to the leftovers: later layers / global colours)
                 }
                 b = e;
             }

@@ -228,6 +228,7 @@ struct sb_solver {
     int narrow_min_tiles = 10240;    // SB_NARROW_MIN_TILES; measured crossover: 160^3 (8000 tiles) ties, 192^3 (13824) +4 % narrow
     size_t lds_pad = 0;              // SB_LDS_PAD bytes of unused LDS per workgroup (occupancy experiments)
     bool pack_tiles = true;          // SB_NO_PACK unset: under-full tiles share a workgroup (build_device)
+    bool fused_unpack = false;       // the T1 kernels read ghosts from the receive buffer: no unpack launch behind the slot-1 exchange
     bool graph_rccl = false;         // a multi-rank tick, exchange included, is captured in the hipGraph (SB_SCHEDULE_*_GRAPH)
     std::vector<float> h_stage;
     // peer-store halo transport (SB_HALO_TRANSPORT=peer; kernels.hip.hpp): one mailbox per rank = [header words | ghost segments]
@@ -314,7 +315,7 @@ sbp::Input make_input(const float *rest, int32_t n, const int32_t *d, int64_t md
 // with sb_plan_build is the one the GPU solver of the same mesh runs.
 sbp::Domain to_domain(const sb_domain &d) {
     sbp::Domain D;
-    D.set = true; D.n_global = d.n_global; D.ell = d.spacing;
+    D.set = true; D.n_global = d.n_global; D.ell = d.spacing; D.fill = d.fill > 0 && d.fill <= 1 ? d.fill : 1.0;
     for (int a = 0; a < 3; ++a) { D.lo[a] = d.lo[a]; D.hi[a] = d.hi[a]; }
     return D;
 }
@@ -336,9 +337,10 @@ sbp::Opts plan_opts(int rank, int world, const int32_t dims[3], int32_t tile_par
     o.cluster_layers = !(plan_flags & SB_PLAN_NO_CLUSTER_LAYERS);
     o.mixed_groups = !(plan_flags & SB_PLAN_NO_MIXED_GROUPS);
     o.bank_aware_lanes = !(plan_flags & SB_PLAN_NO_BANK_ORDER);
+    if ((plan_flags >> 8) & 3u) o.balanced_lists = (int)((plan_flags >> 8) & 3u);
     return o;
 }
-constexpr uint32_t kPlanFlagsAll = SB_PLAN_NO_T2 | SB_PLAN_NO_THIRD_LIST | SB_PLAN_NO_CLUSTER_LAYERS | SB_PLAN_NO_MIXED_GROUPS | SB_PLAN_NO_BANK_ORDER;
+constexpr uint32_t kPlanFlagsAll = SB_PLAN_NO_T2 | SB_PLAN_NO_THIRD_LIST | SB_PLAN_NO_CLUSTER_LAYERS | SB_PLAN_NO_MIXED_GROUPS | SB_PLAN_NO_BANK_ORDER | SB_PLAN_BALANCED_LISTS(3);
 
 // 64-bit FNV-1a over everything the ranks of a partitioned solver must agree on: the published orders, who owns which
 // particle, the phase list with its halo slots, and the options that shaped them. (The halo lists are functions of these.)
@@ -353,7 +355,7 @@ uint64_t hash_plan(const sbp::Plan &P) {
     };
     const int32_t head[8] = {P.n, P.opts.world, P.opts.tile_particles, P.partition,
                              (int32_t)((P.opts.third_tiling ? 0 : 1) | (P.opts.third_list ? 0 : 2) | (P.opts.cluster_layers ? 0 : 4) |
-                                       (P.opts.mixed_groups ? 0 : 8) | (P.opts.bank_aware_lanes ? 0 : 16)),
+                                       (P.opts.mixed_groups ? 0 : 8) | (P.opts.bank_aware_lanes ? 0 : 16) | (P.opts.balanced_lists << 8)),
                              P.dims[0], P.dims[1], P.dims[2]};
     mix(head, sizeof(head));
     mix(P.m, sizeof(P.m));
@@ -874,6 +876,20 @@ void build_device(sb_solver *s) {
     }
     s->d_sendbuf.alloc(max_send, s->dev_bytes);
     s->d_recvbuf.alloc(max_recv, s->dev_bytes);
+    if (max_recv) HIP_CHECK(hipMemset(s->d_recvbuf.p, 0, max_recv * sizeof(float)));
+    // Fused unpack. Ownership is contiguous in the planner's numbering and a rank's ghosts are numbered in that order, so when the
+    // exchange before the T1 kernels is the plan's ONLY exchange (lattice-type plans: no T2 layers, no global colours) its
+    // receive buffer -- peers in rank order, each peer's ghosts in its own order -- IS the ghost range [n_owned, n_local) in
+    // order. The T1 kernels then read ghost k at 6 k floats into the buffer (tile_kernel GHOSTS) and the unpack launch is dropped.
+    s->fused_unpack = false;
+    if (L.world > 1 && !s->peer.enabled && P.tiling && P.gcolours.empty() && P.t2_layers.empty() && !s->tiling[1].has_quads &&
+        s->halos.size() > 1 && !std::getenv("SB_NO_FUSED_UNPACK")) {
+        std::vector<int32_t> ridx;
+        for (int peer = 0; peer < L.world; ++peer) ridx.insert(ridx.end(), L.halo[1].recv_idx[(size_t)peer].begin(), L.halo[1].recv_idx[(size_t)peer].end());
+        bool identity = (int64_t)ridx.size() == s->n_local - s->n_owned && !ridx.empty();
+        for (size_t k = 0; identity && k < ridx.size(); ++k) identity = ridx[k] == (int32_t)(s->n_owned + (int64_t)k);
+        s->fused_unpack = identity;
+    }
     if (s->peer.enabled && L.world > 1) {
         // the mailbox: header words, then one segment per (halo slot, sending rank) in slot order, ranks increasing
         auto &PS = s->peer;
@@ -1036,7 +1052,7 @@ void halo_exchange(sb_solver *s, int slot, hipStream_t st = nullptr) {
         throw;
     }
     NCCL_CHECK(rccl().GroupEnd());
-    if (nr) {
+    if (nr && !(with_prev && s->fused_unpack)) {
         if (with_prev)
             hipLaunchKernelGGL(sbk::halo_unpack_kernel<true>, dim3((nr + 255) / 256), dim3(256), 0, st, s->pos_view(),
                                s->d_prev.p, D.recv_idx.p, s->d_recvbuf.p, nr);
@@ -1047,7 +1063,7 @@ void halo_exchange(sb_solver *s, int slot, hipStream_t st = nullptr) {
 }
 
 template <int KIND>
-void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = -1) {
+void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = -1, bool ghosts = false) {
     if (tile_end < 0) tile_end = D.n_tiles;
     if (tile_end <= tile_begin) return;
     sbk::TileArgs A{};
@@ -1058,6 +1074,7 @@ void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = 
     A.w_uniform = s->w_uniform ? 1 : 0;
     A.item_waves = D.item_waves;
     A.store_through = tile_end - tile_begin <= s->store_through_max_tiles ? 3 : s->store_through_large;
+    A.ghost_src = ghosts ? s->d_recvbuf.p : nullptr; A.n_owned = (int32_t)s->n_owned;
     A.max_local = D.max_local; A.win_dwords = D.win_dwords; A.tile_base = tile_begin; A.pal_dwords = D.pal_dwords; A.rounds_dwords = D.rounds_dwords;
     const sbk::TileDesc *tiles_at_base = D.tiles.p + tile_begin;      // the two preloaded kernel arguments (tile_kernel)
     const int n_wg = tile_end - tile_begin;
@@ -1067,22 +1084,29 @@ void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = 
     // tiles with tets / hinges: optionally 8 waves, so that a group's wave slots (16 four-lane constraints or 64 springs each) fit one row
     const bool quad8 = D.has_quads && s->quad_lanes == sbk::kQuadTileThreads;
     const dim3 grid(tile_end - tile_begin), block(quad8 ? sbk::kQuadTileThreads : (narrow ? sbk::kNarrowTileThreads : sbk::kWideTileThreads));
-#define SB_LAUNCH_TILE(Q, W)                                                                                                  \
+#define SB_LAUNCH_TILE(Q, W, G)                                                                                               \
     do {                                                                                                                      \
         if (Q && quad8) {                                                                                                     \
-            if (small) hipLaunchKernelGGL((sbk::tile_kernel<KIND, true, sbk::kQuadTileThreads, sbk::kSmallTile / sbk::kQuadTileThreads, W>), \
+            if (small) hipLaunchKernelGGL((sbk::tile_kernel<KIND, true, sbk::kQuadTileThreads, sbk::kSmallTile / sbk::kQuadTileThreads, W, false>), \
                                           grid, block, D.lds_bytes + s->lds_pad, s->stream, tiles_at_base, n_wg, A);                                           \
-            else hipLaunchKernelGGL((sbk::tile_kernel<KIND, true, sbk::kQuadTileThreads, sbk::kLargeTile / sbk::kQuadTileThreads, W>), \
+            else hipLaunchKernelGGL((sbk::tile_kernel<KIND, true, sbk::kQuadTileThreads, sbk::kLargeTile / sbk::kQuadTileThreads, W, false>), \
                                     grid, block, D.lds_bytes + s->lds_pad, s->stream, tiles_at_base, n_wg, A);                                                 \
-        } else if (narrow) hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kNarrowTileThreads, sbk::kSmallTile / sbk::kNarrowTileThreads, W>), \
+        } else if (narrow) hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kNarrowTileThreads, sbk::kSmallTile / sbk::kNarrowTileThreads, W, G>), \
                                        grid, block, D.lds_bytes + s->lds_pad, s->stream, tiles_at_base, n_wg, A);                                              \
-        else if (small) hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kWideTileThreads, sbk::kSmallTile / sbk::kWideTileThreads, W>), \
+        else if (small) hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kWideTileThreads, sbk::kSmallTile / sbk::kWideTileThreads, W, G>), \
                                            grid, block, D.lds_bytes + s->lds_pad, s->stream, tiles_at_base, n_wg, A);                                          \
-        else hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kWideTileThreads, sbk::kLargeTile / sbk::kWideTileThreads, W>), \
+        else hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kWideTileThreads, sbk::kLargeTile / sbk::kWideTileThreads, W, G>), \
                                 grid, block, D.lds_bytes + s->lds_pad, s->stream, tiles_at_base, n_wg, A);                                                     \
     } while (0)
-    if (s->w_palette) { if (D.has_quads) SB_LAUNCH_TILE(true, true); else SB_LAUNCH_TILE(false, true); }
-    else { if (D.has_quads) SB_LAUNCH_TILE(true, false); else SB_LAUNCH_TILE(false, false); }
+    // the ghost-reading variant exists for the kernels that can meet ghosts behind a fused exchange: mid-tick and last kernels of
+    // spring-only tilings (enqueue_substeps decides; s->fused_unpack is never set for a tiling with tets / hinges)
+    constexpr bool kCanGhost = KIND == 1 || KIND == 2;
+    if (ghosts && !(kCanGhost && !D.has_quads)) throw std::runtime_error("internal: ghost-reading tile kernel requested for a launch that has none");
+    if (kCanGhost && ghosts) {
+        if (s->w_palette) SB_LAUNCH_TILE(false, true, kCanGhost); else SB_LAUNCH_TILE(false, false, kCanGhost);
+    } else
+    if (s->w_palette) { if (D.has_quads) SB_LAUNCH_TILE(true, true, false); else SB_LAUNCH_TILE(false, true, false); }
+    else { if (D.has_quads) SB_LAUNCH_TILE(true, false, false); else SB_LAUNCH_TILE(false, false, false); }
 #undef SB_LAUNCH_TILE
 }
 
@@ -1105,9 +1129,10 @@ void launch_tick_kernel(sb_solver *s, int it, int substeps, LaunchTimer *lt, int
     const int tl = s->plan->plan.tiling ? (it & 1) : 0;
     DevTiling &D = s->tiling[tl];
     if (lt && D.n_tiles) lt->begin(it == 0 ? 2 + (int)s->gcolours.size() : (it == substeps ? 3 + (int)s->gcolours.size() : tl));
+    const bool ghosts = s->fused_unpack && tl == 1;      // T1 tiles read their ghosts straight from the receive buffer
     if (it == 0) launch_tile<0>(s, D, tile_begin, tile_end);
-    else if (it < substeps) launch_tile<1>(s, D, tile_begin, tile_end);
-    else launch_tile<2>(s, D, tile_begin, tile_end);
+    else if (it < substeps) launch_tile<1>(s, D, tile_begin, tile_end, ghosts);
+    else launch_tile<2>(s, D, tile_begin, tile_end, ghosts);
     if (lt && D.n_tiles) lt->end();
 }
 
@@ -1463,7 +1488,7 @@ int sb_domain_from_mesh(const float *rest, int32_t n, const int32_t *dist_ij, in
         sbp::Domain D;
         sbp::compute_domain(make_input(rest, n, dist_ij, m_d, vol, m_v, bend, m_b), D);
         std::memset(out, 0, sizeof(*out));
-        out->n_global = D.n_global; out->spacing = D.ell;
+        out->n_global = D.n_global; out->spacing = D.ell; out->fill = D.fill;
         for (int a = 0; a < 3; ++a) { out->lo[a] = D.lo[a]; out->hi[a] = D.hi[a]; }
         out->four_vertex_constraints = (m_v + m_b > 0) ? 1 : 0;
         return SB_OK;
@@ -1761,7 +1786,9 @@ int sb_debug_halo_unpack(sb_solver *s, int32_t slot, const float *host_in, int64
         if (need == 0) return SB_OK;
         if (!host_in) return fail(SB_ERR_INVALID_ARG, "sb_debug_halo_unpack: null buffer");
         HIP_CHECK(hipMemcpyAsync(s->d_recvbuf.p, host_in, (size_t)need * sizeof(float), hipMemcpyHostToDevice, s->stream));
-        if (slot == 1)
+        if (slot == 1 && s->fused_unpack) {
+            // (the T1 kernels read the ghosts from the receive buffer: nothing to scatter)
+        } else if (slot == 1)
             hipLaunchKernelGGL(sbk::halo_unpack_kernel<true>, dim3((nr + 255) / 256), dim3(256), 0, s->stream, s->pos_view(), s->d_prev.p,
                                D.recv_idx.p, s->d_recvbuf.p, nr);
         else
@@ -2051,6 +2078,7 @@ int sb_get_stats(sb_solver *s, sb_stats *out) {
     }
     out->partition = P.partition;
     out->halo_schedule = s->schedule;
+    out->halo_unpack_fused = s->fused_unpack ? 1 : 0;
     out->plan_hash = s->plan_hash;
     if (!P.rank_cost.empty()) {
         out->partition_cost = P.rank_cost[(size_t)s->desc.rank];

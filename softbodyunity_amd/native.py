@@ -45,7 +45,7 @@ class SbStats(C.Structure):
                 ("launch_bytes", C.c_int64 * 5), ("partition", C.c_int32), ("halo_peers", C.c_int32),
                 ("partition_cost", C.c_int64), ("partition_cost_max", C.c_int64), ("partition_cost_total", C.c_int64),
                 ("halo_particles_recv", C.c_int64), ("plan_hash", C.c_uint64), ("halo_schedule", C.c_int32),
-                ("reserved", C.c_int32)]
+                ("halo_unpack_fused", C.c_int32)]
 
     def as_dict(self):
         out = {}
@@ -56,7 +56,7 @@ class SbStats(C.Structure):
 
 
 class SbDomain(C.Structure):
-    _fields_ = [("n_global", C.c_int64), ("lo", C.c_double * 3), ("hi", C.c_double * 3), ("spacing", C.c_double),
+    _fields_ = [("n_global", C.c_int64), ("lo", C.c_double * 3), ("hi", C.c_double * 3), ("spacing", C.c_double), ("fill", C.c_double),
                 ("four_vertex_constraints", C.c_int32), ("reserved", C.c_int32)]
 
 
@@ -194,7 +194,8 @@ _PLAN_FLAG_ENV = (("SB_NO_T2", SB_PLAN_NO_T2), ("SB_NO_THIRD_LIST", SB_PLAN_NO_T
 
 
 def plan_flags_from_env():
-    return sum(bit for name, bit in _PLAN_FLAG_ENV if os.environ.get(name))
+    lists = int(os.environ.get("SB_BALANCED_LISTS", "0") or 0) & 3       # irregular meshes: 1..3 balanced extra lists (0 = the default, 2)
+    return sum(bit for name, bit in _PLAN_FLAG_ENV if os.environ.get(name)) | (lists << 8)
 
 
 def halo_transport_from_env():
@@ -237,7 +238,7 @@ def domain_from_mesh(rest_pos, dist_ij=None, vol_ijkl=None, bend_ijkl=None):
 def make_domain(n_global, lo, hi, spacing, four_vertex_constraints=False):
     d = SbDomain()
     d.n_global = int(n_global); d.lo[:] = [float(c) for c in lo]; d.hi[:] = [float(c) for c in hi]
-    d.spacing = float(spacing); d.four_vertex_constraints = 1 if four_vertex_constraints else 0
+    d.spacing = float(spacing); d.fill = 1.0; d.four_vertex_constraints = 1 if four_vertex_constraints else 0
     return d
 
 

@@ -43,7 +43,7 @@ def test_struct_layouts_match_header():
     # sb_desc: 3 + 3 ints, 3 + 1 floats, 2 ints (ABI 5) + partition, plan_flags, transport, schedule, debug_flags, 3 reserved = 80
     # bytes; sb_phase_info has int64 alignment
     assert C.sizeof(native.SbDesc) == 80
-    assert C.sizeof(native.SbPlanOpts) == 48 and C.sizeof(native.SbDomain) == 8 + 8 * 7 + 8
+    assert C.sizeof(native.SbPlanOpts) == 48 and C.sizeof(native.SbDomain) == 8 + 8 * 8 + 8
     assert C.sizeof(native.SbPhaseInfo) == 48
     assert C.sizeof(native.SbStats) == 8 * 2 + 8 * 3 + 4 * 2 + 8 * 4 + 8 * 5 + 8 * 3 + 8 * 5 + (4 * 2 + 8 * 3 + 8 + 8 + 4 * 2)
     assert C.sizeof(native.SbRuntimeInfo) == 8 * 4 + 2 * 256
