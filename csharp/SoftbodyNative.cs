@@ -95,7 +95,7 @@ namespace SoftbodyMI355X
         const CallingConvention CC = CallingConvention.Cdecl;
         public const int UniqueIdBytes = 128;
         public const int PartitionAuto = 0, PartitionBlocks = 1, PartitionRcb = 2;
-        public const uint PlanNoT2 = 1, PlanNoThirdList = 2, PlanNoClusterLayers = 4, PlanNoMixedGroups = 8, PlanNoBankOrder = 16;
+        public const uint PlanNoT2 = 1, PlanNoThirdList = 2, PlanNoClusterLayers = 4, PlanNoMixedGroups = 8, PlanNoBankOrder = 16, PlanNoTileMerge = 32;
         public static uint PlanBalancedLists(int n) => (uint)n << 8;   // irregular meshes: 1..3 balanced extra lists; 0 = default (2)
         public const int TransportRccl = 0, TransportPeer = 1;
         public const int ScheduleAuto = 0, ScheduleSerialEager = 1, ScheduleSerialGraph = 2, ScheduleOverlapEager = 3, ScheduleOverlapGraph = 4;

@@ -59,6 +59,7 @@ typedef struct sb_plan sb_plan;     /* opaque, plugin-owned */
 #define SB_PLAN_NO_CLUSTER_LAYERS 4u   /* T2 layers from grids only */
 #define SB_PLAN_NO_MIXED_GROUPS   8u   /* one constraint type per group of a tile */
 #define SB_PLAN_NO_BANK_ORDER    16u   /* keep the colouring order inside a group (no LDS-bank-aware lane order) */
+#define SB_PLAN_NO_TILE_MERGE     32u   /* irregular meshes: do not merge small tiles of a balanced list around a leftover constraint */
 #define SB_PLAN_BALANCED_LISTS(n) ((uint32_t)(n) << 8)   /* irregular meshes: 1..3 balanced extra lists (grids) beside T0 / T1; 0 = default (2) */
 
 /* Ghost exchange of a world > 1 solver. */

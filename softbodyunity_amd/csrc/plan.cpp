@@ -915,6 +915,69 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
                         }
                     if (!moved) break;
                 }
+                // Leftovers (inside no list's tile: on the surrogate 250 of 1.4 M, nine in ten of them surface hinges) would cost a
+                // cluster layer of their own -- one more launch per substep for a handful of constraints. Where the tiles of ONE
+                // balanced list that hold a leftover's particles are small enough together (surface cells are under-full), merge
+                // them into one sparse tile: tiles of a layer are particle-disjoint, so the union is a valid tile, its program is as
+                // long as the longer of the two, and the leftover fits. (Sparse T2 tiles are explicit particle lists: nothing
+                // requires a tile to be one grid cell.)
+                if (opts.merge_tiles) {
+                    std::vector<std::vector<int32_t>> parent((size_t)n_bal), tsize((size_t)n_bal);
+                    for (int e = 0; e < n_bal; ++e) {
+                        int64_t nt = 0;
+                        for (int32_t q = 0; q < n; ++q) nt = std::max(nt, bal_key[(size_t)e][q] + 1);
+                        parent[(size_t)e].resize((size_t)nt); tsize[(size_t)e].assign((size_t)nt, 0);
+                        std::iota(parent[(size_t)e].begin(), parent[(size_t)e].end(), 0);
+                        for (int32_t q = 0; q < n; ++q) ++tsize[(size_t)e][(size_t)bal_key[(size_t)e][q]];
+                    }
+                    auto find = [&](int e, int32_t x) {
+                        auto &pa = parent[(size_t)e];
+                        while (pa[(size_t)x] != x) { pa[(size_t)x] = pa[(size_t)pa[(size_t)x]]; x = pa[(size_t)x]; }
+                        return x;
+                    };
+                    int64_t merged = 0;
+                    // two sweeps: first only unions that stay a small tile (512 particles); whatever is still left may then build a
+                    // large tile (1024): one tile of the large kind costs less than a launch of its own for the last few constraints
+                    for (int sweep = 0; sweep < 2; ++sweep)
+                    for (int t = 0; t < 3; ++t)
+                        for (int64_t k = 0; k < C.count(t); ++k) {
+                            if (cur[t][k] >= 0) continue;
+                            const int64_t cap_now = sweep == 0 ? kMergedTileCap : (int64_t)kMaxTileLocal;
+                            const int32_t *v = C.idx(t, k);
+                            int best = -1; int64_t best_total = INT64_MAX;
+                            int32_t roots[4];
+                            for (int e = 0; e < n_bal; ++e) {
+                                int nr = 0; int64_t total = 0;
+                                for (int a = 0; a < kVerts[t]; ++a) {
+                                    const int32_t r = find(e, (int32_t)bal_key[(size_t)e][v[a]]);
+                                    bool seen = false;
+                                    for (int q = 0; q < nr; ++q) seen |= roots[q] == r;
+                                    if (!seen) { roots[nr++] = r; total += tsize[(size_t)e][(size_t)r]; }
+                                }
+                                if (total <= cap_now && total < best_total) { best_total = total; best = e; }
+                            }
+                            if (best < 0) continue;
+                            int32_t root = INT32_MAX;
+                            for (int a = 0; a < kVerts[t]; ++a) root = std::min(root, find(best, (int32_t)bal_key[(size_t)best][v[a]]));
+                            for (int a = 0; a < kVerts[t]; ++a) {
+                                const int32_t r = find(best, (int32_t)bal_key[(size_t)best][v[a]]);
+                                if (r != root) { parent[(size_t)best][(size_t)r] = root; tsize[(size_t)best][(size_t)root] += tsize[(size_t)best][(size_t)r]; }
+                            }
+                            cur[t][k] = (int8_t)(2 + best);
+                            for (int a = 0; a < kVerts[t]; ++a) ++deg[(size_t)(2 + best)][v[a]];
+                            ++merged;
+                        }
+                    if (merged)
+                        for (int e = 0; e < n_bal; ++e)
+                            parallel_chunks(n, 1 << 18, [&](int64_t, int64_t pb, int64_t pe) {
+                                for (int64_t q = pb; q < pe; ++q) {      // (read-only walk: find() above compresses paths, this one must not race)
+                                    int32_t x = (int32_t)bal_key[(size_t)e][(size_t)q];
+                                    while (parent[(size_t)e][(size_t)x] != x) x = parent[(size_t)e][(size_t)x];
+                                    bal_key[(size_t)e][(size_t)q] = x;
+                                }
+                            });
+                    if (timer.on) std::fprintf(stderr, "[plan] leftovers placed by merging tiles: %lld\n", (long long)merged);
+                }
                 if (timer.on) {
                     for (int L = 0; L < n_lists; ++L) {
                         int32_t mx = 0; std::vector<int32_t> forced((size_t)n, 0);

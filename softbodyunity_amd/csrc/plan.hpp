@@ -58,6 +58,7 @@ struct Opts {
                                // (dims), 2 = recursive coordinate bisection over whole T0 cells weighted by constraint cost
     bool third_tiling = true;       // constraints inside neither T0 nor T1 get LDS tiles of their own (T2) where they can (SB_NO_T2: A/B runs)
     bool third_list = true;         // irregular meshes: the first T2 layers take a balanced share of the constraints, not only the leftovers (SB_NO_THIRD_LIST: A/B runs)
+    bool merge_tiles = true;        // irregular meshes: merge small tiles of a balanced list around a leftover constraint (SB_PLAN_NO_TILE_MERGE: A/B runs)
     int balanced_lists = 2;         // irregular meshes: how many T2 layers are balanced lists (grids of their own), 1 .. kMaxBalancedLists
     bool cluster_layers = true;     // once few constraints are left, T2 layers are made of connected components instead of grid cells (SB_NO_CLUSTER_LAYERS: A/B runs)
     bool mixed_groups = true;       // colour the constraint types of a tile together (SB_NO_MIXED_GROUPS: one type per group, A/B runs)
@@ -73,6 +74,7 @@ struct Run {            // a contiguous range of particles
 constexpr int kRoundThreads = 256;          // constraints of one type per group (round)
 constexpr int kMaxTileLocal = 1024;         // particles staged per tile (4 per lane)
 constexpr int kMaxTileRuns = 64;
+constexpr int64_t kMergedTileCap = 512;     // particles (of the grid cells) a merged tile of a balanced list may hold: stays a small tile
 constexpr int kMaxBalancedLists = 3;        // of the T2 layers, at most this many are balanced lists (plan.cpp static split)
 constexpr int kMaxT2Layers = 6;             // shifted grids tried in turn for the constraints inside neither T0 nor T1
 // partition cost units: a particle 12; a constraint 12 / 24 / 48 (distance / volume / bending), split evenly over its vertices

@@ -337,10 +337,11 @@ sbp::Opts plan_opts(int rank, int world, const int32_t dims[3], int32_t tile_par
     o.cluster_layers = !(plan_flags & SB_PLAN_NO_CLUSTER_LAYERS);
     o.mixed_groups = !(plan_flags & SB_PLAN_NO_MIXED_GROUPS);
     o.bank_aware_lanes = !(plan_flags & SB_PLAN_NO_BANK_ORDER);
+    o.merge_tiles = !(plan_flags & SB_PLAN_NO_TILE_MERGE);
     if ((plan_flags >> 8) & 3u) o.balanced_lists = (int)((plan_flags >> 8) & 3u);
     return o;
 }
-constexpr uint32_t kPlanFlagsAll = SB_PLAN_NO_T2 | SB_PLAN_NO_THIRD_LIST | SB_PLAN_NO_CLUSTER_LAYERS | SB_PLAN_NO_MIXED_GROUPS | SB_PLAN_NO_BANK_ORDER | SB_PLAN_BALANCED_LISTS(3);
+constexpr uint32_t kPlanFlagsAll = SB_PLAN_NO_T2 | SB_PLAN_NO_THIRD_LIST | SB_PLAN_NO_CLUSTER_LAYERS | SB_PLAN_NO_MIXED_GROUPS | SB_PLAN_NO_BANK_ORDER | SB_PLAN_NO_TILE_MERGE | SB_PLAN_BALANCED_LISTS(3);
 
 // 64-bit FNV-1a over everything the ranks of a partitioned solver must agree on: the published orders, who owns which
 // particle, the phase list with its halo slots, and the options that shaped them. (The halo lists are functions of these.)
@@ -355,7 +356,7 @@ uint64_t hash_plan(const sbp::Plan &P) {
     };
     const int32_t head[8] = {P.n, P.opts.world, P.opts.tile_particles, P.partition,
                              (int32_t)((P.opts.third_tiling ? 0 : 1) | (P.opts.third_list ? 0 : 2) | (P.opts.cluster_layers ? 0 : 4) |
-                                       (P.opts.mixed_groups ? 0 : 8) | (P.opts.bank_aware_lanes ? 0 : 16) | (P.opts.balanced_lists << 8)),
+                                       (P.opts.mixed_groups ? 0 : 8) | (P.opts.bank_aware_lanes ? 0 : 16) | (P.opts.merge_tiles ? 0 : 32) | (P.opts.balanced_lists << 8)),
                              P.dims[0], P.dims[1], P.dims[2]};
     mix(head, sizeof(head));
     mix(P.m, sizeof(P.m));

@@ -19,7 +19,7 @@ SB_UNIQUE_ID_BYTES = 128
 SB_IPC_HANDLE_BYTES = 64
 SB_OK = 0
 SB_PARTITION_AUTO, SB_PARTITION_BLOCKS, SB_PARTITION_RCB = 0, 1, 2
-SB_PLAN_NO_T2, SB_PLAN_NO_THIRD_LIST, SB_PLAN_NO_CLUSTER_LAYERS, SB_PLAN_NO_MIXED_GROUPS, SB_PLAN_NO_BANK_ORDER = 1, 2, 4, 8, 16
+SB_PLAN_NO_T2, SB_PLAN_NO_THIRD_LIST, SB_PLAN_NO_CLUSTER_LAYERS, SB_PLAN_NO_MIXED_GROUPS, SB_PLAN_NO_BANK_ORDER, SB_PLAN_NO_TILE_MERGE = 1, 2, 4, 8, 16, 32
 SB_TRANSPORT_RCCL, SB_TRANSPORT_PEER = 0, 1
 SB_SCHEDULE_AUTO, SB_SCHEDULE_SERIAL_EAGER, SB_SCHEDULE_SERIAL_GRAPH, SB_SCHEDULE_OVERLAP_EAGER, SB_SCHEDULE_OVERLAP_GRAPH = 0, 1, 2, 3, 4
 SB_DEBUG_NO_COMM, SB_DEBUG_LOOPBACK = 1, 2
@@ -190,7 +190,7 @@ def i32(a, shape=None):
 # they are translated here into the sb_desc / sb_plan_opts fields a host would set (include/softbody.h). --------------------
 _PLAN_FLAG_ENV = (("SB_NO_T2", SB_PLAN_NO_T2), ("SB_NO_THIRD_LIST", SB_PLAN_NO_THIRD_LIST),
                   ("SB_NO_CLUSTER_LAYERS", SB_PLAN_NO_CLUSTER_LAYERS), ("SB_NO_MIXED_GROUPS", SB_PLAN_NO_MIXED_GROUPS),
-                  ("SB_NO_BANK_ORDER", SB_PLAN_NO_BANK_ORDER))
+                  ("SB_NO_BANK_ORDER", SB_PLAN_NO_BANK_ORDER), ("SB_NO_TILE_MERGE", SB_PLAN_NO_TILE_MERGE))
 
 
 def plan_flags_from_env():
