@@ -382,7 +382,7 @@ def small_parity(ticks, args, device):
     """Checker leg: the same number of ticks on a 40^3 cube, plugin vs the CPU oracle run live, bit for bit."""
     from softbodyunity_amd import Softbody, jelly_cube
     oracle, _, make_oracle = _oracle_tools()
-    m = jelly_cube(40)
+    m = jelly_cube(40, heterogeneous=args.heterogeneous)
     sb = Softbody(m, substeps=args.substeps, device=device, tile_particles=args.tile, use_graph=not args.no_graph).Start()
     try:
         o = make_oracle(oracle, m, sb.plan())
@@ -406,7 +406,7 @@ def cpu_baseline(mesh, sb, args):
     from softbodyunity_amd import jelly_cube
     n_s = args.cpu_sample_n or args.n
     same = n_s == args.n
-    m = mesh if same else jelly_cube(n_s)
+    m = mesh if same else jelly_cube(n_s, heterogeneous=args.heterogeneous)
     plan = sb.plan() if same else build_plan(m, tile_particles=args.tile)
     o = make_oracle(oracle, m, plan)
     S = args.substeps

@@ -103,6 +103,10 @@ struct TileArgs {
     const float *ghost_src;
     int32_t n_owned;
 };
+// (A PACK variant -- T0 tiles writing the send buffer themselves, entries {tile-local index, send slot} per tile -- was built and
+// measured in round 3: bit-exact, but 0.786 -> 0.861 ms per tick in the serialised W = 8 loopback schedule and no change in the
+// overlapped one (profiles/r03g_loopback_w8_fused_pack_ab_not_kept.txt); removed.)
+constexpr int kHaloNone = 0, kHaloGhosts = 1;
 
 // Lanes per tile (template parameter THREADS of tile_kernel). A round holds up to kRoundSlots independent constraints,
 // so a lane projects kRoundSlots / THREADS of them per round. Fewer waves per tile = more tiles resident per CU (the
@@ -419,8 +423,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // Register budget (HIP: second launch-bound = waves per SIMD). LDS allows ~14 tiles per CU, so aim for that many waves.
 template <bool QUADS, int THREADS> constexpr int kWavesPerSimd = QUADS ? (THREADS == 64 ? 3 : (THREADS == 512 ? 2 : 4)) : (THREADS == 256 ? 8 : (THREADS == 128 ? 6 : 4));   // 128 lanes: 7 waves (72 VGPRs) measured 1 % slower, 8 spill
 // WPAL = inverse masses are read as one-byte palette indices (the palette entry comes from another lane by ds_bpermute).
-template <int KIND, bool QUADS, int THREADS, int PPT, bool WPAL, bool GHOSTS = false>
+template <int KIND, bool QUADS, int THREADS, int PPT, bool WPAL, int HALO = kHaloNone>
 __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile_kernel(const TileDesc *tiles_at_base, int n_workgroups, TileArgs A) {
+    constexpr bool GHOSTS = HALO == kHaloGhosts;
     // The first two arguments (3 dwords) are preloaded into SGPRs at dispatch (-mllvm -amdgpu-kernarg-preload-count=3, Makefile):
     // the descriptor fetch starts with the kernel instead of behind the kernel-argument load (one memory round trip less on the
     // latency chain of a small launch). n_workgroups = gridDim.x (reading gridDim would be another kernel-argument load).

@@ -922,11 +922,11 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
                 // long as the longer of the two, and the leftover fits. (Sparse T2 tiles are explicit particle lists: nothing
                 // requires a tile to be one grid cell.)
                 if (opts.merge_tiles) {
-                    std::vector<std::vector<int32_t>> parent((size_t)n_bal), tsize((size_t)n_bal);
+                    std::vector<std::vector<int32_t>> parent((size_t)n_bal), tsize((size_t)n_bal), tcells((size_t)n_bal);
                     for (int e = 0; e < n_bal; ++e) {
                         int64_t nt = 0;
                         for (int32_t q = 0; q < n; ++q) nt = std::max(nt, bal_key[(size_t)e][q] + 1);
-                        parent[(size_t)e].resize((size_t)nt); tsize[(size_t)e].assign((size_t)nt, 0);
+                        parent[(size_t)e].resize((size_t)nt); tsize[(size_t)e].assign((size_t)nt, 0); tcells[(size_t)e].assign((size_t)nt, 1);
                         std::iota(parent[(size_t)e].begin(), parent[(size_t)e].end(), 0);
                         for (int32_t q = 0; q < n; ++q) ++tsize[(size_t)e][(size_t)bal_key[(size_t)e][q]];
                     }
@@ -947,21 +947,27 @@ void build_plan(const Input &in, const Opts &opts, Plan &P) {
                             int best = -1; int64_t best_total = INT64_MAX;
                             int32_t roots[4];
                             for (int e = 0; e < n_bal; ++e) {
-                                int nr = 0; int64_t total = 0;
+                                int nr = 0; int64_t total = 0; int cells_in = 0;
                                 for (int a = 0; a < kVerts[t]; ++a) {
                                     const int32_t r = find(e, (int32_t)bal_key[(size_t)e][v[a]]);
                                     bool seen = false;
                                     for (int q = 0; q < nr; ++q) seen |= roots[q] == r;
-                                    if (!seen) { roots[nr++] = r; total += tsize[(size_t)e][(size_t)r]; }
+                                    if (!seen) { roots[nr++] = r; total += tsize[(size_t)e][(size_t)r]; cells_in += tcells[(size_t)e][(size_t)r]; }
                                 }
-                                if (total <= cap_now && total < best_total) { best_total = total; best = e; }
+                                // (a union of at most kMaxMergedCells original tiles: the leftovers this is for span neighbouring cells; long-range
+                                // constraints must not chain the whole mesh into one tile -- they keep the cluster layers / global colours)
+                                if (total <= cap_now && cells_in <= kMaxMergedCells && total < best_total) { best_total = total; best = e; }
                             }
                             if (best < 0) continue;
                             int32_t root = INT32_MAX;
                             for (int a = 0; a < kVerts[t]; ++a) root = std::min(root, find(best, (int32_t)bal_key[(size_t)best][v[a]]));
                             for (int a = 0; a < kVerts[t]; ++a) {
                                 const int32_t r = find(best, (int32_t)bal_key[(size_t)best][v[a]]);
-                                if (r != root) { parent[(size_t)best][(size_t)r] = root; tsize[(size_t)best][(size_t)root] += tsize[(size_t)best][(size_t)r]; }
+                                if (r != root) {
+                                    parent[(size_t)best][(size_t)r] = root;
+                                    tsize[(size_t)best][(size_t)root] += tsize[(size_t)best][(size_t)r];
+                                    tcells[(size_t)best][(size_t)root] += tcells[(size_t)best][(size_t)r];
+                                }
                             }
                             cur[t][k] = (int8_t)(2 + best);
                             for (int a = 0; a < kVerts[t]; ++a) ++deg[(size_t)(2 + best)][v[a]];

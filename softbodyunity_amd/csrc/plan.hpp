@@ -75,6 +75,7 @@ constexpr int kRoundThreads = 256;          // constraints of one type per group
 constexpr int kMaxTileLocal = 1024;         // particles staged per tile (4 per lane)
 constexpr int kMaxTileRuns = 64;
 constexpr int64_t kMergedTileCap = 512;     // particles (of the grid cells) a merged tile of a balanced list may hold: stays a small tile
+constexpr int kMaxMergedCells = 8;           // ... and of how many original tiles (grid cells) it may be the union
 constexpr int kMaxBalancedLists = 3;        // of the T2 layers, at most this many are balanced lists (plan.cpp static split)
 constexpr int kMaxT2Layers = 6;             // shifted grids tried in turn for the constraints inside neither T0 nor T1
 // partition cost units: a particle 12; a constraint 12 / 24 / 48 (distance / volume / bending), split evenly over its vertices

@@ -1064,7 +1064,8 @@ void halo_exchange(sb_solver *s, int slot, hipStream_t st = nullptr) {
 }
 
 template <int KIND>
-void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = -1, bool ghosts = false) {
+void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = -1, int halo = sbk::kHaloNone) {
+    const bool ghosts = halo == sbk::kHaloGhosts;
     if (tile_end < 0) tile_end = D.n_tiles;
     if (tile_end <= tile_begin) return;
     sbk::TileArgs A{};
@@ -1088,9 +1089,9 @@ void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = 
 #define SB_LAUNCH_TILE(Q, W, G)                                                                                               \
     do {                                                                                                                      \
         if (Q && quad8) {                                                                                                     \
-            if (small) hipLaunchKernelGGL((sbk::tile_kernel<KIND, true, sbk::kQuadTileThreads, sbk::kSmallTile / sbk::kQuadTileThreads, W, false>), \
+            if (small) hipLaunchKernelGGL((sbk::tile_kernel<KIND, true, sbk::kQuadTileThreads, sbk::kSmallTile / sbk::kQuadTileThreads, W, sbk::kHaloNone>), \
                                           grid, block, D.lds_bytes + s->lds_pad, s->stream, tiles_at_base, n_wg, A);                                           \
-            else hipLaunchKernelGGL((sbk::tile_kernel<KIND, true, sbk::kQuadTileThreads, sbk::kLargeTile / sbk::kQuadTileThreads, W, false>), \
+            else hipLaunchKernelGGL((sbk::tile_kernel<KIND, true, sbk::kQuadTileThreads, sbk::kLargeTile / sbk::kQuadTileThreads, W, sbk::kHaloNone>), \
                                     grid, block, D.lds_bytes + s->lds_pad, s->stream, tiles_at_base, n_wg, A);                                                 \
         } else if (narrow) hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kNarrowTileThreads, sbk::kSmallTile / sbk::kNarrowTileThreads, W, G>), \
                                        grid, block, D.lds_bytes + s->lds_pad, s->stream, tiles_at_base, n_wg, A);                                              \
@@ -1100,14 +1101,14 @@ void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = 
                                 grid, block, D.lds_bytes + s->lds_pad, s->stream, tiles_at_base, n_wg, A);                                                     \
     } while (0)
     // the ghost-reading variant exists for the kernels that can meet ghosts behind a fused exchange: mid-tick and last kernels of
-    // spring-only tilings (enqueue_substeps decides; s->fused_unpack is never set for a tiling with tets / hinges)
+    // spring-only tilings (launch_tick_kernel decides; s->fused_unpack is never set for a tiling with tets / hinges)
     constexpr bool kCanGhost = KIND == 1 || KIND == 2;
     if (ghosts && !(kCanGhost && !D.has_quads)) throw std::runtime_error("internal: ghost-reading tile kernel requested for a launch that has none");
     if (kCanGhost && ghosts) {
-        if (s->w_palette) SB_LAUNCH_TILE(false, true, kCanGhost); else SB_LAUNCH_TILE(false, false, kCanGhost);
+        if (s->w_palette) SB_LAUNCH_TILE(false, true, (kCanGhost ? sbk::kHaloGhosts : sbk::kHaloNone)); else SB_LAUNCH_TILE(false, false, (kCanGhost ? sbk::kHaloGhosts : sbk::kHaloNone));
     } else
-    if (s->w_palette) { if (D.has_quads) SB_LAUNCH_TILE(true, true, false); else SB_LAUNCH_TILE(false, true, false); }
-    else { if (D.has_quads) SB_LAUNCH_TILE(true, false, false); else SB_LAUNCH_TILE(false, false, false); }
+    if (s->w_palette) { if (D.has_quads) SB_LAUNCH_TILE(true, true, sbk::kHaloNone); else SB_LAUNCH_TILE(false, true, sbk::kHaloNone); }
+    else { if (D.has_quads) SB_LAUNCH_TILE(true, false, sbk::kHaloNone); else SB_LAUNCH_TILE(false, false, sbk::kHaloNone); }
 #undef SB_LAUNCH_TILE
 }
 
@@ -1130,10 +1131,10 @@ void launch_tick_kernel(sb_solver *s, int it, int substeps, LaunchTimer *lt, int
     const int tl = s->plan->plan.tiling ? (it & 1) : 0;
     DevTiling &D = s->tiling[tl];
     if (lt && D.n_tiles) lt->begin(it == 0 ? 2 + (int)s->gcolours.size() : (it == substeps ? 3 + (int)s->gcolours.size() : tl));
-    const bool ghosts = s->fused_unpack && tl == 1;      // T1 tiles read their ghosts straight from the receive buffer
+    const int halo_in = s->fused_unpack && tl == 1 ? sbk::kHaloGhosts : sbk::kHaloNone;      // T1 tiles read their ghosts straight from the receive buffer
     if (it == 0) launch_tile<0>(s, D, tile_begin, tile_end);
-    else if (it < substeps) launch_tile<1>(s, D, tile_begin, tile_end, ghosts);
-    else launch_tile<2>(s, D, tile_begin, tile_end, ghosts);
+    else if (it < substeps) launch_tile<1>(s, D, tile_begin, tile_end, halo_in);
+    else launch_tile<2>(s, D, tile_begin, tile_end, halo_in);
     if (lt && D.n_tiles) lt->end();
 }
 

@@ -102,3 +102,21 @@ def test_traffic_file_entries_match_the_compulsory_model_of_a_host_built_plan():
             tiles = ph["task_end"] - ph["task_begin"]
             model = 49.0 * mesh.n + 4.0 * slots + 128.0 * tiles
             assert abs(ent[slot] / model - 1) <= 0.03, (key, slot, ent[slot], model)
+
+
+@pytest.mark.gpu
+def test_bench_heterogeneous_variant_checks_itself_too():
+    # the data-layout worst case (per-particle masses, per-spring rest lengths): own golden checksums, same self-verification
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "64", "--heterogeneous", "--steps", "6", "--warmup", "2"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    j = json.loads([l for l in out.stdout.splitlines() if l.strip()][0])
+    p = j["config"]["parity"]
+    assert "HETEROGENEOUS" in j["config"]["workload"]
+    assert p["golden"]["bitwise"] is True and p["golden"]["schedule_matches"] is True
+    assert p["live"]["bitwise"] is True and p["small"]["bitwise"] is True
+    # 8-byte slots and 4-byte inverse masses: more compulsory bytes per launch than the headline layout of the same size
+    base = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--n", "64", "--steps", "3", "--warmup", "1", "--no-cpu-baseline", "--no-parity"],
+                          capture_output=True, text=True, timeout=600)
+    jb = json.loads([l for l in base.stdout.splitlines() if l.strip()][0])
+    assert j["roofline"]["model_bytes_per_launch"] > 1.1 * jb["roofline"]["model_bytes_per_launch"]

@@ -9,6 +9,7 @@ ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path
 TICKS = int(sys.argv[1]) if len(sys.argv) > 1 else 100     # both transports: RCCL send/recv and the peer-store mailboxes
 WORLD = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 ONLY_SERIAL = len(sys.argv) > 3 and sys.argv[3] == "serial"
+ONLY_RCCL = len(sys.argv) > 3 and sys.argv[3] == "rccl"
 CHILD = r'''
 import os, sys, time, hashlib
 sys.path.insert(0, %r)
@@ -30,7 +31,7 @@ print("RESULT %%.4f ms/tick hash %%s finite %%s" %% (ms, hashlib.sha256(x.tobyte
 sb.OnDestroy()
 ''' % (ROOT, WORLD, TICKS, TICKS)
 
-for transport in ("rccl", "peer"):
+for transport in (("rccl",) if ONLY_RCCL else ("rccl", "peer")):
     for overlap, graph in ((("", ""),) if ONLY_SERIAL else (("", ""), ("", "1"), ("1", ""), ("1", "1"))):
         env = dict(os.environ, SB_TEST_LOOPBACK="1")
         for k, v in (("SB_HALO_OVERLAP", overlap), ("SB_GRAPH_RCCL", graph), ("SB_HALO_TRANSPORT", "peer" if transport == "peer" else "")):

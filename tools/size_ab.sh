@@ -7,7 +7,7 @@ for n in $SIZES; do
       v=$name; [ "$v" = "product" ] && v=""
       SB_LIB_VARIANT=$v python bench.py --n $n --steps 100 --warmup 10 --no-cpu-baseline --no-parity --allow-stale-traffic 2>/dev/null | python -c "
 import json,sys
-d=json.loads(sys.stdin.readline()); print('n=$n %-8s %.4f ms/tick  tiles %s' % ('$name', d['ms_per_step'], d['stats']['n_tiles'] if 'stats' in d else ''))"
+d=json.loads(sys.stdin.readline()); print('n=$n %-8s %.4f ms/tick  tiles %s' % ('$name', d['ms_per_step'], d['plan']['n_tiles'] if 'plan' in d else ''))"
     done
   done
 done
