@@ -653,7 +653,15 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
     // slots and rest lengths in registers: one batch of LDS reads ahead of the first round instead of two dependent LDS
     // round trips (slot, then palette entry) at the head of every round, in both passes. Same constraints, same order.
     constexpr int kRegRounds = THREADS >= 256 ? SB_REG_ROUNDS : SB_REG_ROUNDS_NARROW;
-    if (kRegRounds > 0 && !QUADS && n_rounds_all <= kRegRounds && n_rounds_all > 0 && n_pal > 0 && d_hi - d_lo <= win) {
+    // (round 3: also for tiles whose slots are NOT dictionary-coded -- per-spring rest lengths, {i | j<<16, rest} pairs: the same 2
+    // registers per constraint, only the decode differs -- so that a mesh with varied rest lengths keeps the short path)
+#ifdef SB_REG_COMPACT_ONLY      // A/B timing builds only: the round-2 condition (dictionary-coded tiles only)
+    constexpr bool kRegFullSlots = false;
+#else
+    constexpr bool kRegFullSlots = true;
+#endif
+    if (kRegRounds > 0 && !QUADS && n_rounds_all <= kRegRounds && n_rounds_all > 0 && (kRegFullSlots || n_pal > 0) && d_hi - d_lo <= win) {
+        const bool tile_compact = n_pal > 0;      // (uniform per tile: build_device codes all of a tile's groups one way)
         uint32_t rs[kRegRounds > 0 ? kRegRounds : 1][kCPL];
         float rl[kRegRounds > 0 ? kRegRounds : 1][kCPL];
         int rcnt[kRegRounds > 0 ? kRegRounds : 1];
@@ -664,21 +672,36 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
                 rcnt[r] = 0;
                 if (r < n_rounds_all) {
                     rcnt[r] = (int)((uint32_t)__builtin_amdgcn_readlane((int)rwl, r) & 1023u);
+                    if (tile_compact) {
 #pragma unroll
-                    for (int u = 0; u < kCPL; ++u) {
-                        const int c = tid + u * kTileThreads;
-                        rs[r][u] = cbuf[o + (c < rcnt[r] ? c : 0)];
+                        for (int u = 0; u < kCPL; ++u) {
+                            const int c = tid + u * kTileThreads;
+                            rs[r][u] = cbuf[o + (c < rcnt[r] ? c : 0)];
+                        }
+                        o += ((uint32_t)rcnt[r] + 3u) & ~3u;
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < kCPL; ++u) {
+                            const int c = tid + u * kTileThreads;
+                            const uint2 e = *reinterpret_cast<const uint2 *>(cbuf + o + 2 * (c < rcnt[r] ? c : 0));
+                            // re-code the 16 | 16 bit index pair as the 12 | 12 bit form the rounds decode (tiles of this path hold at
+                            // most 512 particles)
+                            rs[r][u] = (e.x & 0xfffu) | ((e.x >> 16) << 12);
+                            rl[r][u] = __uint_as_float(e.y);
+                        }
+                        o += (2u * (uint32_t)rcnt[r] + 3u) & ~3u;
                     }
-                    o += ((uint32_t)rcnt[r] + 3u) & ~3u;
                 } else {
 #pragma unroll
-                    for (int u = 0; u < kCPL; ++u) rs[r][u] = 0;
+                    for (int u = 0; u < kCPL; ++u) { rs[r][u] = 0; rl[r][u] = 0.0f; }
                 }
             }
+            if (tile_compact) {
 #pragma unroll
-            for (int r = 0; r < kRegRounds; ++r)
+                for (int r = 0; r < kRegRounds; ++r)
 #pragma unroll
-                for (int u = 0; u < kCPL; ++u) rl[r][u] = s_pal[rs[r][u] >> 24];
+                    for (int u = 0; u < kCPL; ++u) rl[r][u] = s_pal[rs[r][u] >> 24];
+            }
         }
         auto reg_round = [&](const uint32_t (&e)[kCPL], const float (&L0)[kCPL], int cnt) {
             if (kCPL == 1) {

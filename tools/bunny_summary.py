@@ -34,7 +34,8 @@ types, ids = plan.order(0)
 tasks, groups = plan.tasks(0), plan.groups(0)
 print("## planner: groups per tile and lanes busy (parity 0; a group = constraints projected concurrently, one barrier)\n")
 print("| phase | tiles | constraints | groups per tile mean / max | springs + 4·(tets + hinges) lanes per group, mean | of 256 |\n|---|---|---|---|---|---|")
-names = {1: "first list (fused tile kernel)", 2: "second list (fused tile kernel)", 3: "T2 layer (sparse tiles)", 0: "global colour"}
+names = {1: "first list (fused tile kernel)", 2: "second list (fused tile kernel)", 3: "T2 layer (sparse tiles: a balanced list or a cluster layer)", 0: "global colour"}
+steps_per_substep = 0
 for ph in plan.phases(0):
     ob, oe = ph["order_begin"], ph["order_end"]
     tk = tasks[ph["task_begin"]:ph["task_end"] + 1]
@@ -45,3 +46,6 @@ for ph in plan.phases(0):
         t = types[a:b]
         lanes.append(np.count_nonzero(t == 0) + 4 * np.count_nonzero(t != 0))
     print(f"| {names[ph['kind']]} | {len(tk) - 1} | {oe - ob} | {per_tile.mean():.1f} / {per_tile.max()} | {np.mean(lanes):.0f} | {np.mean(lanes) / 256:.0%} |")
+    steps_per_substep += int(per_tile.max())
+print(f"\ndependent steps per substep (= groups of the longest tile, summed over the lists a substep walks; one workgroup barrier per group): "
+      f"**{steps_per_substep}** (round 2: 157 = 41 + 43 + 32 + 41)")
