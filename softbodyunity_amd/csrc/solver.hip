@@ -1640,6 +1640,10 @@ int sb_finalize(sb_solver *s) {
             }
             // otherwise (test mode without a communicator) the host connects the mailboxes: sb_peer_mailbox_handle / sb_peer_connect
         }
+        if (std::getenv("SB_PRINT_ALLOC"))       // diagnosis: where the arrays landed (run-to-run timing modes)
+            std::fprintf(stderr, "[alloc] pos3 %p prev %p vel %p wf %p w8 %p T0.stream %p T1.stream %p T0.tiles %p T1.tiles %p\n", (void *)s->d_pos3.p, (void *)s->d_prev.p,
+                         (void *)s->d_vel.p, (void *)s->d_wf.p, (void *)s->d_w8.p, (void *)s->tiling[0].stream.p, (void *)s->tiling[1].stream.p,
+                         (void *)s->tiling[0].tiles.p, (void *)s->tiling[1].tiles.p);
         HIP_CHECK(hipDeviceSynchronize());
         // authoring copies are no longer needed (keep rest values out of memory for 50M-constraint meshes)
         std::vector<float>().swap(s->pos); std::vector<float>().swap(s->vel); std::vector<float>().swap(s->rest);

@@ -286,3 +286,25 @@ def test_plan_is_independent_of_the_thread_count(small_bunny):
         assert r.returncode == 0, r.stderr[-2000:]
         outs.add(r.stdout.strip())
     assert len(outs) == 1, outs
+
+
+def test_null_opts_plan_uses_the_same_automatic_tile_size_as_the_solver(small_bunny):
+    # sb_plan_build(opts = NULL) must resolve tile_particles = 0 by the rule sb_finalize uses (256 with tets / hinges, 512
+    # for spring meshes), or a C host's CPU schedule differs from the one the GPU solver of the same mesh runs
+    import ctypes as C
+    from softbodyunity_amd import native
+    L = native.lib()
+    for mesh, want in ((small_bunny, 256), (jelly_cube(12), 512)):
+        rest = native.f32(mesh.rest_pos, (-1, 3)); d = native.i32(mesh.dist_ij, (-1, 2))
+        v = native.i32(mesh.vol_ijkl, (-1, 4)); b = native.i32(mesh.bend_ijkl, (-1, 4))
+        h = C.c_void_p()
+        native.check(L.sb_plan_build(native.ptr(rest), rest.shape[0], native.ptr(d), d.shape[0], native.ptr(v), v.shape[0], native.ptr(b), b.shape[0],
+                                     None, C.byref(h)))
+        p0 = native.Plan(h.value, True); p0.n = mesh.n; p0.world = 1
+        pe = build_plan(mesh, tile_particles=want)
+        pa = build_plan(mesh, tile_particles=0)
+        for parity in (0, 1):
+            for a, b2 in zip(p0.order(parity), pe.order(parity)):
+                assert np.array_equal(a, b2)
+            for a, b2 in zip(p0.order(parity), pa.order(parity)):
+                assert np.array_equal(a, b2)
