@@ -245,3 +245,23 @@ def test_several_solvers_with_captured_exchanges_in_one_process():
     for sb in reversed(alive):
         sb.OnDestroy()
     assert len(hashes) == 1
+
+
+@pytest.mark.parametrize("partition", [1, 2])
+def test_ranks_that_own_nothing_on_the_device(oracle_mod, partition):
+    # more ranks than occupied cells (6^3 cube in one 512-particle cell, 8 ranks): a rank with n_owned = 0 must finalize, launch nothing,
+    # exchange nothing; the merged result of the others equals the oracle bit for bit (8 hosted solver handles on the one GPU)
+    from softbodyunity_amd.mesh import jelly_cube
+    from helpers import build_plan, make_oracle
+    from hosted import HostedRanks
+    mesh = jelly_cube(6, pin_top=True)
+    with HostedRanks(mesh, world=8, substeps=4, tile_particles=512, partition=partition) as H:
+        owned = [sb.stats()["n_particles_owned"] for sb in H.ranks]
+        assert sum(owned) == mesh.n and 0 in owned
+        for _ in range(2):
+            H.tick()
+        x, v, _ = H.merged_state()
+    ref = make_oracle(oracle_mod, mesh, build_plan(mesh, tile_particles=512))
+    for _ in range(2):
+        ref.step(0.02, 4)
+    assert np.array_equal(x.view(np.uint32), ref.x.view(np.uint32)) and np.array_equal(v.view(np.uint32), ref.v.view(np.uint32))

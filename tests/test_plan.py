@@ -308,3 +308,16 @@ def test_null_opts_plan_uses_the_same_automatic_tile_size_as_the_solver(small_bu
                 assert np.array_equal(a, b2)
             for a, b2 in zip(p0.order(parity), pa.order(parity)):
                 assert np.array_equal(a, b2)
+
+
+@pytest.mark.parametrize("partition", [1, 2])
+def test_more_ranks_than_cells_leaves_ranks_empty_but_the_result_whole(oracle_mod, partition):
+    # 6^3 cube with 512-particle tiles (one cell) on 8 ranks: fewer occupied cells than ranks under some cuts -> ranks that own nothing must plan,
+    # exchange nothing and not disturb the others (both partitions)
+    mesh = jelly_cube(6, pin_top=True)
+    ref = make_oracle(oracle_mod, mesh, build_plan(mesh, tile_particles=512))
+    ref.step(0.02, 4)
+    x, v, ranks = run_partitioned(oracle_mod, mesh, 8, (0, 0, 0), ticks=1, substeps=4, tile=512, partition=partition)
+    owned = np.stack([r.owned for r in ranks]).sum(1)
+    assert owned.sum() == mesh.n and (owned == 0).any()
+    assert np.array_equal(x.view(np.uint32), ref.x.view(np.uint32)) and np.array_equal(v.view(np.uint32), ref.v.view(np.uint32))
