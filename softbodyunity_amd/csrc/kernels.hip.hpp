@@ -988,205 +988,9 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
         }
 }
 
-// ---- EXPERIMENT (round 3; opt-in SB_PERSISTENT=1): one persistent launch per tick ---------------------------------
-// Small lattice launches (64^3: 512 + 515 workgroups on 256 compute units, all resident at once) are chains of kernel boundaries:
-// 2.0 of a launch's 6.0 us are dispatch + descriptor. Here ONE launch walks the whole tick: workgroup w owns T0 tile w and T1 tile
-// w and alternates between them; instead of a kernel boundary a tile waits, before step `it`, until every tile of the OTHER tiling
-// that shares a particle with it has finished step it - 1 (a counter per tile in device memory, system-scope accesses). The L2s of the
-// XCDs are not coherent with each other, so everything a neighbour must see is stored THROUGH the L2 (as small launches do anyway)
-// and everything a neighbour wrote is loaded past it (sc0 sc1 loads). Register-resident programs only (<= 4 dictionary- or
-// full-coded spring rounds, <= 512 particles), 256 lanes. Every wait is bounded (error word instead of a hang).
-struct PersistArgs {
-    PosView pos;
-    const uint8_t *w8;
-    const float *wpal;
-    float *prev, *vel;
-    const TileDesc *tiles[2];
-    const uint32_t *stream[2];
-    const TickParams *tp;
-    uint32_t *flags;                // [2][n_wg]: steps completed (monotonic: `epoch` + steps of this launch)
-    const int32_t *parent_off[2];   // CSR per tile of tiling tl: the tiles of the other tiling it shares particles with
-    const int32_t *parents[2];
-    uint32_t *error;
-    int32_t n_tiles[2];
-    int32_t n_wg;
-    int32_t max_local, pal_dwords;
-    int32_t w_uniform, w_palette;
-    int32_t first_is_mid;           // the first step is a mid-tick kernel on T0 (it also finishes the previous tick) instead of KIND 0
-    int32_t n_steps;                // kernel-equivalents in this launch
-    int32_t last_is_final;          // the last step is KIND 2 (rounds + velocity write, no integrate)
-    uint32_t epoch;
-};
-__device__ __forceinline__ f32x3 load3_sys(const float *p) {
-    f32x3 v;
-    asm volatile("global_load_dwordx3 %0, %1, off sc0 sc1" : "=v"(v) : "v"(p) : "memory");
-    return v;
-}
-constexpr int kPersistSpinLimit = 1 << 22;
-
-__global__ __launch_bounds__(256) void persistent_tick_kernel(PersistArgs A) {
-    constexpr int THREADS = 256, PPT = 2, kMaxR = 4;
-    extern __shared__ uint4 lds_raw[];
-    float4 *lds_pos = reinterpret_cast<float4 *>(lds_raw);
-    float *s_pal = reinterpret_cast<float *>(lds_pos + A.max_local);
-    __shared__ uint32_t s_fail;
-    const int tid = threadIdx.x, wg = (int)blockIdx.x;
-    const TickParams tp = *A.tp;
-    const int mypal = A.w_palette ? __float_as_int(A.wpal[tid & (kMaxMassPalette - 1)]) : 0;
-    if (tid == 0) s_fail = 0;
-    __syncthreads();
-    for (int it = 0; it < A.n_steps; ++it) {
-        const int tl = it & 1;
-        const int kind = (it == 0 && !A.first_is_mid) ? 0 : ((it == A.n_steps - 1 && A.last_is_final) ? 2 : 1);
-        const int nwg = A.n_tiles[tl];
-        // the XCD-contiguous tile map of tile_kernel, per tiling
-        const int xq = nwg >> 3, xr = nwg & 7, xcd = wg & 7;
-        const int tile_index = (xcd < xr ? xcd * (xq + 1) : xr * (xq + 1) + (xcd - xr) * xq) + (wg >> 3);
-        const bool have = wg < nwg;          // (uniform)
-        if (!have) continue;
-        const TileDesc &td = A.tiles[tl][tile_index];
-        // ---- wait for the neighbours of the other tiling (nothing to wait for in the first step: the previous launch ended) ----
-        if (it > 0) {
-            const int pb = A.parent_off[tl][tile_index], pe = A.parent_off[tl][tile_index + 1];
-            const uint32_t want = A.epoch + (uint32_t)it;          // the parent finished step it - 1
-            for (int q = pb + tid; q < pe; q += THREADS) {
-                const uint32_t *f = A.flags + (size_t)(1 - tl) * A.n_wg + A.parents[tl][q];
-                int spins = 0;
-                while ((int32_t)(__hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) - want) < 0) {
-                    __builtin_amdgcn_s_sleep(1);
-                    if (++spins > kPersistSpinLimit) { s_fail = 1; break; }
-                }
-            }
-            __syncthreads();
-            if (s_fail) { if (tid == 0) __hip_atomic_store(A.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); return; }
-        }
-        // ---- particles: device indices from the inline runs ----
-        const int n_local = td.n_local;
-        const uint32_t *tstream = A.stream[tl] + td.s_begin;
-        int g[PPT];
-        {
-            int run_d[kInlineRuns], run_y[kInlineRuns];
-#pragma unroll
-            for (int r = 0; r < kInlineRuns; ++r) { run_y[r] = td.runs[r].y; run_d[r] = td.runs[r].x - td.runs[r].y; }
-#pragma unroll
-            for (int m = 0; m < PPT; ++m) {
-                const int l = tid + m * THREADS;
-                int d = run_d[0];
-#pragma unroll
-                for (int r = 1; r < kInlineRuns; ++r) d = l >= run_y[r] ? run_d[r] : d;
-                g[m] = l < n_local ? l + d : -1;
-            }
-        }
-        // ---- loads: positions and previous positions past the L2 (another XCD may have written them), the rest cached ----
-        f32x3 X3[PPT], P3[PPT];
-        uint32_t wi[PPT];
-        float wf[PPT];
-#pragma unroll
-        for (int m = 0; m < PPT; ++m) {
-            const int gc = max(g[m], 0);
-            X3[m] = load3_sys(A.pos.xyz + 3 * (size_t)gc);
-            if (kind != 0) P3[m] = load3_sys(A.prev + 3 * (size_t)gc);
-            wi[m] = A.w_palette ? A.w8[A.w_uniform ? 0 : gc] : 0u;
-            wf[m] = A.w_palette ? 0.0f : A.pos.w[gc];
-        }
-        const int R = td.n_rounds, n_pal = td.n_pal;
-        const uint32_t rwl = tstream[max(min(tid & 63, R - 1), 0)];
-        const uint32_t palw = tstream[tid < n_pal ? ((R + 3) & ~3) + tid : 0];
-        if (tid < n_pal) s_pal[tid] = __uint_as_float(palw);
-        // the slots straight from the stream into registers (one constraint per lane and round)
-        const bool compact = n_pal > 0;
-        uint32_t rs[kMaxR]; float rl[kMaxR]; int rcnt[kMaxR];
-        {
-            const uint32_t *data = tstream + td.s_hdr;
-            uint32_t o = 0;
-#pragma unroll
-            for (int r = 0; r < kMaxR; ++r) {
-                rcnt[r] = 0; rs[r] = 0; rl[r] = 0.0f;
-                if (r < R) {
-                    rcnt[r] = (int)((uint32_t)__builtin_amdgcn_readlane((int)rwl, r) & 1023u);
-                    const int c = tid < rcnt[r] ? tid : 0;
-                    if (compact) { rs[r] = data[o + c]; o += ((uint32_t)rcnt[r] + 3u) & ~3u; }
-                    else {
-                        const uint2 e = *reinterpret_cast<const uint2 *>(data + o + 2 * c);
-                        rs[r] = (e.x & 0xfffu) | ((e.x >> 16) << 12); rl[r] = __uint_as_float(e.y);
-                        o += (2u * (uint32_t)rcnt[r] + 3u) & ~3u;
-                    }
-                }
-            }
-        }
-        if (kind != 0) asm volatile("s_waitcnt vmcnt(0)" : "+v"(X3[0]), "+v"(X3[1]), "+v"(P3[0]), "+v"(P3[1])::"memory");
-        else asm volatile("s_waitcnt vmcnt(0)" : "+v"(X3[0]), "+v"(X3[1])::"memory");
-#pragma unroll
-        for (int m = 0; m < PPT; ++m) {
-            const float w = A.w_palette ? __int_as_float(__builtin_amdgcn_ds_bpermute((int)(wi[m] << 2), mypal)) : wf[m];
-            if (g[m] >= 0) lds_pos[tid + m * THREADS] = make_float4(X3[m].x, X3[m].y, X3[m].z, w);
-        }
-        __syncthreads();
-        if (compact) {
-#pragma unroll
-            for (int r = 0; r < kMaxR; ++r) rl[r] = s_pal[rs[r] >> 24];
-        }
-        auto rounds = [&]() {
-#pragma unroll
-            for (int r = 0; r < kMaxR; ++r)
-                if (r < R) {
-                    if (tid < rcnt[r]) {
-                        const int i = rs[r] & 0xfffu, k = (rs[r] >> 12) & 0xfffu;
-                        float4 a = lds_pos[i], b = lds_pos[k];
-                        if (project_distance(a, b, rl[r], tp.at_d)) { lds_pos[i] = a; lds_pos[k] = b; }
-                    }
-                    lds_barrier();
-                }
-        };
-        if (kind != 0) rounds();
-        // MARK (SPEC.md 2): collide + velocity of the substep that just finished, integrate of the next -- as tile_kernel's
-#pragma unroll
-        for (int m = 0; m < PPT; ++m)
-            if (g[m] >= 0) {
-                const int l = tid + m * THREADS;
-                float4 P = lds_pos[l];
-                if (kind != 0 && tp.plane_on && P.w > 0.0f) {
-                    float a = tp.pnx * P.x, b = tp.pny * P.y, c = tp.pnz * P.z;
-                    float pen = ((a + b) + c) - tp.pd;
-                    if (pen < 0.0f) {
-                        float dx = pen * tp.pnx, dy = pen * tp.pny, dz = pen * tp.pnz;
-                        P.x = P.x - dx; P.y = P.y - dy; P.z = P.z - dz;
-                        if (kind == 2) lds_pos[l] = P;
-                    }
-                }
-                float vx, vy, vz;
-                const size_t o = 3 * (size_t)g[m];
-                if (kind == 0) { vx = A.vel[o + 0]; vy = A.vel[o + 1]; vz = A.vel[o + 2]; }
-                else {
-                    float dx = P.x - P3[m].x, dy = P.y - P3[m].y, dz = P.z - P3[m].z;
-                    float qx = dx * tp.inv_h, qy = dy * tp.inv_h, qz = dz * tp.inv_h;
-                    vx = qx * tp.kd; vy = qy * tp.kd; vz = qz * tp.kd;
-                }
-                if (kind == 2) { A.vel[o + 0] = vx; A.vel[o + 1] = vy; A.vel[o + 2] = vz; }
-                else {
-                    store3_through(A.prev + o, P.x, P.y, P.z);
-                    if (P.w > 0.0f) {
-                        vx = vx + tp.hgx; vy = vy + tp.hgy; vz = vz + tp.hgz;
-                        float hx = tp.h * vx, hy = tp.h * vy, hz = tp.h * vz;
-                        P.x = P.x + hx; P.y = P.y + hy; P.z = P.z + hz;
-                        lds_pos[l] = P;
-                    }
-                }
-            }
-        lds_barrier();
-        if (kind != 2) rounds();
-#pragma unroll
-        for (int m = 0; m < PPT; ++m)
-            if (g[m] >= 0) {
-                const float4 P = lds_pos[tid + m * THREADS];
-                store3_through(A.pos.xyz + 3 * (size_t)g[m], P.x, P.y, P.z);
-            }
-        // ---- signal: this tile finished step `it` (every wave's stores have left the chip first) ----
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (tid == 0) __hip_atomic_store(A.flags + (size_t)tl * A.n_wg + tile_index, A.epoch + (uint32_t)it + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    }
-}
+// (Round 3, VERDICT r2 item 8: ONE persistent launch per tick for small launches -- tiles handing over through per-tile counters in
+// memory instead of kernel boundaries -- was built and measured: 64^3 0.125 -> 0.177 ms per tick. A hand-off through memory costs more
+// than the dispatch it replaces. Recorded in profiles/r03m_persistent_tick_experiment_negative.txt; the code is in the git history.)
 
 // Global-colour kernels: one constraint per lane, gather/scatter straight on HBM.
 __global__ __launch_bounds__(256) void global_distance_kernel(PosView pos, const int2 *ij, const float *rest, int count,

@@ -228,13 +228,6 @@ struct sb_solver {
     int narrow_min_tiles = 10240;    // SB_NARROW_MIN_TILES; measured crossover: 160^3 (8000 tiles) ties, 192^3 (13824) +4 % narrow
     size_t lds_pad = 0;              // SB_LDS_PAD bytes of unused LDS per workgroup (occupancy experiments)
     bool pack_tiles = true;          // SB_NO_PACK unset: under-full tiles share a workgroup (build_device)
-    // EXPERIMENT (SB_PERSISTENT=1): one persistent launch per tick for small lattice launches (kernels.hip.hpp persistent_tick_kernel)
-    bool persistent = false;
-    DevBuf<uint32_t> d_pflags;       // [2][n_wg] steps completed per tile
-    DevBuf<int32_t> d_parent_off[2], d_parents[2];
-    DevBuf<uint32_t> d_perror;
-    int32_t persist_wg = 0;
-    uint32_t persist_epoch = 0;
     bool fused_unpack = false;       // the T1 kernels read ghosts from the receive buffer: no unpack launch behind the slot-1 exchange
     bool graph_rccl = false;         // a multi-rank tick, exchange included, is captured in the hipGraph (SB_SCHEDULE_*_GRAPH)
     std::vector<float> h_stage;
@@ -845,59 +838,6 @@ void build_device(sb_solver *s) {
         D.stream.upload(stream, s->dev_bytes);
         D.gather.upload(dev_gather, s->dev_bytes);
     }
-    // persistent-tick experiment: which tiles of the other tiling a tile shares particles with
-    s->persistent = false;
-    if (std::getenv("SB_PERSISTENT") && L.world == 1 && P.tiling && P.gcolours.empty() && P.t2_layers.empty() && !s->tiling[0].has_quads &&
-        !s->tiling[1].has_quads && s->tiling[0].max_local <= sbk::kSmallTile && s->tiling[1].max_local <= sbk::kSmallTile) {
-        hipDeviceProp_t prop;
-        HIP_CHECK(hipGetDeviceProperties(&prop, s->desc.device));
-        const int32_t n_wg = std::max(s->tiling[0].n_tiles, s->tiling[1].n_tiles);
-        bool ok = n_wg > 0 && n_wg <= 4 * prop.multiProcessorCount;        // every workgroup must be resident at once
-        std::vector<sbk::TileDesc> ht[2];
-        for (int tl = 0; tl < 2 && ok; ++tl) {
-            ht[tl].resize((size_t)s->tiling[tl].n_tiles);
-            HIP_CHECK(hipMemcpy(ht[tl].data(), s->tiling[tl].tiles.p, ht[tl].size() * sizeof(sbk::TileDesc), hipMemcpyDeviceToHost));
-            for (const sbk::TileDesc &td : ht[tl]) ok &= td.n_rounds <= 4 && td.run_count <= sbk::kInlineRuns && td.n_rounds > 0;
-        }
-        if (ok) {
-            std::vector<int32_t> tile_of[2];
-            for (int tl = 0; tl < 2; ++tl) {
-                tile_of[tl].assign((size_t)s->n_local, -1);
-                for (size_t t = 0; t < ht[tl].size(); ++t) {
-                    const sbk::TileDesc &td = ht[tl][t];
-                    for (int r = 0; r < td.run_count; ++r) {
-                        const int32_t first = td.runs[r].x, l0 = td.runs[r].y, l1 = r + 1 < td.run_count ? td.runs[r + 1].y : td.n_local;
-                        for (int32_t q = 0; q < l1 - l0; ++q) tile_of[tl][(size_t)(first + q)] = (int32_t)t;
-                    }
-                }
-            }
-            for (int tl = 0; tl < 2; ++tl) {
-                std::vector<int32_t> off{0}, par;
-                std::vector<int32_t> seen;
-                for (size_t t = 0; t < ht[tl].size(); ++t) {
-                    seen.clear();
-                    const sbk::TileDesc &td = ht[tl][t];
-                    for (int r = 0; r < td.run_count; ++r) {
-                        const int32_t first = td.runs[r].x, l0 = td.runs[r].y, l1 = r + 1 < td.run_count ? td.runs[r + 1].y : td.n_local;
-                        for (int32_t q = 0; q < l1 - l0; ++q) { const int32_t o = tile_of[1 - tl][(size_t)(first + q)]; if (o >= 0) seen.push_back(o); }
-                    }
-                    std::sort(seen.begin(), seen.end());
-                    seen.erase(std::unique(seen.begin(), seen.end()), seen.end());
-                    par.insert(par.end(), seen.begin(), seen.end());
-                    off.push_back((int32_t)par.size());
-                }
-                s->d_parent_off[tl].upload(off, s->dev_bytes);
-                s->d_parents[tl].upload(par, s->dev_bytes);
-            }
-            s->persist_wg = n_wg;
-            s->d_pflags.alloc((size_t)2 * n_wg, s->dev_bytes);
-            HIP_CHECK(hipMemset(s->d_pflags.p, 0, (size_t)2 * n_wg * sizeof(uint32_t)));
-            s->d_perror.alloc(1, s->dev_bytes);
-            HIP_CHECK(hipMemset(s->d_perror.p, 0, sizeof(uint32_t)));
-            s->persist_epoch = 0;
-            s->persistent = true;
-        }
-    }
     for (const sbp::LocalGColour &LG : L.gcolours) {
         auto D = std::make_unique<DevGColour>();
         D->type = LG.type; D->count = (int32_t)LG.id.size();
@@ -1222,28 +1162,6 @@ void launch_gcolour(sb_solver *s, int gc, LaunchTimer *lt) {
     if (lt) lt->end();
 }
 
-// EXPERIMENT: the kernels enqueue_substeps would launch for one tick, as ONE persistent launch (kernels.hip.hpp).
-void launch_persistent_tick(sb_solver *s, int substeps, bool fused_first, bool defer_last) {
-    sbk::PersistArgs A{};
-    A.pos = s->pos_view(); A.w8 = s->d_w8.p; A.wpal = s->d_wpal.p; A.prev = s->d_prev.p; A.vel = s->d_vel.p;
-    for (int tl = 0; tl < 2; ++tl) {
-        A.tiles[tl] = s->tiling[tl].tiles.p; A.stream[tl] = s->tiling[tl].stream.p; A.n_tiles[tl] = s->tiling[tl].n_tiles;
-        A.parent_off[tl] = s->d_parent_off[tl].p; A.parents[tl] = s->d_parents[tl].p;
-    }
-    A.tp = s->d_tp.p; A.flags = s->d_pflags.p; A.error = s->d_perror.p; A.n_wg = s->persist_wg;
-    A.max_local = std::max(s->tiling[0].max_local, s->tiling[1].max_local);
-    A.pal_dwords = std::max(s->tiling[0].pal_dwords, s->tiling[1].pal_dwords);
-    A.w_uniform = s->w_uniform ? 1 : 0; A.w_palette = s->w_palette ? 1 : 0;
-    A.first_is_mid = fused_first ? 1 : 0;
-    A.n_steps = defer_last ? substeps : substeps + 1;
-    A.last_is_final = defer_last ? 0 : 1;
-    A.epoch = s->persist_epoch;
-    s->persist_epoch += (uint32_t)A.n_steps;
-    const size_t lds = (size_t)A.max_local * sizeof(float4) + (size_t)std::max(A.pal_dwords, 4) * 4 + 16;
-    hipLaunchKernelGGL(sbk::persistent_tick_kernel, dim3((unsigned)s->persist_wg), dim3(256), lds, s->stream, A);
-    HIP_CHECK(hipGetLastError());
-}
-
 // One tick (SPEC.md §2/§3): kernel K_s runs on the tiles of tiling T_(s&1): the tile's rounds (end of substep
 // s-1), collide + velocity update + integrate, the same rounds again (start of substep s).
 // fused_first: the tick starts with an ordinary mid-tick kernel on T0 that also finishes the PREVIOUS tick (its
@@ -1316,14 +1234,6 @@ void check_peer_error(sb_solver *s) {
     if (!s->peer.enabled || !s->peer.h_error) return;
     const uint32_t flag = *reinterpret_cast<volatile uint32_t *>(s->peer.h_error);     // a host load: cheap enough for every sb_step
     if (flag) throw HipError(SB_ERR_RCCL, "peer transport: a halo wait gave up (a neighbour never delivered or never acknowledged)");
-}
-
-// persistent-tick experiment: a dependency wait that gave up (a neighbour tile never finished) must not pass silently
-void check_persist_error(sb_solver *s) {
-    if (!s->persistent || !s->d_perror.p) return;
-    uint32_t flag = 0;
-    HIP_CHECK(hipMemcpy(&flag, s->d_perror.p, sizeof(flag), hipMemcpyDeviceToHost));
-    if (flag) throw HipError(SB_ERR_HIP, "persistent tick: a tile's wait for its neighbours gave up (workgroups not all resident?)");
 }
 
 template <class F>
@@ -1761,9 +1671,7 @@ int sb_step(sb_solver *s, float dt, int32_t substeps) {
         upload_tick_params(s, dt, substeps);
         // world > 1: the exchange inside a captured graph is opt-in (SB_SCHEDULE_*_GRAPH), see DESIGN.md §7
         const bool graph_ok = s->desc.use_graph && (s->desc.world == 1 || s->graph_rccl);     // the overlapped schedule forks onto comm_stream inside the capture
-        if (s->persistent) {
-            launch_persistent_tick(s, substeps, fuse, can_defer);
-        } else if (!graph_ok) {
+        if (!graph_ok) {
             enqueue_substeps(s, substeps, nullptr, fuse, can_defer);
         } else {
             const int key = substeps * 4 + (fuse ? 1 : 0) + (can_defer ? 2 : 0);
@@ -1904,7 +1812,6 @@ int sb_synchronize(sb_solver *s) {
         flush_deferred(s);
         HIP_CHECK(hipStreamSynchronize(s->stream));
         check_peer_error(s);
-        check_persist_error(s);
         return SB_OK;
     });
 }
