@@ -16,18 +16,15 @@ from softbodyunity_amd import Softbody, native
 
 class HostedRanks:
     def __init__(self, mesh, world, substeps, dt=0.02, part_dims=(0, 0, 0), **kw):
-        os.environ["SB_TEST_NO_COMM"] = "1"      # world > 1 without an RCCL communicator: the host carries the halo
         self.mesh, self.world, self.S, self.dt = mesh, world, substeps, dt
         self.ranks = []
         try:
-            for r in range(world):
+            for r in range(world):      # sb_desc.debug_flags = SB_DEBUG_NO_COMM: world > 1 without any transport, the host carries the halo
                 self.ranks.append(Softbody(mesh, substeps=substeps, fixed_delta_time=dt, device=0, rank=r, world=world,
-                                           part_dims=part_dims, unique_id=bytes(128), **kw).Start())
+                                           part_dims=part_dims, unique_id=bytes(128), debug_flags=native.SB_DEBUG_NO_COMM, **kw).Start())
         except Exception:
             self.close()
             raise
-        finally:
-            os.environ.pop("SB_TEST_NO_COMM", None)
         self.L = native.lib()
         st = self.ranks[0].stats()
         self.G, self.n_t2, self.tiling = st["n_global_colours"], st["n_t2_layers"], st["n_tilings"] == 2

@@ -89,7 +89,8 @@ def test_traffic_file_entries_match_the_compulsory_model_of_a_host_built_plan():
     from softbodyunity_amd.mesh import jelly_cube
     tj = json.load(open(os.path.join(ROOT, "profiles", "hbm_traffic.json")))
     for key, ent in tj.items():
-        n, tile, gpus = (int(g) for g in re.match(r"n(\d+)_tile(-?\d+)_gpus(\d+)", key).groups())
+        m = re.match(r"n(\d+)(het)?_tile(-?\d+)_gpus(\d+)", key)
+        n, het, tile, gpus = int(m.group(1)), bool(m.group(2)), int(m.group(3)), int(m.group(4))
         if gpus != 1:
             continue
         mesh = jelly_cube(n)
@@ -100,7 +101,9 @@ def test_traffic_file_entries_match_the_compulsory_model_of_a_host_built_plan():
             ph = [p for p in plan.phases(int(slot)) if p["kind"] == 1][0]
             slots = ph["order_end"] - ph["order_begin"]
             tiles = ph["task_end"] - ph["task_begin"]
-            model = 49.0 * mesh.n + 4.0 * slots + 128.0 * tiles
+            # headline layout: 48 B of particle state + ~1 B, 4-byte dictionary-coded slots; heterogeneous layout (bench.py
+            # --heterogeneous): + a 4-byte inverse mass per particle, 8-byte slots
+            model = (52.0 if het else 49.0) * mesh.n + (8.0 if het else 4.0) * slots + 128.0 * tiles
             assert abs(ent[slot] / model - 1) <= 0.03, (key, slot, ent[slot], model)
 
 

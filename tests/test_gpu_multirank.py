@@ -88,9 +88,8 @@ def _hosted_worker(rank, world, port, tile, mesh_kind, out_dir):
     comp = (0.0, 0.0, 0.0) if mesh_kind == "cube" else (1e-7, 1e-7, 1e-4)
     S, dt = 5, 0.02
     # world > 1 normally needs an RCCL communicator; the hosted test builds the solver with the comm check bypassed
-    os.environ["SB_TEST_NO_COMM"] = "1"
     sb = Softbody(mesh, substeps=S, device=0, rank=rank, world=world, tile_particles=tile, unique_id=bytes(128),
-                  distance_compliance=comp[0], volume_compliance=comp[1], bending_compliance=comp[2])
+                  distance_compliance=comp[0], volume_compliance=comp[1], bending_compliance=comp[2], debug_flags=native.SB_DEBUG_NO_COMM)
     sb.Start()
     L = native.lib()
     plan = sb.plan()

@@ -22,9 +22,6 @@ def _worker(rank, world, port, mesh_kind, graph, out_dir):
     import torch.distributed as dist
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
-    os.environ["SB_HALO_TRANSPORT"] = "peer"
-    if graph:
-        os.environ["SB_GRAPH_RCCL"] = "1"          # capture the tick (exchange kernels included) in the hipGraph
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from softbodyunity_amd import Softbody, native
     from softbodyunity_amd.mesh import bunny_surrogate, jelly_cube, jelly_cube_window
@@ -33,8 +30,10 @@ def _worker(rank, world, port, mesh_kind, graph, out_dir):
     else:
         mesh = jelly_cube(24, pin_top=True) if mesh_kind == "cube" else bunny_surrogate(target_verts=3000, seed=9)
     comp = (1e-7, 1e-7, 1e-4) if mesh_kind == "bunny" else (0.0, 0.0, 0.0)
+    # sb_desc.halo_transport / halo_schedule set explicitly (graph: the tick, exchange kernels included, captured in the hipGraph)
     sb = Softbody(mesh, substeps=6, device=0, rank=rank, world=world, tile_particles=128 if mesh_kind == "bunny" else 64,
-                  distance_compliance=comp[0], volume_compliance=comp[1], bending_compliance=comp[2]).Start()   # no communicator: the host connects
+                  distance_compliance=comp[0], volume_compliance=comp[1], bending_compliance=comp[2], halo_transport=native.SB_TRANSPORT_PEER,
+                  halo_schedule=native.SB_SCHEDULE_SERIAL_GRAPH if graph else native.SB_SCHEDULE_SERIAL_EAGER).Start()   # no communicator: the host connects
     L = native.lib()
     mine = np.zeros(native.SB_IPC_HANDLE_BYTES, np.uint8)
     native.check(L.sb_peer_mailbox_handle(sb._h, native.ptr(mine)))
