@@ -50,6 +50,30 @@ def test_window_plan_equals_whole_plan(n, tile, world, dims):
         assert np.array_equal(pw.pair_hashes(), ps.pair_hashes())
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_window_plan_equals_whole_plan_randomised(seed):
+    # cube edge, tile size, world and block shape drawn from the seed (incl. non-cubic block grids and worlds that are not powers of two)
+    rng = np.random.default_rng(4000 + seed)
+    n = int(rng.integers(18, 44))
+    tile = int(rng.choice([27, 64, 125, 216, 512]))
+    world, dims = [(2, (0, 0, 0)), (3, (3, 1, 1)), (4, (1, 4, 1)), (6, (3, 2, 1)), (8, (0, 0, 0)), (4, (2, 1, 2))][seed]
+    whole = jelly_cube(n)
+    ident = np.arange(whole.n)
+    for rank in range(world):
+        # (block partition on both sides: a sharded plan is always blocks, while SB_PARTITION_AUTO on the WHOLE mesh would switch to RCB
+        # where the cells do not divide evenly among the blocks -- 7 cells over 2 ranks is 4 : 3)
+        pw = build_plan(whole, rank=rank, world=world, part_dims=dims, tile_particles=tile, partition=native.SB_PARTITION_BLOCKS)
+        win = jelly_cube_window(n, rank, world, dims, tile)
+        gid = win.global_id.astype(np.int64)
+        ps = native.Plan.build(win.rest_pos, win.dist_ij, rank=rank, world=world, part_dims=dims, tile_particles=tile,
+                               domain=win.domain, global_id=win.global_id)
+        lw, ow = pw.local_particles(); ls, os_ = ps.local_particles()
+        assert ow == os_ and np.array_equal(lw, gid[ls]), (n, tile, world, dims, rank)
+        for parity in (0, 1):
+            assert np.array_equal(_seq(pw, whole, ident, parity), _seq(ps, win, gid, parity)), (n, tile, world, dims, rank, parity)
+        assert np.array_equal(pw.pair_hashes(), ps.pair_hashes())
+
+
 def test_pair_hashes_are_symmetric_and_detect_a_differing_neighbour():
     n, tile, world = 32, 64, 8
     P = []
