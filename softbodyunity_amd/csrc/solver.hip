@@ -219,7 +219,7 @@ struct sb_solver {
     bool deferred = false;
     int deferred_substeps = 0;
     bool lazy_tick = true;           // SB_NO_LAZY_TICK unset (read once in sb_create)
-    int tile_lanes = 0;              // SB_TILE_LANES=128|256 forces the workgroup width of small tiles (0 = by launch size)
+    int tile_lanes = 0;              // SB_TILE_LANES=128|256|512 forces the workgroup width of small tiles (0 = by launch size)
     int quad_lanes = 512;            // SB_QUAD_LANES=256|512: workgroup width of tiles that hold tets / hinges (8 waves: every group of the
                                      // 100 k surrogate fits one row of wave slots; 1.99 against 2.11 ms per tick with 4 waves)
     int store_through_max_tiles = 6144;   // SB_STORE_THROUGH_MAX_TILES: launches of at most this many tiles store their state through the L2
@@ -1085,7 +1085,12 @@ void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = 
     const bool narrow = small && (s->tile_lanes ? s->tile_lanes == sbk::kNarrowTileThreads : tile_end - tile_begin >= s->narrow_min_tiles);
     // tiles with tets / hinges: optionally 8 waves, so that a group's wave slots (16 four-lane constraints or 64 springs each) fit one row
     const bool quad8 = D.has_quads && s->quad_lanes == sbk::kQuadTileThreads;
-    const dim3 grid(tile_end - tile_begin), block(quad8 ? sbk::kQuadTileThreads : (narrow ? sbk::kNarrowTileThreads : sbk::kWideTileThreads));
+    // spring-only small tiles on 8 waves (one particle per lane in the load / MARK / store phases; the rounds use half the lanes) while
+    // every workgroup of the launch is resident even at that width (4 per compute unit): 64^3 0.1244 -> 0.1213, 48^3 0.1027 -> 0.1005 ms
+    // per tick; 96^3 (1 728 tiles) 0.206 -> 0.230, so only launches of at most kWide8MaxTiles (profiles/r03o_lanes512_small_cubes.txt)
+    constexpr int kWide8MaxTiles = 768;
+    const bool wide8 = small && !D.has_quads && (s->tile_lanes ? s->tile_lanes == 512 : tile_end - tile_begin <= kWide8MaxTiles);
+    const dim3 grid(tile_end - tile_begin), block(quad8 || wide8 ? sbk::kQuadTileThreads : (narrow ? sbk::kNarrowTileThreads : sbk::kWideTileThreads));
 #define SB_LAUNCH_TILE(Q, W, G)                                                                                               \
     do {                                                                                                                      \
         if (Q && quad8) {                                                                                                     \
@@ -1093,7 +1098,9 @@ void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = 
                                           grid, block, D.lds_bytes + s->lds_pad, s->stream, tiles_at_base, n_wg, A);                                           \
             else hipLaunchKernelGGL((sbk::tile_kernel<KIND, true, sbk::kQuadTileThreads, sbk::kLargeTile / sbk::kQuadTileThreads, W, sbk::kHaloNone>), \
                                     grid, block, D.lds_bytes + s->lds_pad, s->stream, tiles_at_base, n_wg, A);                                                 \
-        } else if (narrow) hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kNarrowTileThreads, sbk::kSmallTile / sbk::kNarrowTileThreads, W, G>), \
+        } else if (wide8) hipLaunchKernelGGL((sbk::tile_kernel<KIND, false, sbk::kQuadTileThreads, sbk::kSmallTile / sbk::kQuadTileThreads, W, G>), \
+                                       grid, block, D.lds_bytes + s->lds_pad, s->stream, tiles_at_base, n_wg, A);                                              \
+        else if (narrow) hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kNarrowTileThreads, sbk::kSmallTile / sbk::kNarrowTileThreads, W, G>), \
                                        grid, block, D.lds_bytes + s->lds_pad, s->stream, tiles_at_base, n_wg, A);                                              \
         else if (small) hipLaunchKernelGGL((sbk::tile_kernel<KIND, Q, sbk::kWideTileThreads, sbk::kSmallTile / sbk::kWideTileThreads, W, G>), \
                                            grid, block, D.lds_bytes + s->lds_pad, s->stream, tiles_at_base, n_wg, A);                                          \
@@ -1325,7 +1332,7 @@ int sb_create(const sb_desc *desc, sb_solver **out) {
         s->loopback = d.world > 1 && (d.debug_flags & SB_DEBUG_LOOPBACK) != 0;
         s->pack_tiles = !std::getenv("SB_NO_PACK");
         if (const char *e = std::getenv("SB_LDS_PAD")) s->lds_pad = (size_t)std::max(0, std::atoi(e));
-        if (const char *e = std::getenv("SB_TILE_LANES")) s->tile_lanes = std::atoi(e) == 128 ? 128 : (std::atoi(e) == 256 ? 256 : 0);
+        if (const char *e = std::getenv("SB_TILE_LANES")) s->tile_lanes = std::atoi(e) == 128 ? 128 : (std::atoi(e) == 256 ? 256 : (std::atoi(e) == 512 ? 512 : 0));
         if (const char *e = std::getenv("SB_QUAD_LANES")) s->quad_lanes = std::atoi(e) == 256 ? 256 : 512;
         if (const char *e = std::getenv("SB_STORE_THROUGH_MAX_TILES")) s->store_through_max_tiles = std::max(0, std::atoi(e));
         if (const char *e = std::getenv("SB_STORE_THROUGH_LARGE")) s->store_through_large = std::atoi(e) & 3;
