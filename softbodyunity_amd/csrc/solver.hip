@@ -1592,25 +1592,27 @@ int sb_finalize(sb_solver *s) {
             HIP_CHECK(hipStreamSynchronize(s->stream));
             std::vector<uint64_t> all((size_t)W * rec);
             HIP_CHECK(hipMemcpy(all.data(), d_all.p, all.size() * sizeof(uint64_t), hipMemcpyDeviceToHost));
-            for (int r = 0; r < W; ++r) {
-                if (r == s->desc.rank) continue;
-                const uint64_t *theirs = all.data() + (size_t)r * rec;
-                char msg[320];
-                // whole-mesh ranks must hold the identical plan; any two ranks must agree on what they share (ghost lists both ways,
-                // programs of the tiles both run) -- the only check a sharded rank, which sees just its window, can make
-                if (!s->sharded && !theirs[0] && theirs[1] != s->plan_hash) {
-                    std::snprintf(msg, sizeof msg, "sb_finalize: rank %d planned a different schedule than rank %d (plan hash %016llx vs %016llx): "
-                                  "every rank must pass the same mesh, tile_particles, partition and plan_flags", r, s->desc.rank,
-                                  (unsigned long long)theirs[1], (unsigned long long)s->plan_hash);
-                    return fail(SB_ERR_STATE, msg);
+            // Every rank holds the whole table and checks EVERY pair, so that all ranks fail together (a rank that went on alone would
+            // wait for its neighbours' first exchange forever). Whole-mesh ranks must hold the identical plan; any two ranks must agree
+            // on what they share (ghost lists both ways, programs of the tiles both run) -- the only check a sharded rank, which sees
+            // just its window, can make.
+            for (int a = 0; a < W; ++a)
+                for (int b = a + 1; b < W; ++b) {
+                    const uint64_t *ra = all.data() + (size_t)a * rec, *rb = all.data() + (size_t)b * rec;
+                    char msg[320];
+                    if (!ra[0] && !rb[0] && ra[1] != rb[1]) {
+                        std::snprintf(msg, sizeof msg, "sb_finalize: ranks %d and %d planned different schedules (plan hash %016llx vs %016llx): "
+                                      "every rank must pass the same mesh, tile_particles, partition and plan_flags", a, b,
+                                      (unsigned long long)ra[1], (unsigned long long)rb[1]);
+                        return fail(SB_ERR_STATE, msg);
+                    }
+                    if (ra[2 + (size_t)b] != rb[2 + (size_t)a]) {
+                        std::snprintf(msg, sizeof msg, "sb_finalize: ranks %d and %d disagree on what they share (ghost lists / programs of the tiles both run: pair hash "
+                                      "%016llx vs %016llx): same mesh, domain, tile_particles, partition and plan_flags on every rank? window complete (sb_domain_window)?",
+                                      a, b, (unsigned long long)ra[2 + (size_t)b], (unsigned long long)rb[2 + (size_t)a]);
+                        return fail(SB_ERR_STATE, msg);
+                    }
                 }
-                if (theirs[2 + (size_t)s->desc.rank] != mine[2 + (size_t)r]) {
-                    std::snprintf(msg, sizeof msg, "sb_finalize: ranks %d and %d disagree on what they share (ghost lists / programs of the tiles both run: pair hash "
-                                  "%016llx vs %016llx): same mesh, domain, tile_particles, partition and plan_flags on every rank? window complete (sb_domain_window)?",
-                                  s->desc.rank, r, (unsigned long long)mine[2 + (size_t)r], (unsigned long long)theirs[2 + (size_t)s->desc.rank]);
-                    return fail(SB_ERR_STATE, msg);
-                }
-            }
         }
         if (s->overlap_halo) {
             // opt-in: on the one measurement available (RCCL loopback on one GPU, 8-rank share of 256^3) splitting the T0
