@@ -78,7 +78,8 @@ def main():
                          "never run between two devices)")
     ap.add_argument("--whole-mesh", action="store_true", help="N > 1: every rank generates and plans the whole mesh (round-2 behaviour) instead of its window")
     ap.add_argument("--schedule", choices=["auto", "serial-eager", "serial-graph", "overlap-eager", "overlap-graph"], default="auto",
-                    help="halo schedule for N > 1 (sb_desc.halo_schedule); auto = serialised eager launches")
+                    help="halo schedule for N > 1 (sb_desc.halo_schedule); auto = eager launches, the exchange overlapped with the interior tiles when its "
+                         "largest per-peer message is >= 1 MiB, serialised below (config.halo_schedule says which)")
     ap.add_argument("--loopback-world", type=int, default=0,
                     help="diagnostic: run as rank 0 of this many ranks with SB_TEST_LOOPBACK (RCCL self-exchange on one GPU); "
                          "the reported value counts only the particles this rank owns")

@@ -65,8 +65,9 @@ typedef struct sb_plan sb_plan;     /* opaque, plugin-owned */
 /* Ghost exchange of a world > 1 solver. */
 #define SB_TRANSPORT_RCCL 0            /* pack -> grouped ncclSend/ncclRecv -> unpack (default) */
 #define SB_TRANSPORT_PEER 1            /* peer-store mailboxes (opt-in; see sb_peer_connect) */
-#define SB_SCHEDULE_AUTO               0   /* today: SB_SCHEDULE_SERIAL_EAGER (the only schedule that needs nothing of the bound
-                                              RCCL / HIP runtime beyond plain send/recv; see sb_runtime_info) */
+#define SB_SCHEDULE_AUTO               0   /* an eager schedule (nothing is asked of the bound RCCL / HIP runtime beyond plain send/recv, see
+                                              sb_runtime_info): SB_SCHEDULE_OVERLAP_EAGER when the largest per-peer message of the exchange is
+                                              1 MiB or more (link-bound between devices), else SB_SCHEDULE_SERIAL_EAGER; sb_stats.halo_schedule */
 #define SB_SCHEDULE_SERIAL_EAGER       1
 #define SB_SCHEDULE_SERIAL_GRAPH       2   /* the tick, exchange included, captured in a hipGraph */
 #define SB_SCHEDULE_OVERLAP_EAGER      3   /* exchange on a second stream beside the interior tiles */

@@ -1183,19 +1183,22 @@ void enqueue_substeps(sb_solver *s, int substeps, LaunchTimer *lt = nullptr, boo
         DevTiling &T0 = s->tiling[0], &T1 = s->tiling[1];
         const int t1_interior = T1.n_tiles - T1.n_boundary;
         for (int it = 0; it <= substeps; ++it) {
+            if (it == substeps && defer_last) break;       // (lazy tick boundary, as in the serialised schedule below)
+            // the first kernel of a tick that also finishes the previous one is an ordinary mid-tick kernel on T0: an even, interior step index
+            const int kit = it == 0 && fused_first ? 2 : it, ks = it == 0 && fused_first ? 4 : substeps;
             if (it & 1) {
-                launch_tick_kernel(s, it, substeps, lt, 0, t1_interior);
+                launch_tick_kernel(s, kit, ks, lt, 0, t1_interior);
                 HIP_CHECK(hipStreamWaitEvent(s->stream, s->ev_halo, 0));
-                launch_tick_kernel(s, it, substeps, lt, t1_interior, T1.n_tiles);
+                launch_tick_kernel(s, kit, ks, lt, t1_interior, T1.n_tiles);
             } else {
-                launch_tick_kernel(s, it, substeps, lt, 0, T0.n_boundary);
+                launch_tick_kernel(s, kit, ks, lt, 0, T0.n_boundary);
                 if (it < substeps) {
                     HIP_CHECK(hipEventRecord(s->ev_boundary, s->stream));
                     HIP_CHECK(hipStreamWaitEvent(s->comm_stream, s->ev_boundary, 0));
                     halo_exchange(s, 1, s->comm_stream);
                     HIP_CHECK(hipEventRecord(s->ev_halo, s->comm_stream));
                 }
-                launch_tick_kernel(s, it, substeps, lt, T0.n_boundary, T0.n_tiles);
+                launch_tick_kernel(s, kit, ks, lt, T0.n_boundary, T0.n_tiles);
             }
         }
         HIP_CHECK(hipGetLastError());
@@ -1527,7 +1530,8 @@ int sb_finalize(sb_solver *s) {
         int rc = set_device(s); if (rc) return rc;
         // ---- which schedule (world > 1): decided before any work, from what the process is actually bound to ----
         int sched = s->desc.world > 1 ? s->desc.halo_schedule : SB_SCHEDULE_SERIAL_EAGER;
-        if (sched == SB_SCHEDULE_AUTO) sched = SB_SCHEDULE_SERIAL_EAGER;
+        const bool sched_auto = sched == SB_SCHEDULE_AUTO;       // resolved below, once the size of the exchange is known
+        if (sched_auto) sched = SB_SCHEDULE_SERIAL_EAGER;
         if (s->desc.world > 1 && !no_comm) {
             const bool graph = sched == SB_SCHEDULE_SERIAL_GRAPH || sched == SB_SCHEDULE_OVERLAP_GRAPH;
             if (graph && !s->desc.use_graph) return fail(SB_ERR_INVALID_ARG, "sb_finalize: a captured halo schedule needs use_graph = 1");
@@ -1561,6 +1565,19 @@ int sb_finalize(sb_solver *s) {
             const sbp::LocalPlan &L = s->plan->local;
             bool t1_halo = false;
             if (L.halo.size() > 1) for (int r = 0; r < L.world; ++r) t1_halo |= !L.halo[1].send_idx[(size_t)r].empty() || !L.halo[1].recv_idx[(size_t)r].empty();
+            // SB_SCHEDULE_AUTO (RCCL between devices): xGMI is point-to-point, one link per pair of GPUs, and a rank's ghosts for one
+            // peer travel as one message -- an exchange cannot end before its largest message has crossed its link (<= 77 GB/s per
+            // direction). From kAutoOverlapBytes per peer on (13 us at the link's peak, several times that in practice) the exchange
+            // lasts longer than the two cross-stream events and the two extra launches of the overlapped schedule cost (measured on
+            // one device, where the link time is zero: + 5 .. 15 us per exchange, profiles/r03q_loopback_w2_w4_schedules.txt), so it is
+            // run beside the interior tiles; below that the serialised schedule. A model-based choice: no schedule has run between two
+            // devices yet. Eager in both cases (captured schedules stay opt-in).
+            constexpr int64_t kAutoOverlapBytes = 1 << 20;
+            if (sched_auto && s->comm && !s->peer.enabled && L.halo.size() > 1) {
+                int64_t largest = 0;
+                for (int r = 0; r < L.world; ++r) largest = std::max<int64_t>(largest, (int64_t)L.halo[1].send_idx[(size_t)r].size() * 24);
+                if (largest >= kAutoOverlapBytes) sched = SB_SCHEDULE_OVERLAP_EAGER;
+            }
             const bool want_overlap = sched == SB_SCHEDULE_OVERLAP_EAGER || sched == SB_SCHEDULE_OVERLAP_GRAPH;
             s->overlap_halo = want_overlap && s->desc.world > 1 && s->comm && P.tiling && P.gcolours.empty() && P.t2_layers.empty() && t1_halo;
             if (want_overlap && !s->overlap_halo)      // T2 layers / global colours (irregular mesh) or no T1 halo: the serialised form
@@ -1617,6 +1634,9 @@ int sb_finalize(sb_solver *s) {
         if (s->overlap_halo) {
             // opt-in: on the one measurement available (RCCL loopback on one GPU, 8-rank share of 256^3) splitting the T0
             // launch and running the exchange beside the interior tiles pays only inside a captured graph
+            // (an ordinary stream: a highest-priority one -- meant to keep the pack kernel and RCCL's few workgroups from queueing behind
+            // the interior launch -- made the eager overlapped tick FOUR TIMES slower on this runtime, 0.93 -> 3.35 ms in the W = 8
+            // loopback, profiles/r03r_loopback_w8_priority_stream_not_kept.txt)
             HIP_CHECK(hipStreamCreateWithFlags(&s->comm_stream, hipStreamNonBlocking));
             HIP_CHECK(hipEventCreateWithFlags(&s->ev_boundary, hipEventDisableTiming));
             HIP_CHECK(hipEventCreateWithFlags(&s->ev_halo, hipEventDisableTiming));
@@ -1673,7 +1693,7 @@ int sb_step(sb_solver *s, float dt, int32_t substeps) {
         if (s->peer.enabled && s->desc.world > 1 && !s->peer.linked) peer_link(s);     // (reads the neighbours' offset tables: not inside a capture)
         // lazy tick boundary: fuse with the previous tick's deferred last kernel when nothing changed
         const sbk::TickParams tp_new = tick_params(s, dt, substeps);
-        const bool can_defer = !s->overlap_halo && s->lazy_tick && (!s->plan->plan.tiling || (substeps & 1) == 0);
+        const bool can_defer = s->lazy_tick && (!s->plan->plan.tiling || (substeps & 1) == 0);
         const bool fuse = s->deferred && can_defer && s->deferred_substeps == substeps && s->tp_valid &&
                           std::memcmp(&tp_new, &s->tp_host, sizeof(tp_new)) == 0;
         if (!fuse) flush_deferred(s);

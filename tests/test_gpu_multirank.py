@@ -264,3 +264,32 @@ def test_ranks_that_own_nothing_on_the_device(oracle_mod, partition):
     for _ in range(2):
         ref.step(0.02, 4)
     assert np.array_equal(x.view(np.uint32), ref.x.view(np.uint32)) and np.array_equal(v.view(np.uint32), ref.v.view(np.uint32))
+
+
+def test_auto_schedule_follows_the_size_of_the_exchange():
+    """SB_SCHEDULE_AUTO: the overlapped eager schedule when the largest per-peer message of the T1 exchange is >= 1 MiB (between devices
+    the exchange is then bound by the one xGMI link it crosses), the serialised eager one below; either way the bits of the explicit
+    serialised schedule (RCCL self-exchange on a size-1 communicator)."""
+    import hashlib
+    from softbodyunity_amd import Softbody, comm_unique_id, native
+    from softbodyunity_amd.mesh import jelly_cube
+
+    def run(mesh, schedule):
+        sb = Softbody(mesh, substeps=6, device=0, rank=0, world=2, unique_id=comm_unique_id(), halo_schedule=schedule,
+                      debug_flags=native.SB_DEBUG_LOOPBACK).Start()
+        try:
+            st = sb.stats()
+            for _ in range(3):
+                sb.step()
+            sb.synchronize()
+            return st["halo_schedule"], 24 * st["halo_particles_t1"], hashlib.sha256(sb.get_positions()[sb.owner() == 0].tobytes()).hexdigest()
+        finally:
+            sb.OnDestroy()
+
+    small, large = jelly_cube(32), jelly_cube(112)
+    sched, nbytes, h_auto = run(small, native.SB_SCHEDULE_AUTO)
+    assert sched == native.SB_SCHEDULE_SERIAL_EAGER and nbytes < (1 << 20)
+    sched, nbytes, h_auto = run(large, native.SB_SCHEDULE_AUTO)
+    assert sched == native.SB_SCHEDULE_OVERLAP_EAGER and nbytes >= (1 << 20)
+    sched, _, h_serial = run(large, native.SB_SCHEDULE_SERIAL_EAGER)
+    assert sched == native.SB_SCHEDULE_SERIAL_EAGER and h_serial == h_auto

@@ -17,7 +17,12 @@ import numpy as np
 from softbodyunity_amd import Softbody, comm_unique_id
 from softbodyunity_amd.mesh import jelly_cube
 mesh = jelly_cube(256)
-sb = Softbody(mesh, substeps=20, device=0, rank=0, world=%d, unique_id=comm_unique_id()).Start()
+from softbodyunity_amd import native
+sched = native.halo_schedule_from_env()
+if sched == native.SB_SCHEDULE_AUTO and not os.environ.get("LB_SCHEDULE"):
+    sched = native.SB_SCHEDULE_SERIAL_EAGER
+sb = Softbody(mesh, substeps=20, device=0, rank=0, world=%d, unique_id=comm_unique_id(), halo_schedule=sched).Start()
+print("SCHEDULE", sb.stats()["halo_schedule"], flush=True)
 for _ in range(10):
     sb.step()
 sb.synchronize()
@@ -31,13 +36,17 @@ print("RESULT %%.4f ms/tick hash %%s finite %%s" %% (ms, hashlib.sha256(x.tobyte
 sb.OnDestroy()
 ''' % (ROOT, WORLD, TICKS, TICKS)
 
+# (since round 3 SB_SCHEDULE_AUTO picks the overlapped eager schedule when the largest per-peer message is >= 1 MiB: the "overlap=0 graph=0"
+# row therefore asks for the serialised eager schedule explicitly, LB_SERIAL_EAGER -> halo_schedule = SB_SCHEDULE_SERIAL_EAGER)
 for transport in (("rccl",) if ONLY_RCCL else ("rccl", "peer")):
-    for overlap, graph in ((("", ""),) if ONLY_SERIAL else (("", ""), ("", "1"), ("1", ""), ("1", "1"))):
+    for overlap, graph in ((("", ""),) if ONLY_SERIAL else (("", ""), ("", "1"), ("1", ""), ("1", "1"), ("auto", ""))):
         env = dict(os.environ, SB_TEST_LOOPBACK="1")
-        for k, v in (("SB_HALO_OVERLAP", overlap), ("SB_GRAPH_RCCL", graph), ("SB_HALO_TRANSPORT", "peer" if transport == "peer" else "")):
+        for k, v in (("SB_HALO_OVERLAP", "" if overlap == "auto" else overlap), ("SB_GRAPH_RCCL", graph), ("SB_HALO_TRANSPORT", "peer" if transport == "peer" else ""),
+                     ("LB_SCHEDULE", "auto" if overlap == "auto" else "")):
             env.pop(k, None)
             if v:
                 env[k] = v
         r = subprocess.run([sys.executable, "-X", "faulthandler", "-c", CHILD], env=env, capture_output=True, text=True, timeout=400)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT")]
-        print(f"W={WORLD} {transport} overlap={overlap or 0} graph={graph or 0}: rc={r.returncode} {line[0] if line else r.stderr[-300:]}", flush=True)
+        sch = [l for l in r.stdout.splitlines() if l.startswith("SCHEDULE")]
+        print(f"W={WORLD} {transport} overlap={overlap or 0} graph={graph or 0}: rc={r.returncode} {line[0] if line else r.stderr[-300:]} [{sch[0] if sch else ''}]", flush=True)
