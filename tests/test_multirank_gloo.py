@@ -13,7 +13,7 @@ import torch.multiprocessing as mp
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, tile, out_dir, sharded=False):
+def _worker(rank, world, port, tile, out_dir, sharded=False, tet=False):
     sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
     os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -24,6 +24,11 @@ def _worker(rank, world, port, tile, out_dir, sharded=False):
         win = jelly_cube_window(32, rank, world, (0, 0, 0), tile, pin_top=True)
         R = WindowRankSim(oracle, win, rank, world, (0, 0, 0), tile)
         R.o.params.compliance[0] = 1e-7
+    elif tet:        # irregular tet mesh (springs + volumes + hinges), cost-weighted RCB ownership, T2 layers with their own exchanges
+        from softbodyunity_amd import native
+        from softbodyunity_amd.mesh import bunny_surrogate
+        mesh = bunny_surrogate(3000)
+        R = RankSim(oracle, mesh, rank, world, (0, 0, 0), tile, (0.0, -9.81, 0.0), 0.0, (1e-7, 0.0, 1e-6), partition=native.SB_PARTITION_RCB)
     else:
         mesh = jelly_cube(16, pin_top=True)
         R = RankSim(oracle, mesh, rank, world, (0, 0, 0), tile, (0.0, -9.81, 0.0), 0.0, (1e-7, 0.0, 0.0))
@@ -93,4 +98,26 @@ def test_four_ranks_gloo_on_their_windows_equal_single(tmp_path, oracle_mod):
         g = d["gid"][d["owned"]]
         x[g] = d["x"][d["owned"]]; v[g] = d["v"][d["owned"]]; cover[g] += 1
     assert np.all(cover == 1)
+    assert np.array_equal(x.view(np.uint32), ref.x.view(np.uint32)) and np.array_equal(v.view(np.uint32), ref.v.view(np.uint32))
+
+
+def test_three_ranks_gloo_rcb_tet_mesh_equal_single(tmp_path, oracle_mod):
+    # the irregular-mesh partition (cost-weighted RCB, an odd rank count) over a real process boundary: springs, volumes and hinges,
+    # T0/T1 tiles plus the sparse T2 layers and their own ghost exchanges
+    from softbodyunity_amd import native
+    from softbodyunity_amd.mesh import bunny_surrogate
+    from helpers import build_plan, make_oracle
+    world, tile = 3, 128
+    port = 29500 + (os.getpid() % 2000) + 11
+    mp.spawn(_worker, args=(world, port, tile, str(tmp_path), False, True), nprocs=world, join=True)
+    mesh = bunny_surrogate(3000)
+    ref = make_oracle(oracle_mod, mesh, build_plan(mesh, tile_particles=tile), compliance=(1e-7, 0.0, 1e-6))
+    for _ in range(2):
+        ref.step(0.02, 6)
+    x = np.zeros_like(ref.x); v = np.zeros_like(ref.v); cover = np.zeros(mesh.n, int)
+    owned = []
+    for r in range(world):
+        d = np.load(tmp_path / f"rank{r}.npz")
+        x[d["owned"]] = d["x"][d["owned"]]; v[d["owned"]] = d["v"][d["owned"]]; cover += d["owned"]; owned.append(int(d["owned"].sum()))
+    assert np.all(cover == 1) and min(owned) > 0
     assert np.array_equal(x.view(np.uint32), ref.x.view(np.uint32)) and np.array_equal(v.view(np.uint32), ref.v.view(np.uint32))
