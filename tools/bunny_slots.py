@@ -1,5 +1,5 @@
 import os, sys, json
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from softbodyunity_amd import Softbody
 from softbodyunity_amd.mesh import bunny_surrogate
 mesh = bunny_surrogate(target_verts=100000)

@@ -2,7 +2,7 @@
 """Config 5 (100 k surrogate): ms per tick against tile_particles (two interleaved rounds) + tiles / T2 layers / T2 tiles.
 usage: python tools/bunny_tile_sweep.py"""
 import json, os, sys, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from softbodyunity_amd import Softbody
 from softbodyunity_amd.mesh import bunny_surrogate
 mesh = bunny_surrogate(target_verts=100_000)
