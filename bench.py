@@ -91,6 +91,9 @@ def main():
     real_stdout = os.dup(1)
     os.dup2(2, 1)
 
+    # multi-process GPU work on this image needs dmabuf IPC (RCCL's and hipIpc's handle exchange fail with the legacy mode); the
+    # launch environment exports it already -- keep it if a launcher scrubbed the environment. Must precede the first HIP call.
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
