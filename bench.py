@@ -121,13 +121,13 @@ def main():
 
     t_setup = time.time()
     # N > 1: sharded authoring -- every rank generates, hands over and plans only ITS WINDOW of the cube (its block + two cells
-    # of margin, include/softbody.h sb_domain); the whole 256^3 mesh exists nowhere. (--heterogeneous and --tile -1 keep the
-    # whole mesh on every rank.)
+    # of margin, include/softbody.h sb_domain); the whole 256^3 mesh exists nowhere. (--tile -1 and --whole-mesh keep the whole mesh
+    # on every rank.)
     part_world = args.loopback_world if args.loopback_world > 1 else world        # (the loopback diagnostic is rank 0 of that many ranks)
-    sharded = part_world > 1 and not args.heterogeneous and args.tile > 0 and not args.whole_mesh
+    sharded = part_world > 1 and args.tile > 0 and not args.whole_mesh
     if sharded:
         from softbodyunity_amd.mesh import jelly_cube_window
-        mesh = jelly_cube_window(args.n, rank, part_world, _dims(part_world), args.tile)
+        mesh = jelly_cube_window(args.n, rank, part_world, _dims(part_world), args.tile, heterogeneous=args.heterogeneous)
     else:
         mesh = jelly_cube(args.n, heterogeneous=args.heterogeneous)
     mesh_s = time.time() - t_setup

@@ -95,11 +95,13 @@ def jelly_cube(n, spacing=1.0, perturb=0.05, seed=1234, pin_top=False, stencil="
                         dist_rest=rest_len, label=f"jelly_cube_{n}^3_{stencil}" + ("_heterogeneous" if heterogeneous else ""))
 
 
-def jelly_cube_window(n, rank, world, part_dims=(0, 0, 0), tile_particles=512, spacing=1.0, perturb=0.05, seed=1234, pin_top=False):
+def jelly_cube_window(n, rank, world, part_dims=(0, 0, 0), tile_particles=512, spacing=1.0, perturb=0.05, seed=1234, pin_top=False,
+                      heterogeneous=False):
     """The part of jelly_cube(n) rank `rank` of `world` hands over under sharded authoring: the lattice points inside the box
     sb_domain_window gives for it, the structural springs among them (x, then y, then z, each in ascending order of the lower end
     point: the whole cube's order restricted to the window), ids of the whole cube in `global_id`. Positions are the whole cube's
-    (the jitter stream is drawn for the window's planes only: O(window) memory, identical values)."""
+    (the jitter stream is drawn for the window's planes only: O(window) memory, identical values); heterogeneous=True likewise
+    reproduces the whole cube's per-particle masses and per-spring rest-length factors by seeking in their stream."""
     from . import native
     N = n ** 3
     hi_c = float(np.float32(n - 1) * np.float32(spacing))
@@ -134,10 +136,30 @@ def jelly_cube_window(n, rank, world, part_dims=(0, 0, 0), tile_particles=512, s
         edges.append(np.stack([a, a + off], axis=1))
     ij = np.concatenate(edges).astype(np.int32)
     w = np.ones(len(gid), np.float32)
+    rest_len = np.full(ij.shape[0], spacing, np.float32)
+    if heterogeneous:
+        # jelly_cube draws, from default_rng(seed + 1): N masses in particle order, then one factor per spring in spring order
+        # (x springs by (iz, iy, ix < n-1), y springs by (iz, iy < n-1, ix), z springs by (iz < n-1, iy, ix)): seek plane by plane
+        def planes(offset, rows, cols, zs, ys, xs, lo_v, hi_v):
+            out = np.empty((len(zs), len(ys), len(xs)), np.float64)
+            for k, iz in enumerate(zs):
+                h = np.random.default_rng(seed + 1)
+                h.bit_generator.advance(offset + int(iz) * rows * cols)
+                out[k] = h.uniform(lo_v, hi_v, size=(rows, cols))[np.ix_(ys, xs)]
+            return out.reshape(-1)
+        zs, ys, xs = np.arange(z0, z1), np.arange(y0, y1), np.arange(x0, x1)
+        w = (1.0 / planes(0, n, n, zs, ys, xs, 0.5, 2.0)).astype(np.float32)
+        m1 = n * n * (n - 1)
+        fac = np.concatenate([planes(N, n, n - 1, zs, ys, xs[:-1], 0.95, 1.05),
+                              planes(N + m1, n - 1, n, zs, ys[:-1], xs, 0.95, 1.05),
+                              planes(N + 2 * m1, n, n, zs[:-1], ys, xs, 0.95, 1.05)])
+        d = pos[ij[:, 0]].astype(np.float64)
+        d -= pos[ij[:, 1]]
+        rest_len = (np.sqrt(np.einsum("ij,ij->i", d, d)) * fac).astype(np.float32)
     if pin_top:
         w[gy.reshape(-1) == n - 1] = 0.0
     m = SoftbodyMesh(rest_pos=rest, pos=pos, vel=np.zeros_like(pos), inv_mass=w, dist_ij=ij,
-                     dist_rest=np.full(ij.shape[0], spacing, np.float32), label=f"jelly_cube_{n}^3_window_of_rank_{rank}/{world}")
+                     dist_rest=rest_len, label=f"jelly_cube_{n}^3_window_of_rank_{rank}/{world}" + ("_heterogeneous" if heterogeneous else ""))
     m.domain = dom
     m.global_id = gid.astype(np.int32)
     return m

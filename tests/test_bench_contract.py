@@ -61,21 +61,23 @@ def test_bench_checks_itself_against_the_golden_checksums_and_the_live_oracle():
 
 
 @pytest.mark.gpu
-def test_bench_multi_rank_launch_on_one_gpu_through_the_peer_transport():
+@pytest.mark.parametrize("het", [False, True])
+def test_bench_multi_rank_launch_on_one_gpu_through_the_peer_transport(het):
     # the driver's N > 1 launch (torch.distributed.run, one process per rank) on the ONE GPU of the box: the ranks share the device
     # and exchange ghosts through the peer-store mailboxes (RCCL refuses several ranks on one device). Everything of the multi-rank
     # bench except RCCL / xGMI runs: gloo control plane, per-rank plan of the split mesh, state checksum summed over the ranks
     # against the oracle's golden value, max-over-ranks timing, one JSON line from rank 0.
     env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
-    port = 29700 + os.getpid() % 200
+    port = 29700 + os.getpid() % 200 + (200 if het else 0)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "peer", "--cube-edge", "64",
-                          "--steps", "4", "--warmup", "2"], capture_output=True, text=True, timeout=900, env=env)
+                          "--steps", "4", "--warmup", "2"] + (["--heterogeneous"] if het else []), capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
     j = json.loads(lines[0])
     assert j["n_gpus"] == 2 and j["scaling"] == "strong" and j["config"]["partition"] == "2x1x1" and j["config"]["halo_transport"] == "peer"
+    assert j["config"]["authoring"].startswith("sharded") and ("HETEROGENEOUS" in j["config"]["workload"]) == het     # windows in both layouts
     g = j["config"]["parity"]["golden"]
     assert g["n"] == 64 ** 3 and g["bitwise"] is True and g["expected"] is not None
     assert j["config"]["finite"] is True and j["value"] > 0 and "cpu_baseline" not in j

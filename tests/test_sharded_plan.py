@@ -105,11 +105,30 @@ def test_window_violations_are_rejected():
         native.Plan.build(win.rest_pos, win.dist_ij, **kw)
 
 
-def test_partitioned_run_on_windows_equals_the_unpartitioned_oracle(oracle_mod):
+@pytest.mark.parametrize("world,dims", [(2, (0, 0, 0)), (8, (0, 0, 0)), (6, (1, 3, 2))])
+def test_heterogeneous_window_carries_the_whole_cubes_masses_and_rest_lengths(world, dims):
+    # per-particle masses and per-spring rest lengths of jelly_cube(heterogeneous=True), reproduced for a window by seeking in the stream
+    n, tile = 24, 64
+    whole = jelly_cube(n, heterogeneous=True, pin_top=True)
+    key = whole.dist_ij[:, 0].astype(np.int64) * whole.n + whole.dist_ij[:, 1]
+    order = np.argsort(key); ks = key[order]
+    for rank in range(world):
+        win = jelly_cube_window(n, rank, world, dims, tile, heterogeneous=True, pin_top=True)
+        g = win.global_id.astype(np.int64)
+        assert np.array_equal(win.pos, whole.pos[g]) and np.array_equal(win.inv_mass.view(np.uint32), whole.inv_mass[g].view(np.uint32))
+        k = g[win.dist_ij[:, 0]] * whole.n + g[win.dist_ij[:, 1]]
+        at = np.searchsorted(ks, k)
+        assert np.array_equal(ks[at], k) and np.array_equal(win.dist_rest.view(np.uint32), whole.dist_rest[order[at]].view(np.uint32))
+        assert len(np.unique(win.dist_rest)) > 0.9 * len(win.dist_rest)
+
+
+@pytest.mark.parametrize("het", [False, True])
+def test_partitioned_run_on_windows_equals_the_unpartitioned_oracle(oracle_mod, het):
     n, tile, world, S = 32, 64, 8, 6
-    whole = jelly_cube(n, pin_top=True)
+    whole = jelly_cube(n, pin_top=True, heterogeneous=het)
     ref = make_oracle(oracle_mod, whole, build_plan(whole, tile_particles=tile))
-    ranks = [WindowRankSim(oracle_mod, jelly_cube_window(n, r, world, (0, 0, 0), tile, pin_top=True), r, world, (0, 0, 0), tile) for r in range(world)]
+    ranks = [WindowRankSim(oracle_mod, jelly_cube_window(n, r, world, (0, 0, 0), tile, pin_top=True, heterogeneous=het), r, world, (0, 0, 0), tile)
+             for r in range(world)]
 
     def exchange(slot, with_prev):
         staged = []
