@@ -69,6 +69,16 @@ def test_cfg2_cube64_20substeps(oracle_mod, tile, graph):
         assert st["n_tiles"][0] == 512 and 512 <= st["n_tiles"][1] <= 520
 
 
+def test_cfg2_state_after_100_ticks(oracle_mod):
+    # SURVEY.md 8c parity metric: state T with T = 100 ticks (2 000 substeps) -- the cube hangs from its pinned top layer and swings;
+    # max_i |x_gpu - x_cpu| / diag(bbox_0) <= 1e-4 is the stated bar, identical bits the expected outcome
+    mesh = jelly_cube(64, pin_top=True)
+    rel, mabs, bit, x, v, o, st = _run_pair(oracle_mod, mesh, ticks=100, substeps=20)
+    assert rel <= TOL and bit, (rel, mabs)
+    assert np.array_equal(v.view(np.uint32), o.v.view(np.uint32))
+    assert np.abs(x - mesh.pos).max() > 0.25      # it really went somewhere
+
+
 def test_pinned_top_layer_and_damping_and_compliance(oracle_mod):
     mesh = jelly_cube(20, pin_top=True)
     rel, mabs, bit, x, v, o, st = _run_pair(oracle_mod, mesh, ticks=10, substeps=8, compliance=(1e-6, 0, 0), damping=0.5,
@@ -140,6 +150,26 @@ def test_state_round_trip(oracle_mod):
 @pytest.fixture(scope="module")
 def bunny20k():
     return bunny_surrogate(target_verts=20000, seed=1234)
+
+
+def test_cfg5_surrogate_state_after_60_ticks_on_the_ground(oracle_mod, bunny20k):
+    # a long run on the irregular mesh: springs + volumes + hinges, dropped on a ground plane, 60 ticks x 20 substeps, bit for bit
+    mesh = bunny20k
+    comp = (1e-7, 1e-7, 1e-5)
+    plane = (0.0, 1.0, 0.0, float(mesh.pos[:, 1].min()) - 0.05)
+    sb = Softbody(mesh, substeps=20, distance_compliance=comp[0], volume_compliance=comp[1], bending_compliance=comp[2], ground_plane=plane).Start()
+    try:
+        o = make_oracle(oracle_mod, mesh, sb.plan(), compliance=comp, ground_plane=plane)
+        for _ in range(60):
+            sb.FixedUpdate(readback=False)
+            o.step(0.02, 20)
+        x = sb.get_positions(); v = sb.get_velocities()
+    finally:
+        sb.OnDestroy()
+    rel, mabs, bit = oracle_mod.parity_error(x, o.x, mesh.pos)
+    assert np.isfinite(x).all() and rel <= TOL and bit, (rel, mabs)
+    assert np.array_equal(v.view(np.uint32), o.v.view(np.uint32))
+    assert x[:, 1].min() >= plane[3] - 1e-6 and np.abs(x - mesh.pos).max() > 0.02      # it landed
 
 
 @pytest.mark.parametrize("tile", [256, -1])
