@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""profiles/<tag>_bunny100k_summary.md: kernel-trace table of the 100k surrogate + planner statistics (groups per tile, lanes
-busy per group). usage: python tools/bunny_summary.py <rocprof dir> <tag>"""
+"""profiles/<tag>_bunny100k_summary.md: kernel-trace table of the tet surrogate (100 k vertices; BUNNY_VERTS / BUNNY_CACHE as in
+tools/bunny_run.py) + planner statistics (groups per tile, lanes busy per group). usage: python tools/bunny_summary.py <rocprof dir> <tag>"""
 import collections
 import csv
 import os
@@ -19,7 +19,12 @@ for f in os.listdir(d):
         for r in csv.DictReader(open(os.path.join(d, f))):
             wg = int(r["Grid_Size_X"]) // max(int(r["Workgroup_Size_X"]), 1)
             acc[(r["Kernel_Name"][:58], wg, int(r["Workgroup_Size_X"]))].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-print(f"# config 5 surrogate (100 297 vertices, 755 897 springs, 648 604 tets, 20 959 hinges), 20 substeps per tick ({tag})\n")
+import pickle  # noqa: E402
+verts = int(os.environ.get("BUNNY_VERTS", "100000"))       # (same switches as tools/bunny_run.py)
+cache = os.environ.get("BUNNY_CACHE")
+mesh = pickle.load(open(cache, "rb")) if cache and os.path.exists(cache) else bunny_surrogate(target_verts=verts)
+print(f"# tet surrogate ({mesh.n} vertices, {len(mesh.dist_rest)} springs, {len(mesh.vol_rest)} tets, {len(mesh.bend_rest)} hinges"
+      f"{'; config 5' if verts == 100000 else ''}), 20 substeps per tick ({tag})\n")
 print("## rocprofv3 --kernel-trace: per launch shape\n")
 print("| kernel | workgroups | lanes | launches | avg µs | total ms |\n|---|---|---|---|---|---|")
 tot = 0
@@ -28,7 +33,6 @@ for k in sorted(acc, key=lambda k: -sum(acc[k])):
     tot += sum(v)
     print(f"| `{k[0]}` | {k[1]} | {k[2]} | {len(v)} | {np.mean(v) / 1e3:.1f} | {sum(v) / 1e6:.2f} |")
 print(f"\nsum of kernel time over the 25 ticks of the run: {tot / 1e6:.1f} ms = {tot / 25e6:.2f} ms per tick\n")
-mesh = bunny_surrogate(target_verts=100_000)
 plan = native.Plan.build(mesh.rest_pos, mesh.dist_ij, mesh.vol_ijkl, mesh.bend_ijkl)      # tile_particles = 0: automatic (256)
 types, ids = plan.order(0)
 tasks, groups = plan.tasks(0), plan.groups(0)
