@@ -1,4 +1,4 @@
-// SoftbodyNative.cs — P/Invoke layer over libsoftbody_mi355x.so (include/softbody.h, ABI version 6).
+// SoftbodyNative.cs — P/Invoke layer over libsoftbody_mi355x.so (include/softbody.h, ABI version 7).
 //
 // One [DllImport] per exported function, same name and argument order as the header; the Python twin
 // used by the test-suite is softbodyunity_amd/native.py (tests/test_abi.py keeps the three in sync).
@@ -49,6 +49,7 @@ namespace SoftbodyMI355X
         public long haloParticlesRecv;
         public ulong planHash;
         public int haloSchedule, haloUnpackFused;
+        public long readbackPeeks, readbackPeekTiles;   // position reads served by a peek; T0 workgroups of one render-set peek (-1: none set up)
     }
 
     [StructLayout(LayoutKind.Sequential, CharSet = CharSet.Ansi)]

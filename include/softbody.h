@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define SB_ABI_VERSION 6
+#define SB_ABI_VERSION 7
 
 typedef enum {
     SB_OK = 0,
@@ -163,8 +163,10 @@ int sb_peer_connect(sb_solver *s, int32_t rank, const uint8_t handle[SB_IPC_HAND
 /* ---- the hot path (FixedUpdate) -------------------------------------------------------------- */
 /* One tick of `substeps` substeps (SPEC.md §2). Asynchronous: work is enqueued on the solver's stream. The last
  * kernel of a tick may be held back and fused with the next tick when dt/substeps/plane are unchanged; every call
- * that reads or writes state (sb_get_*, sb_set_state, sb_readback_begin, sb_synchronize, ...) completes it first, so
- * the laziness is not observable. */
+ * that reads or writes state (sb_get_velocities, sb_set_state, sb_synchronize, ...) completes it first, so the laziness is
+ * not observable. Position reads of a single-rank solver (sb_get_positions, sb_readback_begin) do not even need that: they
+ * PEEK -- the held-back kernel's constraint rounds and collision run on the tiles in question into a side array, bit for bit
+ * what the completed tick would hold, and the tick stays fusable with the next one (sb_stats.readback_peeks). */
 int sb_step(sb_solver *s, float dt, int32_t substeps);
 
 /* ---- readback / state round trip ------------------------------------------------------------- */
@@ -179,7 +181,9 @@ int sb_set_state(sb_solver *s, const float *pos_xyz, const float *vel_xyz, int32
  * returns a pointer to n*3 floats in caller numbering (entries of particles another rank owns stay 0), valid
  * until the second sb_readback_begin after it (the plugin keeps three snapshot buffers for at most two pending
  * snapshots, so the buffer handed out last is never the next one filled). sb_set_render_triangles re-allocates the
- * render-set buffers and invalidates pointers returned earlier. */
+ * render-set buffers and invalidates pointers returned earlier.
+ * Cost between two ticks (world == 1): the tick's held-back last kernel is not forced out; with render_set_only the peek
+ * runs only the T0 tiles that hold a render particle (256^3 cube: 5 768 of 32 768 workgroups). */
 int sb_readback_begin(sb_solver *s);
 int sb_readback_end(sb_solver *s, const float **pos_xyz_out);
 /* Render normals (SPEC.md 6a; replaces Unity's Mesh.RecalculateNormals on the main thread): give the render
@@ -248,6 +252,10 @@ typedef struct {
     uint64_t plan_hash;                             /* hash of the published orders, ownership and plan options: equal on every rank */
     int32_t halo_schedule;                          /* SB_SCHEDULE_* in force (what AUTO resolved to) */
     int32_t halo_unpack_fused;                      /* 1 = the T1 kernels read their ghosts straight from the receive buffer (no unpack launch) */
+    /* position reads served by a peek so far (see sb_readback_begin), and the T0 workgroups one render-set peek launches
+     * (-1 = no render-set peek has been set up) */
+    int64_t readback_peeks;
+    int64_t readback_peek_tiles;
 } sb_stats;
 int sb_get_stats(sb_solver *s, sb_stats *out);
 

@@ -102,6 +102,9 @@ struct TileArgs {
     // ghost order) instead of from the arrays -- the unpack kernel between the exchange and this launch is gone
     const float *ghost_src;
     int32_t n_owned;
+    // KIND 4 (peek): where the tick-end positions of the launch's tiles go (packed xyz, device numbering); the state arrays stay as
+    // they are
+    float *peek_out;
 };
 // (A PACK variant -- T0 tiles writing the send buffer themselves, entries {tile-local index, send slot} per tile -- was built and
 // measured in round 3: bit-exact, but 0.786 -> 0.861 ms per tick in the serialised W = 8 loopback schedule and no change in the
@@ -412,6 +415,9 @@ __device__ __forceinline__ bool project_bending_row(const float (&P)[4], float r
 //                                      (start substep s), the same rounds again
 //   KIND 2 (after the last substep)  : the tile's rounds, MARK: write v, stop
 //   KIND 3 (T2 layer, every substep)  : the tile's rounds once, no MARK; the particles come from an explicit list
+//   KIND 4 (peek at the tick's end)   : what KIND 2 would leave as positions (the tile's rounds + collide), written to a side
+//                                      array; nothing of the state is written, so the deferred last kernel of a tick can still
+//                                      be fused with the first kernel of the next one (render readback, solver.hip peek_positions)
 // Particles AND the tile's constraint stream are staged in LDS with wide coalesced loads issued together,
 // so a tile pays the HBM latency once; rounds then run LDS-to-LDS with one barrier each. Each lane keeps
 // ownership of up to PPT particles for the MARK step and projects kRoundSlots / THREADS constraints per round.
@@ -495,7 +501,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
     // virtual program: rounds 0..R-1 (finish the previous substep), MARK, rounds 0..R-1 again (start the next)
     const int R = n_rounds_all;
     const int v_begin = KIND == 0 ? R : 0;
-    const int v_end = KIND == 3 ? R : (KIND == 2 ? R + 1 : 2 * R + 1);
+    const int v_end = KIND == 3 ? R : (KIND == 2 || KIND == 4 ? R + 1 : 2 * R + 1);
     const uint32_t d_lo = td.s_hdr;
     const uint32_t d_hi = td.s_len;
     const uint32_t win = (uint32_t)A.win_dwords;
@@ -532,7 +538,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
         X[m].x = px[0]; X[m].y = px[1]; X[m].z = px[2];
         if (WPAL) { wi[m] = A.w8[A.w_uniform ? 0 : gc]; X[m].w = 0.0f; } else { wi[m] = 0; X[m].w = A.pos.w[gc]; }
         pvx[m] = pvy[m] = pvz[m] = 0.0f;
-        if (KIND != 0 && KIND != 3) {
+        if (KIND != 0 && KIND != 3 && KIND != 4) {
             const float *pp = ghost ? px + 3 : A.prev + 3 * (size_t)gc;
             pvx[m] = pp[0]; pvy[m] = pp[1]; pvz[m] = pp[2];
         }
@@ -616,9 +622,10 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
                     if (pen < 0.0f) {
                         float dx = pen * tp.pnx, dy = pen * tp.pny, dz = pen * tp.pnz;
                         P.x = P.x - dx; P.y = P.y - dy; P.z = P.z - dz;
-                        if (KIND == 2) lds_pos[l] = P;
+                        if (KIND == 2 || KIND == 4) lds_pos[l] = P;
                     }
                 }
+                if (KIND == 4) continue;     // (a peek ends with the collided positions: no velocity, no state write)
                 float vx, vy, vz;
                 const size_t o = 3 * (size_t)g[m];
                 if (KIND == 0) {
@@ -983,7 +990,8 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
     for (int m = 0; m < PPT; ++m)
         if (g[m] >= 0) {
             const float4 P = lds_pos[tid + m * kTileThreads];
-            if (A.store_through & 2) store3_through(A.pos.xyz + 3 * (size_t)g[m], P.x, P.y, P.z);
+            if (KIND == 4) { float *o = A.peek_out + 3 * (size_t)g[m]; o[0] = P.x; o[1] = P.y; o[2] = P.z; }
+            else if (A.store_through & 2) store3_through(A.pos.xyz + 3 * (size_t)g[m], P.x, P.y, P.z);
             else pv_store(A.pos, g[m], P);
         }
 }

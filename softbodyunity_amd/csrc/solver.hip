@@ -269,6 +269,14 @@ struct sb_solver {
     float *h_nrm[kSnapSlots] = {nullptr, nullptr, nullptr};
     bool snap_has_normals[kSnapSlots] = {false, false, false};
     int snap_last_ended = -1;
+    // Peek (world == 1): a position read while the tick's last kernel is deferred runs tile_kernel<4> -- the same rounds + collide on
+    // the same inputs, written to d_peek instead of the state -- so the deferred kernel can still be fused with the next tick's first
+    // one. A render-set-only readback peeks only at the T0 tiles that hold a render particle (peek_tiles: copies of their descriptors).
+    DevBuf<float> d_peek;                  // packed xyz per local particle; only the peeked tiles' entries are ever written or read
+    DevBuf<sbk::TileDesc> peek_tiles;
+    int32_t n_peek_tiles = -1;             // -1: not built for the current render set
+    bool peek_enabled = true;              // SB_NO_PEEK unset (read once in sb_create)
+    int64_t n_peeks = 0;                   // launches so far (sb_stats.readback_peeks)
 
     ~sb_solver() {
         // Teardown order: everything the device may still be running for this solver first (compute, exchange and copy
@@ -1063,8 +1071,9 @@ void halo_exchange(sb_solver *s, int slot, hipStream_t st = nullptr) {
     }
 }
 
+// `table` (KIND 4 only): a descriptor table of its own -- copies of some of D's descriptors -- instead of D's tiles [tile_begin, tile_end)
 template <int KIND>
-void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = -1, int halo = sbk::kHaloNone) {
+void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = -1, int halo = sbk::kHaloNone, const sbk::TileDesc *table = nullptr) {
     const bool ghosts = halo == sbk::kHaloGhosts;
     if (tile_end < 0) tile_end = D.n_tiles;
     if (tile_end <= tile_begin) return;
@@ -1077,8 +1086,9 @@ void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = 
     A.item_waves = D.item_waves;
     A.store_through = tile_end - tile_begin <= s->store_through_max_tiles ? 3 : s->store_through_large;
     A.ghost_src = ghosts ? s->d_recvbuf.p : nullptr; A.n_owned = (int32_t)s->n_owned;
+    A.peek_out = KIND == 4 ? s->d_peek.p : nullptr;
     A.max_local = D.max_local; A.win_dwords = D.win_dwords; A.tile_base = tile_begin; A.pal_dwords = D.pal_dwords; A.rounds_dwords = D.rounds_dwords;
-    const sbk::TileDesc *tiles_at_base = D.tiles.p + tile_begin;      // the two preloaded kernel arguments (tile_kernel)
+    const sbk::TileDesc *tiles_at_base = table ? table : D.tiles.p + tile_begin;      // the two preloaded kernel arguments (tile_kernel)
     const int n_wg = tile_end - tile_begin;
     const bool small = D.max_local <= sbk::kSmallTile;   // every tile <= 512 particles
     // narrow (2-wave) workgroups once the launch oversubscribes the chip; wide ones while every tile is resident at once
@@ -1229,6 +1239,54 @@ void flush_deferred(sb_solver *s) {
     HIP_CHECK(hipGetLastError());
 }
 
+// ---- peek: tick-end positions without completing the tick ------------------------------------------------------------------------
+// While the last kernel K_S of a tick is deferred, the positions the tick ends with are K_S's rounds + collide applied to the state
+// in memory. tile_kernel<4> computes exactly that -- same tiles, same programs, same inputs, hence the same bits -- into d_peek and
+// leaves the state alone, so the next sb_step still fuses K_S with its first kernel (one launch instead of two) and a render
+// readback after every tick no longer costs a whole extra pass over the mesh. world == 1 only (a rank of a partitioned solver would
+// need its ghosts refreshed first).
+bool can_peek(const sb_solver *s) {
+    if (!s->peek_enabled || !s->deferred || s->desc.world != 1) return false;
+    const int tl = s->plan->plan.tiling ? (s->deferred_substeps & 1) : 0;
+    return tl == 0 && s->tiling[0].n_tiles > 0;
+}
+
+// The T0 device tiles (packs) that hold at least one particle of `wanted` (device numbering): copies of their descriptors.
+void build_peek_subset(sb_solver *s, const std::vector<int32_t> &wanted) {
+    DevTiling &D = s->tiling[0];
+    std::vector<sbk::TileDesc> tiles((size_t)D.n_tiles);
+    std::vector<int2> ovf(D.runs_overflow.count);
+    if (!tiles.empty()) HIP_CHECK(hipMemcpy(tiles.data(), D.tiles.p, tiles.size() * sizeof(sbk::TileDesc), hipMemcpyDeviceToHost));
+    if (!ovf.empty()) HIP_CHECK(hipMemcpy(ovf.data(), D.runs_overflow.p, ovf.size() * sizeof(int2), hipMemcpyDeviceToHost));
+    std::vector<uint8_t> is_wanted((size_t)s->n_local, 0);
+    for (int32_t g : wanted) is_wanted[(size_t)g] = 1;
+    std::vector<sbk::TileDesc> keep;
+    for (const sbk::TileDesc &td : tiles) {
+        bool hit = false;
+        for (int r = 0; r < td.run_count && !hit; ++r) {
+            auto run = [&](int q) { return q < sbk::kInlineRuns ? td.runs[q] : ovf[(size_t)(td.run_overflow + q - sbk::kInlineRuns)]; };
+            const int2 a = run(r);
+            const int end = r + 1 < td.run_count ? run(r + 1).y : td.n_local;
+            for (int l = a.y; l < end && !hit; ++l) hit = is_wanted[(size_t)(a.x + (l - a.y))] != 0;
+        }
+        if (hit) keep.push_back(td);
+    }
+    s->peek_tiles.upload(keep, s->dev_bytes);
+    s->n_peek_tiles = (int32_t)keep.size();
+}
+
+// Enqueue the peek on the solver's stream; afterwards d_peek holds the tick-end positions of every particle of the peeked tiles.
+// subset = only the tiles of build_peek_subset (render-set readback), else every T0 tile.
+void peek_positions(sb_solver *s, bool subset) {
+    DevTiling &D = s->tiling[0];
+    if (!s->d_peek.p) s->d_peek.alloc((size_t)s->n_local * 3, s->dev_bytes);
+    if (subset) {
+        if (s->n_peek_tiles > 0) launch_tile<4>(s, D, 0, s->n_peek_tiles, sbk::kHaloNone, s->peek_tiles.p);
+    } else launch_tile<4>(s, D);
+    HIP_CHECK(hipGetLastError());
+    ++s->n_peeks;
+}
+
 void upload_tick_params(sb_solver *s, float dt, int substeps) {
     sbk::TickParams tp = tick_params(s, dt, substeps);
     if (!s->tp_valid || std::memcmp(&tp, &s->tp_host, sizeof(tp)) != 0) {
@@ -1334,6 +1392,7 @@ int sb_create(const sb_desc *desc, sb_solver **out) {
         s->peer.enabled = d.world > 1 && d.halo_transport == SB_TRANSPORT_PEER;
         s->loopback = d.world > 1 && (d.debug_flags & SB_DEBUG_LOOPBACK) != 0;
         s->pack_tiles = !std::getenv("SB_NO_PACK");
+        s->peek_enabled = !std::getenv("SB_NO_PEEK");
         if (const char *e = std::getenv("SB_LDS_PAD")) s->lds_pad = (size_t)std::max(0, std::atoi(e));
         if (const char *e = std::getenv("SB_TILE_LANES")) s->tile_lanes = std::atoi(e) == 128 ? 128 : (std::atoi(e) == 256 ? 256 : (std::atoi(e) == 512 ? 512 : 0));
         if (const char *e = std::getenv("SB_QUAD_LANES")) s->quad_lanes = std::atoi(e) == 256 ? 256 : 512;
@@ -1852,13 +1911,16 @@ static int get_state(sb_solver *s, float *out, int32_t n, bool velocity) {
     return guarded([&]() -> int {
         int rc = set_device(s); if (rc) return rc;
         const sbp::LocalPlan &L = s->plan->local;
-        flush_deferred(s);
+        // positions while the tick's last kernel is deferred: peek instead of completing the tick (the next sb_step keeps its fusion)
+        const bool peek = !velocity && can_peek(s);
+        if (peek) peek_positions(s, false); else flush_deferred(s);
         if (s->desc.world == 1) {
             // single rank: every entry is ours, so the permutation to caller numbering runs on the GPU and one copy
             // lands in the caller's array (the host-side scatter below costs 25 ms for 16.7 M particles)
             if (!s->d_local_to_old.p) s->d_local_to_old.upload(L.local_to_old, s->dev_bytes);
             if (!s->d_get_scratch.p) s->d_get_scratch.alloc((size_t)s->n * 3, s->dev_bytes);
             sbk::PosView src = s->pos_view();
+            if (peek) src.xyz = s->d_peek.p;
             if (velocity) src.xyz = s->d_vel.p;
             hipLaunchKernelGGL(sbk::snapshot_kernel, dim3((unsigned)((s->n_owned + 255) / 256)), dim3(256), 0, s->stream, src,
                                s->d_local_to_old.p, s->d_get_scratch.p, (int)s->n_owned);
@@ -1926,10 +1988,11 @@ int sb_readback_begin(sb_solver *s) {
                 HIP_CHECK(hipEventCreateWithFlags(&s->ev_copied[k], hipEventDisableTiming));
             }
         }
-        flush_deferred(s);
         const int k = (s->snap_head + s->snap_pending) % sb_solver::kSnapSlots;
         // snapshot on the compute stream (ordered after every tick enqueued so far, before the next one) ...
         const bool compact = s->render_set_only && !s->render_tri.empty();
+        const bool peek = can_peek(s);       // the tick's last kernel is deferred: snapshot a peek and leave it deferred
+        if (!peek) flush_deferred(s);
         if (!s->render_tri.empty() && s->render_dirty) {     // (re)build the incident-triangle lists: triangle ids ascending per particle
             HIP_CHECK(hipStreamSynchronize(s->copy_stream));
             const int64_t m = (int64_t)s->render_tri.size() / 3;
@@ -1957,15 +2020,26 @@ int sb_readback_begin(sb_solver *s) {
                 HIP_CHECK(hipHostMalloc((void **)&s->h_cpos[q], std::max<size_t>(s->render_set.size(), 1) * 3 * sizeof(float), hipHostMallocDefault));
             }
             s->render_dirty = false;
+            s->n_peek_tiles = -1;
+        }
+        sbk::PosView src = s->pos_view();
+        if (peek) {
+            if (compact && s->n_peek_tiles < 0) {
+                std::vector<int32_t> wanted(s->render_set.size());
+                for (size_t q = 0; q < wanted.size(); ++q) wanted[q] = s->plan->plan.new_of_old[s->render_set[q]];
+                build_peek_subset(s, wanted);
+            }
+            peek_positions(s, compact);
+            src.xyz = s->d_peek.p;
         }
         if (compact) {      // only the render set leaves the device: snapshot just those particles
             const int cnt = (int)s->render_set.size();
             if (cnt)
-                hipLaunchKernelGGL(sbk::snapshot_subset_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s->stream, s->pos_view(),
+                hipLaunchKernelGGL(sbk::snapshot_subset_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, s->stream, src,
                                    s->d_render_set.p, s->d_render_local.p, s->d_snap[k].p, cnt);
         } else if (s->n_owned)
             hipLaunchKernelGGL(sbk::snapshot_kernel, dim3((unsigned)((s->n_owned + 255) / 256)), dim3(256), 0, s->stream,
-                               s->pos_view(), s->d_local_to_old.p, s->d_snap[k].p, (int)s->n_owned);
+                               src, s->d_local_to_old.p, s->d_snap[k].p, (int)s->n_owned);
         HIP_CHECK(hipEventRecord(s->ev_snap[k], s->stream));
         // ... D2H on the copy stream, overlapping whatever the compute stream does next
         HIP_CHECK(hipStreamWaitEvent(s->copy_stream, s->ev_snap[k], 0));
@@ -2114,6 +2188,8 @@ int sb_get_stats(sb_solver *s, sb_stats *out) {
     out->partition = P.partition;
     out->halo_schedule = s->schedule;
     out->halo_unpack_fused = s->fused_unpack ? 1 : 0;
+    out->readback_peeks = s->n_peeks;
+    out->readback_peek_tiles = s->n_peek_tiles;
     out->plan_hash = s->plan_hash;
     if (!P.rank_cost.empty()) {
         out->partition_cost = P.rank_cost[(size_t)s->desc.rank];

@@ -45,7 +45,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(native.SbDesc) == 80
     assert C.sizeof(native.SbPlanOpts) == 48 and C.sizeof(native.SbDomain) == 8 + 8 * 8 + 8
     assert C.sizeof(native.SbPhaseInfo) == 48
-    assert C.sizeof(native.SbStats) == 8 * 2 + 8 * 3 + 4 * 2 + 8 * 4 + 8 * 5 + 8 * 3 + 8 * 5 + (4 * 2 + 8 * 3 + 8 + 8 + 4 * 2)
+    assert C.sizeof(native.SbStats) == 8 * 2 + 8 * 3 + 4 * 2 + 8 * 4 + 8 * 5 + 8 * 3 + 8 * 5 + (4 * 2 + 8 * 3 + 8 + 8 + 4 * 2) + 8 * 2
     assert C.sizeof(native.SbRuntimeInfo) == 8 * 4 + 2 * 256
 
 
@@ -75,7 +75,7 @@ def test_runtime_info_names_the_bound_libraries():
 
 def test_loads_without_gpu_and_fails_loudly():
     L = native.lib()
-    assert L.sb_abi_version() == 6
+    assert L.sb_abi_version() == 7
     d = native.SbDesc()
     L.sb_desc_default(C.byref(d))
     assert d.world == 1 and d.tile_particles == 0 and d.use_graph == 1 and abs(d.gravity[1] + 9.81) < 1e-6

@@ -68,7 +68,10 @@ def main():
     timed("async_readback_with_normals_ms", async_tick, drain)
     sb.set_readback_render_set_only(True)
     timed("async_render_set_only_with_normals_ms", async_tick, drain)
-    out["render_set_particles"] = int(len(sb.render_set())) if False else int(len(np.unique(tri)))
+    out["render_set_particles"] = int(len(np.unique(tri)))
+    st = sb.stats()
+    out["peek"] = {"enabled": not os.environ.get("SB_NO_PEEK"), "readback_peeks": st["readback_peeks"], "peek_tiles": st["readback_peek_tiles"],
+                   "t0_tiles": st["n_tiles"][0]}
     sb.OnDestroy()
     print(json.dumps(out))
 
