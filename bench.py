@@ -112,6 +112,8 @@ def main():
     # a launcher may expose all GPUs to every rank (use LOCAL_RANK) or exactly one per rank (use 0)
     n_dev = torch.cuda.device_count()
     device = local_rank if (n_dev == 0 or local_rank < n_dev) else local_rank % n_dev
+    if n_dev > 0:
+        torch.cuda.set_device(device)      # torch.cuda.synchronize() in barrier() then waits for THIS rank's device, not for device 0 on every rank
 
     # torch is imported BEFORE the plugin on purpose and always: the plugin then binds the HIP runtime and the RCCL torch brought
     # (one ROCm stack per process); which ones is recorded in the line (config.runtime, from sb_runtime_info)

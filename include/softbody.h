@@ -256,6 +256,7 @@ typedef struct {
      * (-1 = no render-set peek has been set up) */
     int64_t readback_peeks;
     int64_t readback_peek_tiles;
+    int64_t ticks_fused;                            /* sb_step calls whose first kernel also finished the tick before (lazy tick boundary kept) */
 } sb_stats;
 int sb_get_stats(sb_solver *s, sb_stats *out);
 

@@ -277,6 +277,7 @@ struct sb_solver {
     int32_t n_peek_tiles = -1;             // -1: not built for the current render set
     bool peek_enabled = true;              // SB_NO_PEEK unset (read once in sb_create)
     int64_t n_peeks = 0;                   // launches so far (sb_stats.readback_peeks)
+    int64_t n_fused = 0;                   // ticks that started with the fused kernel (sb_stats.ticks_fused)
 
     ~sb_solver() {
         // Teardown order: everything the device may still be running for this solver first (compute, exchange and copy
@@ -1755,7 +1756,7 @@ int sb_step(sb_solver *s, float dt, int32_t substeps) {
         const bool can_defer = s->lazy_tick && (!s->plan->plan.tiling || (substeps & 1) == 0);
         const bool fuse = s->deferred && can_defer && s->deferred_substeps == substeps && s->tp_valid &&
                           std::memcmp(&tp_new, &s->tp_host, sizeof(tp_new)) == 0;
-        if (!fuse) flush_deferred(s);
+        if (!fuse) flush_deferred(s); else ++s->n_fused;
         upload_tick_params(s, dt, substeps);
         // world > 1: the exchange inside a captured graph is opt-in (SB_SCHEDULE_*_GRAPH), see DESIGN.md §7
         const bool graph_ok = s->desc.use_graph && (s->desc.world == 1 || s->graph_rccl);     // the overlapped schedule forks onto comm_stream inside the capture
@@ -2190,6 +2191,7 @@ int sb_get_stats(sb_solver *s, sb_stats *out) {
     out->halo_unpack_fused = s->fused_unpack ? 1 : 0;
     out->readback_peeks = s->n_peeks;
     out->readback_peek_tiles = s->n_peek_tiles;
+    out->ticks_fused = s->n_fused;
     out->plan_hash = s->plan_hash;
     if (!P.rank_cost.empty()) {
         out->partition_cost = P.rank_cost[(size_t)s->desc.rank];

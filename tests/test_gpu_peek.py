@@ -107,9 +107,9 @@ def test_peeked_reads_equal_flushed_reads_and_the_oracle(case, monkeypatch, orac
 def test_a_peek_keeps_the_tick_fusable(monkeypatch):
     """The point of the peek: with a render readback after every tick, a tick of S substeps stays S launches over the mesh plus one
     over the surface tiles, instead of S + 1 (the held-back last kernel forced out, the next tick starting with an unfused first
-    kernel). Measured as HIP-event time on the solver's stream, readbacks pipelined one tick behind as a renderer would, on a cube
-    whose launches outlast the host's enqueue work (at 128^3 the tick is bound by the ~130 us of host calls either way): 192^3 with
-    4 substeps -- flushed 5 x 13 824 workgroups per tick, peeked 4 x 13 824 + 3 176; measured 0.397 -> 0.349 ms per tick."""
+    kernel). Checked through the plugin's own counters (sb_stats.ticks_fused), readbacks pipelined one tick behind as a renderer
+    would; the HIP-event time per tick is printed, not asserted (192^3, 4 substeps, one box: 0.397 -> 0.349 ms per tick; at 128^3 the
+    tick is bound by the ~130 us of host calls either way)."""
     from readback_bench import surface_triangles
     n = 192
     mesh = jelly_cube(n)
@@ -139,6 +139,7 @@ def test_a_peek_keeps_the_tick_fusable(monkeypatch):
             return best, sb.stats()
         finally:
             sb.OnDestroy()
-    (t_flush, _), (t_peek, st) = per_tick(False), per_tick(True)
-    assert st["readback_peek_tiles"] == 24 ** 3 - 22 ** 3
-    assert t_peek < t_flush * 0.95, (t_peek, t_flush)
+    (t_flush, st_flush), (t_peek, st) = per_tick(False), per_tick(True)
+    print(f"192^3, 4 substeps, render-set readback every tick: flushed {t_flush:.4f} ms per tick, peeked {t_peek:.4f}")
+    assert st["readback_peek_tiles"] == 24 ** 3 - 22 ** 3 and st["readback_peeks"] == 125
+    assert st["ticks_fused"] == 124 and st_flush["ticks_fused"] == 0 and st_flush["readback_peeks"] == 0
