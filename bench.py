@@ -53,6 +53,97 @@ def _golden_entry(n, substeps, tile, het=False):
     return json.load(open(path)).get(f"cube{n}{'het' if het else ''}_s{substeps}_tile{tile}")
 
 
+class GpuStateSampler:
+    """What the amdgpu driver shows an ordinary user about THIS rank's GPU while the workload runs: shader / memory / fabric clock,
+    package power and its cap (sysfs, no child process). The headline launch sits at the package power cap on MI355X (measured:
+    1 391 W of 1 400 W), so boxes whose silicon needs more voltage hold a lower shader clock -- 2.0-2.15 GHz against 2.4 GHz --
+    and run the same launch in 161 us instead of 148 us (tools/clock_probe.py, profiles/r03s2_clock_probe.json). The line carries
+    the numbers so that a roofline fraction can be read against the state of the box that produced it."""
+
+    def __init__(self, pci_bus_id):
+        import glob
+        self.dev = None
+        cards = sorted(glob.glob("/sys/class/drm/card*/device"))
+        for d in cards:
+            if pci_bus_id and os.path.realpath(d).lower().endswith(pci_bus_id.lower()):
+                self.dev = d
+        self.cards = cards
+        self.samples = []
+        self._stop = None
+        self._th = None
+
+    @staticmethod
+    def _active(path):
+        try:
+            for line in open(path):
+                if line.rstrip().endswith("*"):
+                    digits = "".join(ch for ch in line.split(":", 1)[1] if ch.isdigit() or ch == ".")
+                    return float(digits) if digits else None
+        except OSError:
+            pass
+        return None
+
+    def _sample(self, d):
+        import glob
+        out = {}
+        for name in ("sclk", "mclk", "fclk"):
+            v = self._active(os.path.join(d, f"pp_dpm_{name}"))
+            if v is not None:
+                out[name + "_MHz"] = v
+        for hw in glob.glob(os.path.join(d, "hwmon", "hwmon*")):
+            for key, name in (("power1_input", "power_W"), ("power1_average", "power_W"), ("power1_cap", "power_cap_W")):
+                try:
+                    out[name] = float(open(os.path.join(hw, key)).read()) * 1e-6
+                except (OSError, ValueError):
+                    pass
+        try:
+            out["busy_percent"] = float(open(os.path.join(d, "gpu_busy_percent")).read())
+        except (OSError, ValueError):
+            pass
+        return out
+
+    def start(self):
+        import threading
+        if not self.cards:
+            return self
+        self._stop = threading.Event()
+
+        def watch():
+            while not self._stop.is_set():
+                # the device's PCI address is known: one card; else every card, the busiest one is picked afterwards
+                self.samples.append({d: self._sample(d) for d in ([self.dev] if self.dev else self.cards)})
+                self._stop.wait(0.01)
+        self._th = threading.Thread(target=watch, daemon=True)
+        self._th.start()
+        return self
+
+    def stop(self):
+        if self._th is None:
+            return None
+        self._stop.set(); self._th.join()
+        if not self.samples:
+            return None
+        dev = self.dev
+        if dev is None:      # (a launcher that hides the PCI address) the card that was busiest while we ran
+            dev = max(self.cards, key=lambda d: sum(smp[d].get("busy_percent", 0.0) for smp in self.samples))
+        keys = sorted({k for smp in self.samples for k in smp[dev]})
+        rng = {k: [min(smp[dev][k] for smp in self.samples if k in smp[dev]), max(smp[dev][k] for smp in self.samples if k in smp[dev])] for k in keys}
+        out = {"source": dev + (" (matched by PCI address)" if self.dev else " (busiest card)"), "samples": len(self.samples),
+               "window": "warm-up + timed region", "min_max": rng}
+        pw, cap = rng.get("power_W"), rng.get("power_cap_W")
+        if pw and cap and cap[1] > 0:
+            out["at_power_cap"] = bool(pw[1] >= 0.97 * cap[1])
+        return out
+
+
+def _pci_bus_id(torch, device):
+    try:
+        p = torch.cuda.get_device_properties(device)
+        return "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -175,6 +266,7 @@ def main():
             if dist is not None:
                 dist.barrier()
 
+        sampler = GpuStateSampler(_pci_bus_id(torch, device) if n_dev > 0 else None).start() if rank == 0 else None
         for _ in range(args.warmup):
             sb.step()
         barrier()
@@ -185,6 +277,7 @@ def main():
         ev_ms = sb.profile_end()
         barrier()
         elapsed = time.perf_counter() - t0
+        gpu_state = sampler.stop() if sampler is not None else None
         if dist is not None:
             t = torch.tensor([elapsed], dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -321,7 +414,7 @@ def main():
                        "authoring": ("sharded: each rank hands over and plans its window only (sb_set_domain)" if sharded else "whole mesh on every rank"),
                            "halo_transport": args.transport if (world > 1 or loopback) else None,
                            "halo_schedule": {1: "serial-eager", 2: "serial-graph", 3: "overlap-eager", 4: "overlap-graph"}.get(stats["halo_schedule"]) if (world > 1 or loopback) else None,
-                           "runtime": runtime,
+                           "runtime": runtime, "gpu_state": gpu_state,
                            "finite": finite, "parity": parity},
                 "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                              "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
