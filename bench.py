@@ -313,6 +313,13 @@ def main():
         else:
             finite = bool(np.isfinite(sb.get_positions()[sb.owner() == rank]).all())
 
+        # the tables the timed launches read, re-read by the validator kernel (sb_debug_validate): a group or a launch that touched a
+        # particle twice would be a race, whatever the state looks like
+        if not args.no_parity:
+            rep = sb.validate()
+            parity["tables"] = {"constraints_checked": rep["constraints_checked"], "tiles_checked": rep["tiles_checked"], "errors": rep["errors"],
+                                "clean": rep["errors"] == [0] * 6}
+
         # per-kernel HIP-event timing on the solver's stream: a few extra eager ticks, outside the timed region
         prof_ticks = 2
         slot_ms = None

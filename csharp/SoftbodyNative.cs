@@ -52,6 +52,16 @@ namespace SoftbodyMI355X
         public long readbackPeeks, readbackPeekTiles, ticksFused;   // position reads served by a peek; T0 workgroups of one render-set peek (-1: none set up)
     }
 
+    [StructLayout(LayoutKind.Sequential)]
+    public struct SbValidateReport
+    {
+        public long tilesChecked, groupsChecked, constraintsChecked;
+        // 0 index out of range, 1 a particle twice in one group / colour, 2 a particle staged by two tiles of one launch,
+        // 3 a group's data leaves the tile's stream, 4 malformed run table / particle list, 5 wave items disagree with the group words
+        public long errors0, errors1, errors2, errors3, errors4, errors5;
+        public int firstStage, firstTile, firstGroup, firstKind;   // -1 = no error
+    }
+
     [StructLayout(LayoutKind.Sequential, CharSet = CharSet.Ansi)]
     public struct SbRuntimeInfo
     {
@@ -134,6 +144,8 @@ namespace SoftbodyMI355X
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_debug_launch(IntPtr s, float dt, int substeps, int it, int gcolour);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_debug_halo_pack(IntPtr s, int slot, IntPtr hostOut, long capacityFloats, out long countFloats);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_debug_halo_unpack(IntPtr s, int slot, IntPtr hostIn, long countFloats);
+        // table validator ("race detector"): a GPU kernel re-reads every table the tile kernels read and counts violations (softbody.h)
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_debug_validate(IntPtr s, int injectFault, out SbValidateReport report);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_get_stats(IntPtr s, out SbStats stats);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_runtime_info(out SbRuntimeInfo info);
         // opt-in peer-store halo transport (SbDesc.haloTransport = TransportPeer): see softbody.h

@@ -223,6 +223,22 @@ int sb_step_profiled(sb_solver *s, float dt, int32_t substeps, float *slot_ms_ou
 int sb_debug_launch(sb_solver *s, float dt, int32_t substeps, int32_t it, int32_t gcolour);
 int sb_debug_halo_pack(sb_solver *s, int32_t slot, float *host_out, int64_t capacity_floats, int64_t *count_floats_out);
 int sb_debug_halo_unpack(sb_solver *s, int32_t slot, const float *host_in, int64_t count_floats);
+/* Table validator (debug; the "race detector" of this design): the only race the tile kernels can have is two constraints of one
+ * group -- or two tiles of one launch -- touching the same particle. A GPU kernel re-reads everything the tile kernels read (the
+ * uploaded descriptors, run tables / particle lists, group words, 4- and 8-byte spring slots, four-vertex slots, wave items: after
+ * packing, lane dealing and cost ordering) with their own decoding rules and counts violations; the global colours likewise.
+ * inject_fault != 0 runs the same check on a COPY of tiling T0's tables with one fault planted (1: a slot copied over its
+ * neighbour = a particle twice in one group; 2: a descriptor copied over its neighbour = a particle staged by two tiles), so a host
+ * can see the detector detect. The solver's own tables are never modified. Returns SB_OK when the check RAN; look at errors[]. */
+typedef struct {
+    int64_t tiles_checked, groups_checked, constraints_checked;
+    /* 0 index out of range, 1 a particle twice in one group (or one global colour), 2 a particle staged by two tiles of one launch,
+     * 3 a group's data leaves the tile's stream, 4 malformed run table / particle list, 5 wave items disagree with the group words */
+    int64_t errors[6];
+    int32_t first_stage;                            /* -1 none; 0 / 1 = tiling T0 / T1, 2 = a T2 layer, 3 = a global colour */
+    int32_t first_tile, first_group, first_kind;    /* device tile index of that tiling (global colour: -2 - its number), group (colour: constraint), errors[] index */
+} sb_validate_report;
+int sb_debug_validate(sb_solver *s, int32_t inject_fault, sb_validate_report *out);
 typedef struct {
     int64_t n_particles_owned, n_particles_local;   /* local = owned + ghost */
     int64_t n_constraints_local[3];                 /* distance, volume, bending (incl. redundant cut copies) */

@@ -55,6 +55,11 @@ class SbStats(C.Structure):
         return out
 
 
+class SbValidateReport(C.Structure):
+    _fields_ = [("tiles_checked", C.c_int64), ("groups_checked", C.c_int64), ("constraints_checked", C.c_int64), ("errors", C.c_int64 * 6),
+                ("first_stage", C.c_int32), ("first_tile", C.c_int32), ("first_group", C.c_int32), ("first_kind", C.c_int32)]
+
+
 class SbDomain(C.Structure):
     _fields_ = [("n_global", C.c_int64), ("lo", C.c_double * 3), ("hi", C.c_double * 3), ("spacing", C.c_double), ("fill", C.c_double),
                 ("four_vertex_constraints", C.c_int32), ("reserved", C.c_int32)]
@@ -115,6 +120,7 @@ SIGNATURES = {
     "sb_debug_launch": (C.c_int, [_P, C.c_float, C.c_int32, C.c_int32, C.c_int32]),
     "sb_debug_halo_pack": (C.c_int, [_P, C.c_int32, _P, C.c_int64, C.POINTER(C.c_int64)]),
     "sb_debug_halo_unpack": (C.c_int, [_P, C.c_int32, _P, C.c_int64]),
+    "sb_debug_validate": (C.c_int, [_P, C.c_int32, C.POINTER(SbValidateReport)]),
     "sb_get_stats": (C.c_int, [_P, C.POINTER(SbStats)]),
     "sb_plan_build": (C.c_int, [_P, C.c_int32, _P, C.c_int32, _P, C.c_int32, _P, C.c_int32, C.POINTER(SbPlanOpts),
                                 C.POINTER(_P)]),

@@ -213,6 +213,14 @@ class Softbody:
         check(native.lib().sb_get_owner(self._h, ptr(out), self.n))
         return out
 
+    def validate(self, inject_fault=0):
+        """Table validator (sb_debug_validate): a GPU kernel re-reads every table the tile kernels read -> report dict."""
+        rep = native.SbValidateReport()
+        check(native.lib().sb_debug_validate(self._h, int(inject_fault), C.byref(rep)))
+        return {"tiles_checked": rep.tiles_checked, "groups_checked": rep.groups_checked, "constraints_checked": rep.constraints_checked,
+                "errors": list(rep.errors), "first_stage": rep.first_stage, "first_tile": rep.first_tile, "first_group": rep.first_group,
+                "first_kind": rep.first_kind}
+
     def stats(self):
         st = native.SbStats()
         check(native.lib().sb_get_stats(self._h, C.byref(st)))

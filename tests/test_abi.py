@@ -52,13 +52,13 @@ def test_struct_layouts_match_header():
 def test_header_structs_compile_to_the_same_sizes(tmp_path):
     # the ctypes twin against the header itself, through the C compiler
     src = tmp_path / "sizes.c"
-    src.write_text('#include <stdio.h>\n#include "softbody.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu\\n", sizeof(sb_desc), sizeof(sb_plan_opts), '
-                   'sizeof(sb_phase_info), sizeof(sb_stats), sizeof(sb_runtime_info_t), sizeof(sb_domain)); return 0;}\n')
+    src.write_text('#include <stdio.h>\n#include "softbody.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(sb_desc), sizeof(sb_plan_opts), '
+                   'sizeof(sb_phase_info), sizeof(sb_stats), sizeof(sb_runtime_info_t), sizeof(sb_domain), sizeof(sb_validate_report)); return 0;}\n')
     exe = tmp_path / "sizes"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
     assert got == [C.sizeof(native.SbDesc), C.sizeof(native.SbPlanOpts), C.sizeof(native.SbPhaseInfo), C.sizeof(native.SbStats),
-                   C.sizeof(native.SbRuntimeInfo), C.sizeof(native.SbDomain)]
+                   C.sizeof(native.SbRuntimeInfo), C.sizeof(native.SbDomain), C.sizeof(native.SbValidateReport)]
 
 
 def test_runtime_info_names_the_bound_libraries():

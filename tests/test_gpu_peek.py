@@ -58,7 +58,7 @@ def _session(mesh, tri, peek, monkeypatch, ticks, compact, **kw):
         sb.OnDestroy()
 
 
-@pytest.mark.parametrize("case", ["cube_full", "cube_render_set", "cube_heterogeneous_ground", "tets_render_set", "cube_wide_tiles"])
+@pytest.mark.parametrize("case", ["cube_full", "cube_render_set", "cube_heterogeneous_ground", "tets_render_set", "cube_wide_tiles", "cube_large_tiles"])
 def test_peeked_reads_equal_flushed_reads_and_the_oracle(case, monkeypatch, oracle_mod):
     from readback_bench import surface_triangles
     kw, ticks, compact, tri = dict(substeps=6), 5, False, None
@@ -73,6 +73,8 @@ def test_peeked_reads_equal_flushed_reads_and_the_oracle(case, monkeypatch, orac
         mesh = bunny_surrogate(target_verts=6000, seed=7); tri = _surface_triangles_of_tets(mesh); compact = True
         kw = dict(substeps=4, distance_compliance=1e-7, volume_compliance=1e-7, bending_compliance=1e-4,
                   ground_plane=(0, 1, 0, float(mesh.pos[:, 1].min()) + 0.02))
+    elif case == "cube_large_tiles":                     # tiles of up to 1 024 particles: the kernels' second capacity
+        mesh = jelly_cube(30); tri = surface_triangles(30); compact = True; kw = dict(substeps=6, tile_particles=1000)
     else:                                                # > 768 tiles: 256-lane workgroups; tile 128 also makes under-full packs
         mesh = jelly_cube(40); kw = dict(substeps=4, tile_particles=128)
     a = _session(mesh, tri, True, monkeypatch, ticks, compact, **kw)
