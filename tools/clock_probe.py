@@ -49,6 +49,23 @@ def sample(dev):
     return out
 
 
+def own_card(devs):
+    """The sysfs node of HIP device 0, by PCI address (the runtime the plugin loaded is asked through ctypes)."""
+    import ctypes
+    for name in ("libamdhip64.so.7", "libamdhip64.so"):
+        try:
+            hip = ctypes.CDLL(name)
+            buf = ctypes.create_string_buffer(64)
+            if hip.hipDeviceGetPCIBusId(buf, 64, 0) == 0:
+                addr = buf.value.decode().lower()
+                for d in devs:
+                    if os.path.realpath(d).lower().endswith(addr):
+                        return d
+        except OSError:
+            pass
+    return None
+
+
 def main():
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
     devs = sorted(d for d in glob.glob("/sys/class/drm/card*/device") if os.path.exists(os.path.join(d, "pp_dpm_sclk")) or glob.glob(os.path.join(d, "hwmon", "hwmon*")))
@@ -78,6 +95,8 @@ def main():
     stop.set(); th.join()
     sb.OnDestroy()
     report["ms_per_tick_5x60"] = per
+    report["own_card"] = own_card(devs)
+    report["library_variant"] = os.environ.get("SB_LIB_VARIANT") or "product"
     report["idle"] = idle
     rng = {}
     for d in devs:
