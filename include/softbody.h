@@ -166,7 +166,8 @@ int sb_peer_connect(sb_solver *s, int32_t rank, const uint8_t handle[SB_IPC_HAND
  * that reads or writes state (sb_get_velocities, sb_set_state, sb_synchronize, ...) completes it first, so the laziness is
  * not observable. Position reads of a single-rank solver (sb_get_positions, sb_readback_begin) do not even need that: they
  * PEEK -- the held-back kernel's constraint rounds and collision run on the tiles in question into a side array, bit for bit
- * what the completed tick would hold, and the tick stays fusable with the next one (sb_stats.readback_peeks). */
+ * what the completed tick would hold, and the tick stays fusable with the next one (sb_stats.readback_peeks). Only where that pays:
+ * tilings of at least 2 048 workgroups, whose launches are bandwidth-bound; smaller ones complete the tick as before. */
 int sb_step(sb_solver *s, float dt, int32_t substeps);
 
 /* ---- readback / state round trip ------------------------------------------------------------- */

@@ -276,6 +276,11 @@ struct sb_solver {
     DevBuf<sbk::TileDesc> peek_tiles;
     int32_t n_peek_tiles = -1;             // -1: not built for the current render set
     bool peek_enabled = true;              // SB_NO_PEEK unset (read once in sb_create)
+    // A peek is one more launch; what it saves is the difference between a fused first kernel and a separate last + first kernel. That
+    // pays where launches are bandwidth-bound (256^3 render-set readback: 3.49 -> 3.35 ms per tick) and costs where a launch is a fixed
+    // latency whatever it covers (every tile resident at once -- 100 k tet mesh: +15 us per tick, 64^3: +2 us; profiles/
+    // r03s2_soak_peek.jsonl): peek only from this many T0 workgroups on (SB_PEEK_MIN_TILES).
+    int peek_min_tiles = 2048;
     int64_t n_peeks = 0;                   // launches so far (sb_stats.readback_peeks)
     int64_t n_fused = 0;                   // ticks that started with the fused kernel (sb_stats.ticks_fused)
 
@@ -1249,7 +1254,7 @@ void flush_deferred(sb_solver *s) {
 bool can_peek(const sb_solver *s) {
     if (!s->peek_enabled || !s->deferred || s->desc.world != 1) return false;
     const int tl = s->plan->plan.tiling ? (s->deferred_substeps & 1) : 0;
-    return tl == 0 && s->tiling[0].n_tiles > 0;
+    return tl == 0 && s->tiling[0].n_tiles > 0 && s->tiling[0].n_tiles >= s->peek_min_tiles;
 }
 
 // The T0 device tiles (packs) that hold at least one particle of `wanted` (device numbering): copies of their descriptors.
@@ -1394,6 +1399,7 @@ int sb_create(const sb_desc *desc, sb_solver **out) {
         s->loopback = d.world > 1 && (d.debug_flags & SB_DEBUG_LOOPBACK) != 0;
         s->pack_tiles = !std::getenv("SB_NO_PACK");
         s->peek_enabled = !std::getenv("SB_NO_PEEK");
+        if (const char *e = std::getenv("SB_PEEK_MIN_TILES")) s->peek_min_tiles = std::max(0, std::atoi(e));
         if (const char *e = std::getenv("SB_LDS_PAD")) s->lds_pad = (size_t)std::max(0, std::atoi(e));
         if (const char *e = std::getenv("SB_TILE_LANES")) s->tile_lanes = std::atoi(e) == 128 ? 128 : (std::atoi(e) == 256 ? 256 : (std::atoi(e) == 512 ? 512 : 0));
         if (const char *e = std::getenv("SB_QUAD_LANES")) s->quad_lanes = std::atoi(e) == 256 ? 256 : 512;

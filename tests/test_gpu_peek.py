@@ -33,6 +33,7 @@ def _surface_triangles_of_tets(mesh):
 
 def _session(mesh, tri, peek, monkeypatch, ticks, compact, **kw):
     """ticks x (step, async readback [+ a blocking get_positions on odd ticks]) -> snapshots, final state, stats"""
+    monkeypatch.setenv("SB_PEEK_MIN_TILES", "0")        # (by default only launches of >= 2 048 workgroups peek: below that it does not pay)
     if peek:
         monkeypatch.delenv("SB_NO_PEEK", raising=False)
     else:
@@ -145,3 +146,16 @@ def test_a_peek_keeps_the_tick_fusable(monkeypatch):
     print(f"192^3, 4 substeps, render-set readback every tick: flushed {t_flush:.4f} ms per tick, peeked {t_peek:.4f}")
     assert st["readback_peek_tiles"] == 24 ** 3 - 22 ** 3 and st["readback_peeks"] == 125
     assert st["ticks_fused"] == 124 and st_flush["ticks_fused"] == 0 and st_flush["readback_peeks"] == 0
+
+
+def test_small_launches_do_not_peek(monkeypatch):
+    """Where every tile of a launch is resident at once a launch is a fixed latency, and a peek (one more launch) costs more than the
+    fusion it keeps: by default only tilings of at least 2 048 workgroups peek."""
+    monkeypatch.delenv("SB_NO_PEEK", raising=False); monkeypatch.delenv("SB_PEEK_MIN_TILES", raising=False)
+    sb = Softbody(jelly_cube(32), substeps=4).Start()
+    try:
+        for _ in range(3):
+            sb.step(); sb.get_positions()
+        assert sb.stats()["readback_peeks"] == 0
+    finally:
+        sb.OnDestroy()
