@@ -156,6 +156,7 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the self-verification legs (profiling runs)")
+    ap.add_argument("--no-gpu-state", action="store_true", help="do not sample the card's clocks and power (sysfs) while measuring")
     ap.add_argument("--cpu-sample-n", type=int, default=0, help="cube edge for the CPU baseline sample (0 = the workload itself)")
     ap.add_argument("--strict-traffic", action="store_true",
                     help="fail (instead of falling back to the compulsory-bytes model and saying so) when profiles/hbm_traffic.json is "
@@ -266,7 +267,9 @@ def main():
             if dist is not None:
                 dist.barrier()
 
-        sampler = GpuStateSampler(_pci_bus_id(torch, device) if n_dev > 0 else None).start() if rank == 0 else None
+        sampler = None
+        if rank == 0 and not args.no_gpu_state:
+            sampler = GpuStateSampler(_pci_bus_id(torch, device) if n_dev > 0 else None).start()
         for _ in range(args.warmup):
             sb.step()
         barrier()
