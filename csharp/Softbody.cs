@@ -186,6 +186,18 @@ namespace SoftbodyMI355X
             if (handle != IntPtr.Zero) { SoftbodyNative.sb_destroy(handle); handle = IntPtr.Zero; }
         }
 
+        /// <summary>Debug aid (GPU backend): a GPU kernel re-reads every table the solver's kernels read and counts the one kind of
+        /// fault that could make a tick racy -- a particle twice in a group of concurrently projected constraints, or in two tiles of
+        /// one launch (softbody.h, sb_debug_validate). True = clean.</summary>
+        public bool ValidateTables(out SbValidateReport report)
+        {
+            report = default(SbValidateReport);
+            if (handle == IntPtr.Zero) return true;          // CPU branch: nothing uploaded
+            int rc = SoftbodyNative.sb_debug_validate(handle, 0, out report);
+            if (rc != 0) throw new InvalidOperationException(SoftbodyNative.LastError());
+            return report.errors0 + report.errors1 + report.errors2 + report.errors3 + report.errors4 + report.errors5 == 0;
+        }
+
         // accessors for SoftbodyCpuSolver
         internal Vector3 Gravity => gravity;
         internal float Damping => damping;
