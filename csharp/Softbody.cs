@@ -186,6 +186,28 @@ namespace SoftbodyMI355X
             if (handle != IntPtr.Zero) { SoftbodyNative.sb_destroy(handle); handle = IntPtr.Zero; }
         }
 
+        /// <summary>Attachments: move pinned particles (inverse mass 0) to new positions before the next FixedUpdate; their constrained
+        /// neighbours are pulled along (SPEC.md 2, sb_set_kinematic_positions). ids index the particle arrays.</summary>
+        public void MoveKinematic(int[] ids, Vector3[] targets)
+        {
+            if (ids.Length != targets.Length) throw new ArgumentException("ids and targets differ in length");
+            if (handle == IntPtr.Zero)
+            {
+                // CPU branch: the same assignment on the arrays the C# solver steps
+                for (int k = 0; k < ids.Length; ++k)
+                {
+                    if (inverseMass[ids[k]] != 0f) throw new ArgumentException("only pinned particles (inverse mass 0) are kinematic");
+                    positions[ids[k]] = targets[k];
+                }
+                return;
+            }
+            Pin(ids, pi => Pin(targets, pt =>
+            {
+                int rc = SoftbodyNative.sb_set_kinematic_positions(handle, pi, pt, ids.Length);
+                if (rc != 0) throw new InvalidOperationException(SoftbodyNative.LastError());
+            }));
+        }
+
         /// <summary>Debug aid (GPU backend): a GPU kernel re-reads every table the solver's kernels read and counts the one kind of
         /// fault that could make a tick racy -- a particle twice in a group of concurrently projected constraints, or in two tiles of
         /// one launch (softbody.h, sb_debug_validate). True = clean.</summary>

@@ -130,6 +130,8 @@ namespace SoftbodyMI355X
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_get_positions(IntPtr s, IntPtr posXyzOut, int n);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_get_velocities(IntPtr s, IntPtr velXyzOut, int n);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_state(IntPtr s, IntPtr posXyz, IntPtr velXyz, int n);
+        // kinematic particles (attachments): move particles with inverse mass 0 between two ticks (SPEC.md 2); world == 1
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_kinematic_positions(IntPtr s, IntPtr ids, IntPtr posXyz, int count);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_readback_begin(IntPtr s);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_readback_end(IntPtr s, out IntPtr posXyz);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_render_triangles(IntPtr s, int[] triAbc, int m);

@@ -176,6 +176,12 @@ int sb_step(sb_solver *s, float dt, int32_t substeps);
 int sb_get_positions(sb_solver *s, float *pos_xyz_out, int32_t n);
 int sb_get_velocities(sb_solver *s, float *vel_xyz_out, int32_t n);
 int sb_set_state(sb_solver *s, const float *pos_xyz, const float *vel_xyz, int32_t n); /* after finalize */
+/* Kinematic particles (SPEC.md 2; attachments to animated objects): between two ticks, move particles whose inverse mass is 0 to new
+ * positions -- count entries, ids in the caller's numbering (each at most once), pos_xyz 3 floats per entry. The next tick's constraints
+ * pull their neighbours along. An id whose inverse mass is not 0 is refused (SB_ERR_INVALID_ARG, nothing is changed). Asynchronous like
+ * sb_step (the targets are copied before the call returns); completes the previous tick first, so a host that calls it every tick gives up
+ * the fused tick boundary (one launch per tick). Single-rank solvers only (world == 1). */
+int sb_set_kinematic_positions(sb_solver *s, const int32_t *ids, const float *pos_xyz, int32_t count);
 /* Asynchronous render readback: sb_readback_begin snapshots the positions as of every sb_step issued so far
  * (a small kernel on the compute stream) and starts a D2H copy into plugin-owned pinned memory on a second
  * stream; the next sb_step overlaps with that copy. sb_readback_end waits for the OLDEST pending snapshot and

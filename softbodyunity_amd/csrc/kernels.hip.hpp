@@ -1022,6 +1022,15 @@ __global__ __launch_bounds__(256) void global_quad_kernel(PosView pos, const int
     if (ok) { pv_store(pos, e.x, p0); pv_store(pos, e.y, p1); pv_store(pos, e.z, p2); pv_store(pos, e.w, p3); }
 }
 
+// Kinematic particles (SPEC.md 2): entry k moves particle idx[k] (device numbering) to targets[3k..]; the tables live in pinned host
+// memory (a few hundred entries per tick: not worth a copy of their own).
+__global__ __launch_bounds__(256) void kinematic_scatter_kernel(float *pos_xyz, const int32_t *idx, const float *targets, int count) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
+    const size_t o = 3 * (size_t)idx[k];
+    pos_xyz[o] = targets[3 * (size_t)k]; pos_xyz[o + 1] = targets[3 * (size_t)k + 1]; pos_xyz[o + 2] = targets[3 * (size_t)k + 2];
+}
+
 // Render readback: owned positions (device order, float4) -> caller order, packed xyz.
 __global__ __launch_bounds__(256) void snapshot_kernel(PosView pos, const int32_t *local_to_old, float *out_xyz, int n_owned) {
     const int l = blockIdx.x * 256 + threadIdx.x;

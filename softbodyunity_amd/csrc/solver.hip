@@ -269,6 +269,14 @@ struct sb_solver {
     float *h_nrm[kSnapSlots] = {nullptr, nullptr, nullptr};
     bool snap_has_normals[kSnapSlots] = {false, false, false};
     int snap_last_ended = -1;
+    // kinematic targets (sb_set_kinematic_positions): a ring of pinned host tables the scatter kernel reads directly; a table is reused
+    // only after the kernel that read it has finished (its event)
+    static constexpr int kKinSlots = 4;
+    int32_t *h_kin_idx[kKinSlots] = {nullptr, nullptr, nullptr, nullptr};
+    float *h_kin_pos[kKinSlots] = {nullptr, nullptr, nullptr, nullptr};
+    size_t kin_cap[kKinSlots] = {0, 0, 0, 0};
+    hipEvent_t ev_kin[kKinSlots] = {nullptr, nullptr, nullptr, nullptr};
+    int kin_next = 0;
     // Peek (world == 1): a position read while the tick's last kernel is deferred runs tile_kernel<4> -- the same rounds + collide on
     // the same inputs, written to d_peek instead of the state -- so the deferred kernel can still be fused with the next tick's first
     // one. A render-set-only readback peeks only at the T0 tiles that hold a render particle (peek_tiles: copies of their descriptors).
@@ -310,6 +318,11 @@ struct sb_solver {
             if (ev_copied[k]) (void)hipEventDestroy(ev_copied[k]);
         }
         if (copy_stream) (void)hipStreamDestroy(copy_stream);
+        for (int k = 0; k < kKinSlots; ++k) {
+            if (h_kin_idx[k]) (void)hipHostFree(h_kin_idx[k]);
+            if (h_kin_pos[k]) (void)hipHostFree(h_kin_pos[k]);
+            if (ev_kin[k]) (void)hipEventDestroy(ev_kin[k]);
+        }
         if (ev0) (void)hipEventDestroy(ev0);
         if (ev1) (void)hipEventDestroy(ev1);
         if (stream) (void)hipStreamDestroy(stream);
@@ -2056,6 +2069,43 @@ int sb_set_state(sb_solver *s, const float *pos, const float *vel, int32_t n) {
         }
         HIP_CHECK(hipMemcpy(s->d_pos3.p, hp.data(), hp.size() * sizeof(float), hipMemcpyHostToDevice));
         HIP_CHECK(hipMemcpy(s->d_vel.p, hv.data(), hv.size() * sizeof(float), hipMemcpyHostToDevice));
+        return SB_OK;
+    });
+}
+
+int sb_set_kinematic_positions(sb_solver *s, const int32_t *ids, const float *pos, int32_t count) {
+    if (!s || count < 0 || (count > 0 && (!ids || !pos))) return fail(SB_ERR_INVALID_ARG, "sb_set_kinematic_positions: bad argument");
+    if (!s->finalized) return fail(SB_ERR_STATE, "sb_set_kinematic_positions before sb_finalize");
+    if (s->desc.world != 1) return fail(SB_ERR_UNSUPPORTED, "sb_set_kinematic_positions: single-rank solvers only (world == 1)");
+    if (count == 0) return SB_OK;
+    return guarded([&]() -> int {
+        int rc = set_device(s); if (rc) return rc;
+        for (int32_t k = 0; k < count; ++k) {
+            if (ids[k] < 0 || ids[k] >= s->n) return fail(SB_ERR_INVALID_ARG, "sb_set_kinematic_positions: particle index out of range");
+            if (s->invm[(size_t)ids[k]] != 0.0f)
+                return fail(SB_ERR_INVALID_ARG, "sb_set_kinematic_positions: particle " + std::to_string(ids[k]) + " has a non-zero inverse mass (only pinned particles are kinematic)");
+            for (int c = 0; c < 3; ++c) if (!(pos[3 * (size_t)k + c] == pos[3 * (size_t)k + c])) return fail(SB_ERR_INVALID_ARG, "sb_set_kinematic_positions: NaN");
+        }
+        const int q = s->kin_next;
+        s->kin_next = (q + 1) % sb_solver::kKinSlots;
+        if (!s->ev_kin[q]) HIP_CHECK(hipEventCreateWithFlags(&s->ev_kin[q], hipEventDisableTiming));
+        else HIP_CHECK(hipEventSynchronize(s->ev_kin[q]));       // the kernel that read this table (four calls ago) is done
+        if (s->kin_cap[q] < (size_t)count) {
+            if (s->h_kin_idx[q]) { (void)hipHostFree(s->h_kin_idx[q]); s->h_kin_idx[q] = nullptr; }
+            if (s->h_kin_pos[q]) { (void)hipHostFree(s->h_kin_pos[q]); s->h_kin_pos[q] = nullptr; }
+            const size_t cap = std::max<size_t>(256, (size_t)count * 2);
+            HIP_CHECK(hipHostMalloc((void **)&s->h_kin_idx[q], cap * sizeof(int32_t), hipHostMallocDefault));
+            HIP_CHECK(hipHostMalloc((void **)&s->h_kin_pos[q], cap * 3 * sizeof(float), hipHostMallocDefault));
+            s->kin_cap[q] = cap;
+        }
+        const std::vector<int32_t> &new_of_old = s->plan->plan.new_of_old;      // world == 1: device numbering = the planner's numbering
+        for (int32_t k = 0; k < count; ++k) s->h_kin_idx[q][k] = new_of_old[(size_t)ids[k]];
+        std::memcpy(s->h_kin_pos[q], pos, (size_t)count * 3 * sizeof(float));
+        flush_deferred(s);       // the previous tick's last kernel still reads the old positions of these particles
+        hipLaunchKernelGGL(sbk::kinematic_scatter_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s->stream, s->d_pos3.p, s->h_kin_idx[q],
+                           s->h_kin_pos[q], (int)count);
+        HIP_CHECK(hipGetLastError());
+        HIP_CHECK(hipEventRecord(s->ev_kin[q], s->stream));
         return SB_OK;
     });
 }

@@ -105,6 +105,7 @@ SIGNATURES = {
     "sb_step": (C.c_int, [_P, C.c_float, C.c_int32]),
     "sb_get_positions": (C.c_int, [_P, _P, C.c_int32]),
     "sb_get_velocities": (C.c_int, [_P, _P, C.c_int32]),
+    "sb_set_kinematic_positions": (C.c_int, [_P, _P, _P, C.c_int32]),
     "sb_set_state": (C.c_int, [_P, _P, _P, C.c_int32]),
     "sb_readback_begin": (C.c_int, [_P]),
     "sb_readback_end": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_float))]),

@@ -204,6 +204,12 @@ class Softbody:
         tri = np.ascontiguousarray(tri, dtype=np.int32).reshape(-1, 3)
         check(native.lib().sb_set_render_triangles(self._h, tri.ctypes.data_as(C.POINTER(C.c_int32)), tri.shape[0]))
 
+    def set_kinematic_positions(self, ids, pos):
+        """Move pinned particles (inverse mass 0) to new positions between two ticks (SPEC.md 2, attachments)."""
+        ids = i32(ids); pos = f32(pos, (-1, 3))
+        assert pos.shape[0] == ids.shape[0]
+        check(native.lib().sb_set_kinematic_positions(self._h, ptr(ids), ptr(pos), int(ids.shape[0])))
+
     def set_state(self, pos, vel):
         pos = f32(pos, (-1, 3)); vel = f32(vel, (-1, 3))
         check(native.lib().sb_set_state(self._h, ptr(pos), ptr(vel), self.n))
