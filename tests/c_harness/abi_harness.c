@@ -67,6 +67,13 @@ int main(int argc, char **argv) {
         CHECK(sb_get_positions(s, out, N) == SB_OK, "sb_get_positions");
         int finite = 1; for (int k = 0; k < 3 * N; ++k) if (!isfinite(out[k])) finite = 0;
         CHECK(finite && out[1] < pos[1], "positions are finite and the cube fell");
+        /* the table validator and kinematic particles through the plain C ABI */
+        sb_validate_report rep;
+        CHECK(sb_debug_validate(s, 0, &rep) == SB_OK && rep.constraints_checked == m && rep.first_stage == -1, "sb_debug_validate: every constraint seen, clean");
+        { int clean = 1; for (int k = 0; k < 6; ++k) if (rep.errors[k]) clean = 0; CHECK(clean, "no validator errors"); }
+        int32_t free_id = 0; float target[3] = {0.0f, 9.0f, 0.0f};
+        CHECK(sb_set_kinematic_positions(s, &free_id, target, 1) == SB_ERR_INVALID_ARG, "a free particle cannot be moved kinematically");
+        CHECK(sb_set_kinematic_positions(s, NULL, NULL, 0) == SB_OK, "an empty kinematic list is accepted");
         CHECK(sb_destroy(s) == SB_OK, "sb_destroy");
         free(out);
     } else {
