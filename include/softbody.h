@@ -179,8 +179,10 @@ int sb_set_state(sb_solver *s, const float *pos_xyz, const float *vel_xyz, int32
 /* Kinematic particles (SPEC.md 2; attachments to animated objects): between two ticks, move particles whose inverse mass is 0 to new
  * positions -- count entries, ids in the caller's numbering (each at most once), pos_xyz 3 floats per entry. The next tick's constraints
  * pull their neighbours along. An id whose inverse mass is not 0 is refused (SB_ERR_INVALID_ARG, nothing is changed). Asynchronous like
- * sb_step (the targets are copied before the call returns); completes the previous tick first, so a host that calls it every tick gives up
- * the fused tick boundary (one launch per tick). Single-rank solvers only (world == 1). */
+ * sb_step (the targets are copied before the call returns). The targets are pending until the next tick starts: when that tick's first
+ * kernel also finishes the previous tick (the lazy tick boundary of sb_step) they are applied inside it, so a host that moves its pins
+ * every tick keeps the fusion (sb_stats.ticks_fused_kinematic); position reads in between already show them. Single-rank solvers only
+ * (world == 1). */
 int sb_set_kinematic_positions(sb_solver *s, const int32_t *ids, const float *pos_xyz, int32_t count);
 /* Asynchronous render readback: sb_readback_begin snapshots the positions as of every sb_step issued so far
  * (a small kernel on the compute stream) and starts a D2H copy into plugin-owned pinned memory on a second
@@ -280,6 +282,7 @@ typedef struct {
     int64_t readback_peeks;
     int64_t readback_peek_tiles;
     int64_t ticks_fused;                            /* sb_step calls whose first kernel also finished the tick before (lazy tick boundary kept) */
+    int64_t ticks_fused_kinematic;                  /* ... of which that kernel also applied kinematic targets (sb_set_kinematic_positions) */
 } sb_stats;
 int sb_get_stats(sb_solver *s, sb_stats *out);
 

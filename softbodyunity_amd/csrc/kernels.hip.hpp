@@ -105,6 +105,10 @@ struct TileArgs {
     // KIND 4 (peek): where the tick-end positions of the launch's tiles go (packed xyz, device numbering); the state arrays stay as
     // they are
     float *peek_out;
+    // KIND 5 (kinematic targets inside the fused tick boundary): kin_map[g] = slot of pinned particle g (-1: free particle),
+    // kin_target[3 slot ..] = its pending target or NaN; the lane that applies a target writes NaN back
+    const int32_t *kin_map;
+    float *kin_target;
 };
 // (A PACK variant -- T0 tiles writing the send buffer themselves, entries {tile-local index, send slot} per tile -- was built and
 // measured in round 3: bit-exact, but 0.786 -> 0.861 ms per tick in the serialised W = 8 loopback schedule and no change in the
@@ -415,6 +419,8 @@ __device__ __forceinline__ bool project_bending_row(const float (&P)[4], float r
 //                                      (start substep s), the same rounds again
 //   KIND 2 (after the last substep)  : the tile's rounds, MARK: write v, stop
 //   KIND 3 (T2 layer, every substep)  : the tile's rounds once, no MARK; the particles come from an explicit list
+//   KIND 5 (a tick's fused first kernel when kinematic targets are pending): KIND 1, and between the velocity of the substep that
+//                                      ended and the integrate of the next one a particle with w = 0 that has a target takes it
 //   KIND 4 (peek at the tick's end)   : what KIND 2 would leave as positions (the tile's rounds + collide), written to a side
 //                                      array; nothing of the state is written, so the deferred last kernel of a tick can still
 //                                      be fused with the first kernel of the next one (render readback, solver.hip peek_positions)
@@ -429,8 +435,12 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 // Register budget (HIP: second launch-bound = waves per SIMD). LDS allows ~14 tiles per CU, so aim for that many waves.
 template <bool QUADS, int THREADS> constexpr int kWavesPerSimd = QUADS ? (THREADS == 64 ? 3 : (THREADS == 512 ? 2 : 4)) : (THREADS == 256 ? 8 : (THREADS == 128 ? 6 : 4));   // 128 lanes: 7 waves (72 VGPRs) measured 1 % slower, 8 spill
 // WPAL = inverse masses are read as one-byte palette indices (the palette entry comes from another lane by ds_bpermute).
-template <int KIND, bool QUADS, int THREADS, int PPT, bool WPAL, int HALO = kHaloNone>
+template <int KIND_, bool QUADS, int THREADS, int PPT, bool WPAL, int HALO = kHaloNone>
 __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile_kernel(const TileDesc *tiles_at_base, int n_workgroups, TileArgs A) {
+    // KIND 5 = KIND 1 whose MARK step also applies pending kinematic targets (see TileArgs::kin_map): an instantiation of its own, so the
+    // ordinary mid-tick kernel carries nothing of it
+    constexpr int KIND = KIND_ == 5 ? 1 : KIND_;
+    constexpr bool KIN = KIND_ == 5;
     constexpr bool GHOSTS = HALO == kHaloGhosts;
     // The first two arguments (3 dwords) are preloaded into SGPRs at dispatch (-mllvm -amdgpu-kernarg-preload-count=3, Makefile):
     // the descriptor fetch starts with the kernel instead of behind the kernel-argument load (one memory round trip less on the
@@ -635,6 +645,15 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
                     float qx = dx * tp.inv_h, qy = dy * tp.inv_h, qz = dz * tp.inv_h;
                     vx = qx * tp.kd; vy = qy * tp.kd; vz = qz * tp.kd;
                 }
+                bool moved = false;
+                if (KIN && P.w == 0.0f) {     // kinematic particle: SPEC.md 2 -- after the velocity of the tick that ended, before the integrate
+                    const int ks = A.kin_map[g[m]];
+                    if (ks >= 0) {
+                        float *t = A.kin_target + 3 * (size_t)ks;
+                        const float tx = t[0], ty = t[1], tz = t[2];
+                        if (tx == tx) { P.x = tx; P.y = ty; P.z = tz; moved = true; t[0] = __int_as_float(0x7fc00000); }
+                    }
+                }
                 if (KIND == 2) {
                     A.vel[o + 0] = vx; A.vel[o + 1] = vy; A.vel[o + 2] = vz;
                 } else {
@@ -645,7 +664,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
                         float hx = tp.h * vx, hy = tp.h * vy, hz = tp.h * vz;
                         P.x = P.x + hx; P.y = P.y + hy; P.z = P.z + hz;
                         lds_pos[l] = P;
-                    }
+                    } else if (KIN && moved) lds_pos[l] = P;
                 }
             }
     };
@@ -1029,6 +1048,14 @@ __global__ __launch_bounds__(256) void kinematic_scatter_kernel(float *pos_xyz, 
     if (k >= count) return;
     const size_t o = 3 * (size_t)idx[k];
     pos_xyz[o] = targets[3 * (size_t)k]; pos_xyz[o + 1] = targets[3 * (size_t)k + 1]; pos_xyz[o + 2] = targets[3 * (size_t)k + 2];
+}
+
+// The same targets handed to the fused first kernel of the next tick instead (tile_kernel KIND 5): entry k goes to its particle's slot.
+__global__ __launch_bounds__(256) void kinematic_fill_kernel(const int32_t *kin_map, float *kin_target, const int32_t *idx, const float *targets, int count) {
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
+    const size_t o = 3 * (size_t)kin_map[idx[k]];
+    kin_target[o] = targets[3 * (size_t)k]; kin_target[o + 1] = targets[3 * (size_t)k + 1]; kin_target[o + 2] = targets[3 * (size_t)k + 2];
 }
 
 // Render readback: owned positions (device order, float4) -> caller order, packed xyz.

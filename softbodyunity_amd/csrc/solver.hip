@@ -16,6 +16,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -210,7 +211,7 @@ struct sb_solver {
     sbk::TickParams tp_host{};
     bool tp_valid = false;
     struct CachedGraph { hipGraphExec_t exec; uint64_t last_use; };
-    std::map<int, CachedGraph> graphs;         // key = substeps * 4 + (1: tick starts with the fused kernel) + (2: last kernel deferred)
+    std::map<int, CachedGraph> graphs;         // key = substeps * 8 + (1: tick starts with the fused kernel) + (2: last kernel deferred) + (4: that kernel carries kinematic targets)
     uint64_t graph_clock = 0;                  // least recently used entry is evicted beyond kMaxGraphs (a host that varies substeps)
     static constexpr size_t kMaxGraphs = 8;
     // Lazy tick boundary: the last kernel of a tick (rounds + collide + velocity write) is deferred; if the next tick
@@ -277,6 +278,15 @@ struct sb_solver {
     size_t kin_cap[kKinSlots] = {0, 0, 0, 0};
     hipEvent_t ev_kin[kKinSlots] = {nullptr, nullptr, nullptr, nullptr};
     int kin_next = 0;
+    // Targets are PENDING until the next tick starts: if that tick's first kernel also finishes the tick before (lazy tick boundary),
+    // they travel into it (tile_kernel KIND 5 applies them between the old tick's velocity and the new tick's integrate) and the
+    // fusion is kept; any other way across the boundary (state read or written, parameters changed, first tick) completes the old
+    // tick and scatters them onto the positions (materialise_kinematic).
+    int kin_pending = -1, kin_pending_count = 0;      // ring slot that holds them, or -1
+    DevBuf<int32_t> d_kin_map;             // per local particle: slot of a pinned particle, -1 for a free one (built at the first use)
+    DevBuf<float> d_kin_target;            // 3 floats per pinned particle: pending target or NaN
+    int64_t n_kin_fused = 0;               // ticks whose fused first kernel carried targets
+    bool kin_fuse = true;                  // SB_NO_KIN_FUSE unset (A/B: pending targets always complete the previous tick first)
     // Peek (world == 1): a position read while the tick's last kernel is deferred runs tile_kernel<4> -- the same rounds + collide on
     // the same inputs, written to d_peek instead of the state -- so the deferred kernel can still be fused with the next tick's first
     // one. A render-set-only readback peeks only at the T0 tiles that hold a render particle (peek_tiles: copies of their descriptors).
@@ -1106,6 +1116,7 @@ void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = 
     A.store_through = tile_end - tile_begin <= s->store_through_max_tiles ? 3 : s->store_through_large;
     A.ghost_src = ghosts ? s->d_recvbuf.p : nullptr; A.n_owned = (int32_t)s->n_owned;
     A.peek_out = KIND == 4 ? s->d_peek.p : nullptr;
+    A.kin_map = KIND == 5 ? s->d_kin_map.p : nullptr; A.kin_target = KIND == 5 ? s->d_kin_target.p : nullptr;
     A.max_local = D.max_local; A.win_dwords = D.win_dwords; A.tile_base = tile_begin; A.pal_dwords = D.pal_dwords; A.rounds_dwords = D.rounds_dwords;
     const sbk::TileDesc *tiles_at_base = table ? table : D.tiles.p + tile_begin;      // the two preloaded kernel arguments (tile_kernel)
     const int n_wg = tile_end - tile_begin;
@@ -1163,12 +1174,13 @@ struct LaunchTimer {            // optional HIP-event pair around every launch o
 };
 
 // Launch the tile kernel K_it of a tick of `substeps` substeps (no halo).
-void launch_tick_kernel(sb_solver *s, int it, int substeps, LaunchTimer *lt, int tile_begin = 0, int tile_end = -1) {
+void launch_tick_kernel(sb_solver *s, int it, int substeps, LaunchTimer *lt, int tile_begin = 0, int tile_end = -1, bool kin = false) {
     const int tl = s->plan->plan.tiling ? (it & 1) : 0;
     DevTiling &D = s->tiling[tl];
     if (lt && D.n_tiles) lt->begin(it == 0 ? 2 + (int)s->gcolours.size() : (it == substeps ? 3 + (int)s->gcolours.size() : tl));
     const int halo_in = s->fused_unpack && tl == 1 ? sbk::kHaloGhosts : sbk::kHaloNone;      // T1 tiles read their ghosts straight from the receive buffer
     if (it == 0) launch_tile<0>(s, D, tile_begin, tile_end);
+    else if (it < substeps && kin) launch_tile<5>(s, D, tile_begin, tile_end);        // (world == 1: the fused first kernel of a tick, with kinematic targets)
     else if (it < substeps) launch_tile<1>(s, D, tile_begin, tile_end, halo_in);
     else launch_tile<2>(s, D, tile_begin, tile_end, halo_in);
     if (lt && D.n_tiles) lt->end();
@@ -1202,7 +1214,7 @@ void launch_gcolour(sb_solver *s, int gc, LaunchTimer *lt) {
 // s-1), collide + velocity update + integrate, the same rounds again (start of substep s).
 // fused_first: the tick starts with an ordinary mid-tick kernel on T0 that also finishes the PREVIOUS tick (its
 // deferred last kernel); defer_last: leave K_substeps to the next tick / to flush_deferred().
-void enqueue_substeps(sb_solver *s, int substeps, LaunchTimer *lt = nullptr, bool fused_first = false, bool defer_last = false) {
+void enqueue_substeps(sb_solver *s, int substeps, LaunchTimer *lt = nullptr, bool fused_first = false, bool defer_last = false, bool kin = false) {
     const bool two = s->plan->plan.tiling;
     if (s->overlap_halo) {
         // Overlapped schedule (opt-in, SB_HALO_OVERLAP): a T0 kernel runs its boundary tiles first; the ghost exchange
@@ -1236,7 +1248,7 @@ void enqueue_substeps(sb_solver *s, int substeps, LaunchTimer *lt = nullptr, boo
     for (int it = 0; it <= substeps; ++it) {
         if (it == substeps && defer_last) break;
         if (two && (it & 1)) halo_exchange(s, 1);
-        if (it == 0 && fused_first) launch_tick_kernel(s, 2, 4, lt);   // an even, interior step index: KIND 1 on T0
+        if (it == 0 && fused_first) launch_tick_kernel(s, 2, 4, lt, 0, -1, kin);   // an even, interior step index: KIND 1 (5 with kinematic targets) on T0
         else launch_tick_kernel(s, it, substeps, lt);
         if (it == substeps) break;
         for (size_t ly = 0; ly < s->t2_layer_range.size(); ++ly) launch_t2_layer(s, (int)ly, lt);
@@ -1249,13 +1261,49 @@ void enqueue_substeps(sb_solver *s, int substeps, LaunchTimer *lt = nullptr, boo
 }
 
 // Launch the deferred last kernel of the previous tick (uses the tick parameters still on the device).
-void flush_deferred(sb_solver *s) {
-    if (!s->deferred) return;
-    const int S = s->deferred_substeps;
-    s->deferred = false;
-    if (s->plan->plan.tiling && (S & 1)) halo_exchange(s, 1);
-    launch_tick_kernel(s, S, S, nullptr);
+// Pending kinematic targets onto `dst` (the positions, or the peek's side array): scatter kernel over the pinned host table.
+void scatter_kinematic(sb_solver *s, float *dst) {
+    const int q = s->kin_pending, count = s->kin_pending_count;
+    hipLaunchKernelGGL(sbk::kinematic_scatter_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s->stream, dst, s->h_kin_idx[q], s->h_kin_pos[q], count);
     HIP_CHECK(hipGetLastError());
+}
+// The table of the pending targets has been handed to its last reader: it may be reused once that kernel is done.
+void retire_kinematic(sb_solver *s) {
+    HIP_CHECK(hipEventRecord(s->ev_kin[s->kin_pending], s->stream));
+    s->kin_pending = -1; s->kin_pending_count = 0;
+}
+
+void flush_deferred(sb_solver *s) {
+    if (s->deferred) {
+        const int S = s->deferred_substeps;
+        s->deferred = false;
+        if (s->plan->plan.tiling && (S & 1)) halo_exchange(s, 1);
+        launch_tick_kernel(s, S, S, nullptr);
+        HIP_CHECK(hipGetLastError());
+    }
+    if (s->kin_pending >= 0) {       // the tick they follow is complete: the targets take effect
+        scatter_kinematic(s, s->d_pos3.p);
+        retire_kinematic(s);
+    }
+}
+
+// Everything a fused first kernel needs to apply the pending targets itself: the particle -> slot map (built once), the slot
+// array (NaN = no target), and this tick's targets written into their slots on the solver's stream.
+void stage_kinematic_for_fusion(sb_solver *s) {
+    if (!s->d_kin_map.p) {
+        const sbp::LocalPlan &L = s->plan->local;
+        std::vector<int32_t> map((size_t)s->n_local, -1);
+        int32_t n_pinned = 0;
+        for (int64_t l = 0; l < s->n_local; ++l) if (s->invm[(size_t)L.local_to_old[(size_t)l]] == 0.0f) map[(size_t)l] = n_pinned++;
+        s->d_kin_map.upload(map, s->dev_bytes);
+        std::vector<float> nan((size_t)std::max(n_pinned, 1) * 3, std::numeric_limits<float>::quiet_NaN());
+        s->d_kin_target.upload(nan, s->dev_bytes);
+    }
+    const int q = s->kin_pending, count = s->kin_pending_count;
+    hipLaunchKernelGGL(sbk::kinematic_fill_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s->stream, s->d_kin_map.p, s->d_kin_target.p,
+                       s->h_kin_idx[q], s->h_kin_pos[q], count);
+    HIP_CHECK(hipGetLastError());
+    retire_kinematic(s);
 }
 
 // ---- peek: tick-end positions without completing the tick ------------------------------------------------------------------------
@@ -1412,6 +1460,7 @@ int sb_create(const sb_desc *desc, sb_solver **out) {
         s->loopback = d.world > 1 && (d.debug_flags & SB_DEBUG_LOOPBACK) != 0;
         s->pack_tiles = !std::getenv("SB_NO_PACK");
         s->peek_enabled = !std::getenv("SB_NO_PEEK");
+        s->kin_fuse = !std::getenv("SB_NO_KIN_FUSE");
         if (const char *e = std::getenv("SB_PEEK_MIN_TILES")) s->peek_min_tiles = std::max(0, std::atoi(e));
         if (const char *e = std::getenv("SB_LDS_PAD")) s->lds_pad = (size_t)std::max(0, std::atoi(e));
         if (const char *e = std::getenv("SB_TILE_LANES")) s->tile_lanes = std::atoi(e) == 128 ? 128 : (std::atoi(e) == 256 ? 256 : (std::atoi(e) == 512 ? 512 : 0));
@@ -1774,21 +1823,24 @@ int sb_step(sb_solver *s, float dt, int32_t substeps) {
         const sbk::TickParams tp_new = tick_params(s, dt, substeps);
         const bool can_defer = s->lazy_tick && (!s->plan->plan.tiling || (substeps & 1) == 0);
         const bool fuse = s->deferred && can_defer && s->deferred_substeps == substeps && s->tp_valid &&
-                          std::memcmp(&tp_new, &s->tp_host, sizeof(tp_new)) == 0;
+                          std::memcmp(&tp_new, &s->tp_host, sizeof(tp_new)) == 0 && (s->kin_fuse || s->kin_pending < 0);
         if (!fuse) flush_deferred(s); else ++s->n_fused;
+        // pending kinematic targets cross a fused tick boundary INSIDE the fused kernel (tile_kernel KIND 5)
+        const bool kin = fuse && s->kin_pending >= 0;
+        if (kin) { stage_kinematic_for_fusion(s); ++s->n_kin_fused; }
         upload_tick_params(s, dt, substeps);
         // world > 1: the exchange inside a captured graph is opt-in (SB_SCHEDULE_*_GRAPH), see DESIGN.md §7
         const bool graph_ok = s->desc.use_graph && (s->desc.world == 1 || s->graph_rccl);     // the overlapped schedule forks onto comm_stream inside the capture
         if (!graph_ok) {
-            enqueue_substeps(s, substeps, nullptr, fuse, can_defer);
+            enqueue_substeps(s, substeps, nullptr, fuse, can_defer, kin);
         } else {
-            const int key = substeps * 4 + (fuse ? 1 : 0) + (can_defer ? 2 : 0);
+            const int key = substeps * 8 + (fuse ? 1 : 0) + (can_defer ? 2 : 0) + (kin ? 4 : 0);
             auto it = s->graphs.find(key);
             if (it == s->graphs.end()) {
                 hipGraph_t g = nullptr;
                 HIP_CHECK(hipStreamBeginCapture(s->stream, hipStreamCaptureModeThreadLocal));
                 try {
-                    enqueue_substeps(s, substeps, nullptr, fuse, can_defer);
+                    enqueue_substeps(s, substeps, nullptr, fuse, can_defer, kin);
                 } catch (...) {
                     (void)hipStreamEndCapture(s->stream, &g);
                     if (g) (void)hipGraphDestroy(g);
@@ -2018,7 +2070,8 @@ static int get_state(sb_solver *s, float *out, int32_t n, bool velocity) {
         const sbp::LocalPlan &L = s->plan->local;
         // positions while the tick's last kernel is deferred: peek instead of completing the tick (the next sb_step keeps its fusion)
         const bool peek = !velocity && can_peek(s);
-        if (peek) peek_positions(s, false); else flush_deferred(s);
+        if (peek) { peek_positions(s, false); if (s->kin_pending >= 0) scatter_kinematic(s, s->d_peek.p); }     // (pending targets show in what is read; they stay pending)
+        else flush_deferred(s);
         if (s->desc.world == 1) {
             // single rank: every entry is ours, so the permutation to caller numbering runs on the GPU and one copy
             // lands in the caller's array (the host-side scatter below costs 25 ms for 16.7 M particles)
@@ -2086,6 +2139,7 @@ int sb_set_kinematic_positions(sb_solver *s, const int32_t *ids, const float *po
                 return fail(SB_ERR_INVALID_ARG, "sb_set_kinematic_positions: particle " + std::to_string(ids[k]) + " has a non-zero inverse mass (only pinned particles are kinematic)");
             for (int c = 0; c < 3; ++c) if (!(pos[3 * (size_t)k + c] == pos[3 * (size_t)k + c])) return fail(SB_ERR_INVALID_ARG, "sb_set_kinematic_positions: NaN");
         }
+        if (s->kin_pending >= 0) flush_deferred(s);       // two moves without a tick between them: the earlier one takes effect first
         const int q = s->kin_next;
         s->kin_next = (q + 1) % sb_solver::kKinSlots;
         if (!s->ev_kin[q]) HIP_CHECK(hipEventCreateWithFlags(&s->ev_kin[q], hipEventDisableTiming));
@@ -2101,11 +2155,9 @@ int sb_set_kinematic_positions(sb_solver *s, const int32_t *ids, const float *po
         const std::vector<int32_t> &new_of_old = s->plan->plan.new_of_old;      // world == 1: device numbering = the planner's numbering
         for (int32_t k = 0; k < count; ++k) s->h_kin_idx[q][k] = new_of_old[(size_t)ids[k]];
         std::memcpy(s->h_kin_pos[q], pos, (size_t)count * 3 * sizeof(float));
-        flush_deferred(s);       // the previous tick's last kernel still reads the old positions of these particles
-        hipLaunchKernelGGL(sbk::kinematic_scatter_kernel, dim3((unsigned)((count + 255) / 256)), dim3(256), 0, s->stream, s->d_pos3.p, s->h_kin_idx[q],
-                           s->h_kin_pos[q], (int)count);
-        HIP_CHECK(hipGetLastError());
-        HIP_CHECK(hipEventRecord(s->ev_kin[q], s->stream));
+        // PENDING until the next tick starts (the previous tick's held-back last kernel still reads the old positions of these
+        // particles): a fused first kernel takes them along, every other way across the tick boundary scatters them (flush_deferred)
+        s->kin_pending = q; s->kin_pending_count = count;
         return SB_OK;
     });
 }
@@ -2172,6 +2224,7 @@ int sb_readback_begin(sb_solver *s) {
                 build_peek_subset(s, wanted);
             }
             peek_positions(s, compact);
+            if (s->kin_pending >= 0) scatter_kinematic(s, s->d_peek.p);
             src.xyz = s->d_peek.p;
         }
         if (compact) {      // only the render set leaves the device: snapshot just those particles
@@ -2333,6 +2386,7 @@ int sb_get_stats(sb_solver *s, sb_stats *out) {
     out->readback_peeks = s->n_peeks;
     out->readback_peek_tiles = s->n_peek_tiles;
     out->ticks_fused = s->n_fused;
+    out->ticks_fused_kinematic = s->n_kin_fused;
     out->plan_hash = s->plan_hash;
     if (!P.rank_cost.empty()) {
         out->partition_cost = P.rank_cost[(size_t)s->desc.rank];

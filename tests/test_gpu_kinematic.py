@@ -13,8 +13,15 @@ def _bits(a):
     return np.ascontiguousarray(a).view(np.uint32)
 
 
+@pytest.mark.parametrize("peek_small", [False, True])
 @pytest.mark.parametrize("case", ["hanging_cube", "tets_dragged_over_the_ground"])
-def test_moved_pins_match_the_oracle(case, oracle_mod):
+def test_moved_pins_match_the_oracle(case, peek_small, oracle_mod, monkeypatch):
+    # peek_small: position reads between a move and the step peek (side array + the pending targets scattered onto it) instead of
+    # completing the tick, also on these small meshes
+    if peek_small:
+        monkeypatch.setenv("SB_PEEK_MIN_TILES", "0")
+    else:
+        monkeypatch.delenv("SB_PEEK_MIN_TILES", raising=False)
     if case == "hanging_cube":
         n = 20
         mesh = jelly_cube(n)
@@ -46,6 +53,10 @@ def test_moved_pins_match_the_oracle(case, oracle_mod):
         x, v = sb.get_positions(), sb.get_velocities()
         assert np.array_equal(_bits(x), _bits(o.x)) and np.array_equal(_bits(v), _bits(o.v))
         assert np.array_equal(_bits(x[pins]), _bits(target)) and not v[pins].any()              # where they were put, at rest
+        st = sb.stats()
+        # moves that met a held-back last kernel travelled INSIDE the fused first kernel of the next tick (tile_kernel KIND 5)
+        assert st["ticks_fused_kinematic"] >= (9 if peek_small else 4), st
+        assert st["ticks_fused"] >= st["ticks_fused_kinematic"]
         moved = np.linalg.norm(x - mesh.pos, axis=1)
         assert moved[np.setdiff1d(np.arange(mesh.n), pins)].max() > 0.05                         # the body followed
     finally:
