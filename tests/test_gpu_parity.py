@@ -22,6 +22,8 @@ def _run_pair(oracle_mod, mesh, ticks, substeps, dt=0.02, compliance=(0.0, 0.0, 
             o.step(dt, substeps)
         x = sb.get_positions(); v = sb.get_velocities()
         st = sb.stats()
+        rep = sb.validate()          # every parity case also has the validator kernel re-read the tables its launches used
+        assert rep["errors"] == [0] * 6 and rep["constraints_checked"] == sum(st["n_constraints_local"]), rep
     finally:
         sb.OnDestroy()
     rel, mabs, bit = oracle_mod.parity_error(x, o.x, mesh.pos)
