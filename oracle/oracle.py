@@ -114,6 +114,13 @@ class Oracle:
         self.params.plane[:] = [float(normal[0]), float(normal[1]), float(normal[2]), float(d)]
         self.params.plane_on = 1 if enabled else 0
 
+    def set_kinematic_positions(self, ids, pos):
+        """SPEC.md §2, kinematic particles: between two ticks x <- target for particles with w = 0 (others are refused)."""
+        ids = np.asarray(ids, np.int64)
+        if (self.w[ids] != 0).any():
+            raise ValueError("only particles with inverse mass 0 are kinematic")
+        self.x[ids] = np.asarray(pos, np.float32).reshape(-1, 3)
+
     def collide(self):
         lib().orc_collide(_p(self.x), _p(self.w), C.c_int(self.n), C.byref(self.params))
 

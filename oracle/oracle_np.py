@@ -106,6 +106,14 @@ class NumpySolver:
     def v(self):
         return np.stack(self.V, axis=1)
 
+    def set_kinematic_positions(self, ids, pos):
+        """SPEC.md §2, kinematic particles: between two ticks x <- target for particles with w = 0 (others are refused)."""
+        ids = np.asarray(ids, np.int64); pos = np.asarray(pos, np.float32).reshape(-1, 3)
+        if (self.w[ids] != 0).any():
+            raise ValueError("only particles with inverse mass 0 are kinematic")
+        for c in range(3):
+            self.X[c][ids] = pos[:, c]
+
     # ---- SPEC §2 ----------------------------------------------------------------------------------
     def step(self, dt, substeps):
         S = F(substeps)

@@ -45,7 +45,7 @@ def test_moved_pins_match_the_oracle(case, peek_small, oracle_mod, monkeypatch):
             if t != 5:
                 target = rest + np.array([0.3 * np.sin(0.4 * t), 0.1 * np.cos(0.7 * t) - 0.1, 0.05 * t], np.float32)
                 sb.set_kinematic_positions(pins, target)
-                o.x[pins] = target
+                o.set_kinematic_positions(pins, target)
             if t & 1:
                 assert np.array_equal(_bits(sb.get_positions()), _bits(o.x)), f"after the move of tick {t}"
             sb.step()

@@ -83,6 +83,26 @@ def test_c_oracle_equals_the_numpy_restatement_bit_for_bit(oracle_mod, case):
     assert np.isfinite(c.x).all() and not np.array_equal(_bits(c.x), _bits(mesh.pos))
 
 
+def test_kinematic_particles_in_both_restatements(oracle_mod):
+    # SPEC.md 2, kinematic particles: the pinned top layer of the cube is moved by the host between ticks; both restatements take the
+    # assignment, agree bit for bit, keep the pins where they were put (at rest) and drag the body along; a free particle is refused
+    mesh = jelly_cube(8, pin_top=True)
+    pins = np.nonzero(mesh.inv_mass == 0)[0]
+    rest = mesh.pos[pins].copy()
+    c, p = _pair(oracle_mod, mesh, damping=0.3)
+    for t in range(8):
+        target = rest + np.array([0.25 * np.sin(0.5 * t), 0.0, 0.1 * t], np.float32)
+        c.set_kinematic_positions(pins, target); p.set_kinematic_positions(pins, target)
+        c.step(0.02, 6); p.step(0.02, 6)
+        assert np.array_equal(_bits(c.x), _bits(p.x)) and np.array_equal(_bits(c.v), _bits(p.v))
+        assert np.array_equal(_bits(c.x[pins]), _bits(target)) and not c.v[pins].any()
+    free = np.nonzero(mesh.inv_mass > 0)[0]
+    assert (c.x[free, 2] - mesh.pos[free, 2]).mean() > 0.03           # the body followed the handle along z
+    for solver in (c, p):
+        with pytest.raises(ValueError):
+            solver.set_kinematic_positions(free[:1], np.zeros((1, 3), np.float32))
+
+
 def test_numpy_restatement_on_the_planners_groups_equals_the_c_oracle_on_the_planners_order(oracle_mod):
     # the one test here that uses the plugin's planner: its published GROUPS (claimed vertex-disjoint) become the numpy solver's
     # classes, its flat order drives the sequential C oracle -- equal bits means the groups really commute, per substep parity
