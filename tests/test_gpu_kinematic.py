@@ -14,7 +14,7 @@ def _bits(a):
 
 
 @pytest.mark.parametrize("peek_small", [False, True])
-@pytest.mark.parametrize("case", ["hanging_cube", "tets_dragged_over_the_ground"])
+@pytest.mark.parametrize("case", ["hanging_cube", "tets_dragged_over_the_ground", "hanging_cube_global_colours_only"])
 def test_moved_pins_match_the_oracle(case, peek_small, oracle_mod, monkeypatch):
     # peek_small: position reads between a move and the step peek (side array + the pending targets scattered onto it) instead of
     # completing the tick, also on these small meshes
@@ -22,11 +22,13 @@ def test_moved_pins_match_the_oracle(case, peek_small, oracle_mod, monkeypatch):
         monkeypatch.setenv("SB_PEEK_MIN_TILES", "0")
     else:
         monkeypatch.delenv("SB_PEEK_MIN_TILES", raising=False)
-    if case == "hanging_cube":
+    if case.startswith("hanging_cube"):
         n = 20
         mesh = jelly_cube(n)
         pins = np.nonzero(mesh.pos[:, 1] > mesh.pos[:, 1].max() - 0.5)[0].astype(np.int32)       # the top layer
         kw = dict(substeps=8, damping=0.05)
+        if case.endswith("global_colours_only"):
+            kw["tile_particles"] = -1              # tiles without constraints of their own: the MARK step alone carries the targets
         okw = dict(damping=0.05)
     else:
         mesh = bunny_surrogate(target_verts=5000, seed=11)
