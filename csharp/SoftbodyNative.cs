@@ -49,7 +49,8 @@ namespace SoftbodyMI355X
         public long haloParticlesRecv;
         public ulong planHash;
         public int haloSchedule, haloUnpackFused;
-        public long readbackPeeks, readbackPeekTiles, ticksFused, ticksFusedKinematic;   // position reads served by a peek; T0 workgroups of one render-set peek (-1: none set up)
+        public long readbackPeeks, readbackPeekTiles, ticksFused, ticksFusedKinematic;
+        public long lanePackedTilesT0, lanePackedTilesT1;   // workgroups whose spring slots are lane-packed (16 B per lane)   // position reads served by a peek; T0 workgroups of one render-set peek (-1: none set up)
     }
 
     [StructLayout(LayoutKind.Sequential)]

@@ -283,6 +283,7 @@ typedef struct {
     int64_t readback_peek_tiles;
     int64_t ticks_fused;                            /* sb_step calls whose first kernel also finished the tick before (lazy tick boundary kept) */
     int64_t ticks_fused_kinematic;                  /* ... of which that kernel also applied kinematic targets (sb_set_kinematic_positions) */
+    int64_t lane_packed_tiles[2];                   /* workgroups per tiling whose spring slots are lane-packed (16 B per lane instead of 4 B per slot) */
 } sb_stats;
 int sb_get_stats(sb_solver *s, sb_stats *out);
 

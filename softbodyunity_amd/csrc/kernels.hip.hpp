@@ -31,7 +31,7 @@ struct TileDesc {
     uint32_t s_begin;          // dword offset of the tile's stream
     uint32_t s_hdr;            // dwords of round words + palette (each padded to 4): round data starts at s_begin + s_hdr
     uint32_t s_len;            // total dwords (multiple of 4)
-    uint32_t pad3;
+    uint32_t packed_lanes;     // 0, or 128: LANE-PACKED slots (see kLanePack*) for workgroups of that many lanes -- the launch must use that width
     int32_t run_overflow;      // runs beyond kInlineRuns live at runs_overflow[run_overflow ...]
     int32_t n_pal;             // palette entries (0 = no dictionary coding), stored after the round words
     int32_t n_steps;           // wave items per wave (meshes with tets / hinges; 0 = none), see kItem* below
@@ -39,6 +39,12 @@ struct TileDesc {
     int2 runs[10];             // {first particle (device numbering), first tile-local index}; unused entries: {0, INT_MAX}
 };
 constexpr int kInlineRuns = 10;
+// Lane-packed slots (round 3, second session). A register-resident spring tile run by 128-lane workgroups gives every lane two slots in
+// each of its (at most three) rounds and keeps them in registers for both passes; the slots need 9 + 9 bits of tile-local indices and a
+// palette index. Stored as ONE 16-byte word per lane -- six 21-bit fields {i:9 | j:9 | palette:3}, field 2 r + u = the lane's slot u of
+// round r (constraint lane + 128 u of that round; beyond the round's count the field is 0) -- the tile's data is 2 KiB instead of 3 KiB
+// (4 bytes per slot), it arrives in the lane's first window load and never touches LDS. build_device decides per tile (solver.hip).
+constexpr int kLanePackLanes = 128, kLanePackRounds = 3, kLanePackFieldBits = 21, kLanePackMaxPalette = 8;
 // Wave items (meshes with tets / hinges, 4-wave tiles): the host deals every group's work to the four waves ahead of time --
 // hinges first, then tets (16 four-lane constraints per wave), then springs (64 per wave), boustrophedon over the rows of
 // a group -- and stores for every wave one dword per STEP (= one row of one group): what to project, how many, where the
@@ -575,6 +581,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
 #define SB_KW (QUADS ? 4 : 2)
 #endif
     constexpr int kW = SB_KW;
+    const bool lane_packed = !QUADS && kTileThreads == kLanePackLanes && td.packed_lanes == (uint32_t)kLanePackLanes;     // (uniform)
     const uint32_t n4_first = (min(win_lo + win, d_hi) - win_lo) >> 2;
     const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(tstream + win_lo);
     u32x4 wv[kW];
@@ -610,7 +617,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
 #pragma unroll
         for (int q = 0; q < kW; ++q) {
             const uint32_t i = tid + q * kTileThreads;
-            if (i < n4_first) dst[i] = wv[q];
+            if (i < n4_first && !lane_packed) dst[i] = wv[q];      // (lane-packed slots stay in wv[0])
         }
         for (uint32_t i = tid + kW * kTileThreads; i < n4_first; i += kTileThreads) dst[i] = wsrc[i];
     }
@@ -698,7 +705,17 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
                 rcnt[r] = 0;
                 if (r < n_rounds_all) {
                     rcnt[r] = (int)((uint32_t)__builtin_amdgcn_readlane((int)rwl, r) & 1023u);
-                    if (tile_compact) {
+                    if (kCPL == 2 && lane_packed) {
+                        // the lane's own 16-byte word, loaded with the window's first sweep: fields 2 r and 2 r + 1
+#pragma unroll
+                        for (int u = 0; u < kCPL; ++u) {
+                            const int bit = kLanePackFieldBits * (2 * r + u), w0 = bit >> 5, sh = bit & 31;
+                            const uint32_t lo = wv[0][w0] >> sh;
+                            const uint32_t hi = (sh + kLanePackFieldBits > 32) ? (wv[0][w0 + 1 < 4 ? w0 + 1 : 3] << ((32 - sh) & 31)) : 0u;
+                            const uint32_t f = (lo | hi) & ((1u << kLanePackFieldBits) - 1u);
+                            rs[r][u] = (f & 511u) | (((f >> 9) & 511u) << 12) | ((f >> 18) << 24);
+                        }
+                    } else if (tile_compact) {
 #pragma unroll
                         for (int u = 0; u < kCPL; ++u) {
                             const int c = tid + u * kTileThreads;
@@ -1340,6 +1357,34 @@ __global__ __launch_bounds__(kValidateThreads) void validate_tiles_kernel(const 
     unsigned int tot[3] = {0, 0, 0};
     uint32_t off = td.s_hdr;
     bool walk_ok = size_ok;
+    if (size_ok && td.packed_lanes) {
+        // lane-packed slots (kLanePack*): one 16-byte word per lane, field 2 r + u = slot lane + 128 u of round r
+        const uint32_t P = td.packed_lanes;
+        if (P != (uint32_t)kLanePackLanes || td.n_rounds > kLanePackRounds || td.n_pal <= 0 || td.n_pal > kLanePackMaxPalette || td.n_local > kSmallTile ||
+            td.s_hdr + 4u * P > td.s_len) { if (tid == 0) flag(3, -1); walk_ok = false; }
+        for (int r = 0; walk_ok && r < td.n_rounds; ++r) {
+            const uint32_t w = ts[r];
+            const uint32_t cnt = w & 1023u;
+            if (cnt > 2u * P || ((w >> 10) & 0xfffffu) != 0u) { if (tid == 0) flag(3, r); walk_ok = false; break; }
+            for (int q = tid; q < kLargeTile / 32; q += kValidateThreads) bitmap[q] = 0;
+            __syncthreads();
+            for (uint32_t c = tid; c < cnt; c += kValidateThreads) {
+                const uint32_t lane = c % P, u = c / P, bit = (uint32_t)kLanePackFieldBits * (2u * (uint32_t)r + u), w0 = bit >> 5, sh = bit & 31u;
+                const uint32_t *wd = ts + td.s_hdr + 4u * lane;
+                uint64_t two = (uint64_t)wd[w0] | ((uint64_t)(w0 + 1 < 4 ? wd[w0 + 1] : 0u) << 32);
+                const uint32_t f = (uint32_t)(two >> sh) & ((1u << kLanePackFieldBits) - 1u);
+                const uint32_t p0 = f & 511u, p1 = (f >> 9) & 511u;
+                if ((f >> 18) >= (uint32_t)td.n_pal) flag(0, r);
+                for (int e = 0; e < 2; ++e) {
+                    const uint32_t p = e ? p1 : p0;
+                    if (p >= (uint32_t)td.n_local) flag(0, r);
+                    else if (atomicOr(&bitmap[p >> 5], 1u << (p & 31)) & (1u << (p & 31))) flag(1, r);
+                }
+            }
+            __syncthreads();
+            tot[0] += cnt;
+        }
+    } else
     for (int r = 0; walk_ok && r < td.n_rounds; ++r) {
         const uint32_t w = ts[r];
         const uint32_t cnt = w & 1023u, n_vol = (w >> 10) & 1023u, n_bend = (w >> 20) & 1023u;

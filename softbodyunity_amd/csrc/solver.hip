@@ -142,6 +142,8 @@ struct DevTiling {
                                  // n_boundary tiles hold every ghost and every sent particle
     bool has_quads = false;
     int32_t item_waves = 0;      // waves per tile the wave items were dealt for (0 = the streams hold none)
+    int32_t packed_lanes = 0;    // 128: tiles of this tiling may hold lane-packed slots (kernels.hip.hpp kLanePack*): EVERY launch of it runs 128-lane workgroups
+    int64_t n_packed_tiles = 0;
     DevBuf<sbk::TileDesc> tiles;
     DevBuf<int2> runs_overflow;
     DevBuf<uint32_t> stream;     // per tile: [round words][rest-length dictionary][round data], see kernels.hip.hpp
@@ -607,6 +609,16 @@ void build_device(sb_solver *s) {
         const bool emit_items = (!s->vol_rest.empty() || !s->bend_rest.empty()) && !std::getenv("SB_NO_WAVE_ITEMS");
         const int item_waves = s->quad_lanes / 64;
         D.item_waves = emit_items ? item_waves : 0;
+        // Lane-packed slots (kernels.hip.hpp kLanePack*): only where every launch of the tiling is known to run 128-lane workgroups --
+        // a single-rank solver (no boundary / interior ranges) whose launches oversubscribe the chip (launch_tile: narrow) -- and the
+        // mesh has springs only. Which TILES then qualify is decided tile by tile below.
+        D.packed_lanes = 0;
+        bool all_small = true;       // (a tiling with a tile above 512 particles launches the 1 024-particle kernels)
+        for (size_t ci = 0; ci < n_plan_tiles; ++ci) all_small = all_small && G.tiles[LT.tile_ids[ci]].n_local <= sbk::kSmallTile;
+        if (tl < 2 && L.world == 1 && all_small && s->vol_rest.empty() && s->bend_rest.empty() && !no_palette && !std::getenv("SB_NO_LANE_PACK") &&
+            (s->tile_lanes == 0 || s->tile_lanes == sbk::kLanePackLanes) && (int64_t)packs.size() >= (int64_t)s->narrow_min_tiles)
+            D.packed_lanes = sbk::kLanePackLanes;
+        std::atomic<int64_t> n_packed_tiles{0};
         constexpr int64_t kPacksPerChunk = 128;
         const int64_t n_chunks = ((int64_t)packs.size() + kPacksPerChunk - 1) / kPacksPerChunk;
         std::vector<Piece> pieces((size_t)n_chunks);
@@ -745,7 +757,35 @@ void build_device(sb_solver *s) {
                 }
             }
             td.s_hdr = (uint32_t)(stream.size() - s0);
-            for (const PackRound &R : prog) {
+            bool lane_pack = D.packed_lanes == sbk::kLanePackLanes && compact && (int)pal.size() <= sbk::kLanePackMaxPalette && td.n_local <= sbk::kSmallTile &&
+                             !prog.empty() && (int)prog.size() <= sbk::kLanePackRounds;
+            for (const PackRound &R : prog) lane_pack = lane_pack && R.cnt[1] == 0 && R.cnt[2] == 0 && R.cnt[0] <= 2 * sbk::kLanePackLanes;
+            if (lane_pack) {
+                // one 16-byte word per lane: six 21-bit fields {i:9 | j:9 | palette:3}, field 2 r + u = slot lane + 128 u of round r
+                std::vector<uint32_t> words(4 * (size_t)sbk::kLanePackLanes, 0u);
+                for (size_t r = 0; r < prog.size(); ++r) {
+                    int32_t c = 0;
+                    for (const Part &pt : prog[r].parts) {
+                        const uint32_t b = (uint32_t)base[pt.member], b2 = b | (b << 16);
+                        for (int64_t k = pt.first_d; k < pt.first_d + pt.cnt[0]; ++k, ++c) {
+                            const uint32_t idx = G.t_dist[k] + b2, rb = fbits(s->dist_rest[G.t_dist_id[k]]);
+                            const uint32_t pi = (uint32_t)(std::lower_bound(pal.begin(), pal.end(), rb) - pal.begin());
+                            const uint32_t i = idx & 0xffffu, j = idx >> 16;
+                            if (i > 511u || j > 511u || pi > 7u) throw std::runtime_error("internal: lane-packed slot out of range");
+                            const uint64_t f = (uint64_t)(i | (j << 9) | (pi << 18));
+                            const int lane = c % sbk::kLanePackLanes, u = c / sbk::kLanePackLanes;
+                            const int bit = sbk::kLanePackFieldBits * (2 * (int)r + u), w0 = bit >> 5, sh = bit & 31;
+                            uint32_t *wd = &words[4 * (size_t)lane];
+                            wd[w0] |= (uint32_t)(f << sh);
+                            if (sh + sbk::kLanePackFieldBits > 32) wd[w0 + 1] |= (uint32_t)(f >> (32 - sh));
+                        }
+                    }
+                }
+                stream.insert(stream.end(), words.begin(), words.end());
+                td.packed_lanes = (uint32_t)sbk::kLanePackLanes;
+                n_packed_tiles.fetch_add(1, std::memory_order_relaxed);
+            }
+            else for (const PackRound &R : prog) {
                 // a group's data: its distance slots (padded to 4 dwords), then its volume slots, then its bending slots
                 for (const Part &pt : R.parts) {
                     const uint32_t b = (uint32_t)base[pt.member], b2 = b | (b << 16);   // added to both 16-bit local indices
@@ -857,6 +897,7 @@ void build_device(sb_solver *s) {
             }
         }
         D.n_tiles = (int32_t)tiles.size();
+        D.n_packed_tiles = n_packed_tiles.load();
         D.max_local = std::max(max_local, 1);
         D.win_dwords = (int32_t)std::min<uint32_t>(max_data, 8192u);     // <= 32 KiB of LDS; >= one round (4 KiB)
         if (const char *e = std::getenv("SB_WIN_DWORDS")) D.win_dwords = std::max(1024, std::min(D.win_dwords, std::atoi(e)) & ~3);   // tuning experiments
@@ -1122,14 +1163,15 @@ void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = 
     const int n_wg = tile_end - tile_begin;
     const bool small = D.max_local <= sbk::kSmallTile;   // every tile <= 512 particles
     // narrow (2-wave) workgroups once the launch oversubscribes the chip; wide ones while every tile is resident at once
-    const bool narrow = small && (s->tile_lanes ? s->tile_lanes == sbk::kNarrowTileThreads : tile_end - tile_begin >= s->narrow_min_tiles);
+    // (a tiling with lane-packed slots runs 128-lane workgroups in EVERY launch, also the peek's subset of its tiles)
+    const bool narrow = small && (D.packed_lanes ? true : (s->tile_lanes ? s->tile_lanes == sbk::kNarrowTileThreads : tile_end - tile_begin >= s->narrow_min_tiles));
     // tiles with tets / hinges: optionally 8 waves, so that a group's wave slots (16 four-lane constraints or 64 springs each) fit one row
     const bool quad8 = D.has_quads && s->quad_lanes == sbk::kQuadTileThreads;
     // spring-only small tiles on 8 waves (one particle per lane in the load / MARK / store phases; the rounds use half the lanes) while
     // every workgroup of the launch is resident even at that width (4 per compute unit): 64^3 0.1244 -> 0.1213, 48^3 0.1027 -> 0.1005 ms
     // per tick; 96^3 (1 728 tiles) 0.206 -> 0.230, so only launches of at most kWide8MaxTiles (profiles/r03o_lanes512_small_cubes.txt)
     constexpr int kWide8MaxTiles = 768;
-    const bool wide8 = small && !D.has_quads && (s->tile_lanes ? s->tile_lanes == 512 : tile_end - tile_begin <= kWide8MaxTiles);
+    const bool wide8 = small && !D.has_quads && !D.packed_lanes && (s->tile_lanes ? s->tile_lanes == 512 : tile_end - tile_begin <= kWide8MaxTiles);
     const dim3 grid(tile_end - tile_begin), block(quad8 || wide8 ? sbk::kQuadTileThreads : (narrow ? sbk::kNarrowTileThreads : sbk::kWideTileThreads));
 #define SB_LAUNCH_TILE(Q, W, G)                                                                                               \
     do {                                                                                                                      \
@@ -2012,7 +2054,12 @@ int sb_debug_validate(sb_solver *s, int32_t inject_fault, sb_validate_report *ou
                     std::vector<uint32_t> words((size_t)std::max(td.n_rounds, 1));
                     HIP_CHECK(hipMemcpy(words.data(), D.stream.p + td.s_begin, words.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
                     uint32_t off = td.s_hdr;
-                    for (int r = 0; r < td.n_rounds && !planted; ++r) {
+                    if (td.packed_lanes && td.n_rounds > 0 && (words[0] & 1023u) >= 2) {      // lane-packed: lane 0's word over lane 1's
+                        uint32_t *base = s_copy.p + td.s_begin + off;
+                        HIP_CHECK(hipMemcpy(base + 4, base, 4 * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+                        planted = true;
+                    }
+                    for (int r = 0; r < td.n_rounds && !planted && !td.packed_lanes; ++r) {
                         const uint32_t w = words[(size_t)r], cnt = w & 1023u, nq = ((w >> 10) & 1023u) + ((w >> 20) & 1023u);
                         const bool compact = (w >> 30) & 1u;
                         const uint32_t dsize = compact ? ((cnt + 3u) & ~3u) : ((2u * cnt + 3u) & ~3u);
@@ -2387,6 +2434,7 @@ int sb_get_stats(sb_solver *s, sb_stats *out) {
     out->readback_peek_tiles = s->n_peek_tiles;
     out->ticks_fused = s->n_fused;
     out->ticks_fused_kinematic = s->n_kin_fused;
+    for (int tl = 0; tl < 2; ++tl) out->lane_packed_tiles[tl] = s->tiling[tl].n_packed_tiles;
     out->plan_hash = s->plan_hash;
     if (!P.rank_cost.empty()) {
         out->partition_cost = P.rank_cost[(size_t)s->desc.rank];

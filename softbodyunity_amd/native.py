@@ -45,7 +45,7 @@ class SbStats(C.Structure):
                 ("launch_bytes", C.c_int64 * 5), ("partition", C.c_int32), ("halo_peers", C.c_int32),
                 ("partition_cost", C.c_int64), ("partition_cost_max", C.c_int64), ("partition_cost_total", C.c_int64),
                 ("halo_particles_recv", C.c_int64), ("plan_hash", C.c_uint64), ("halo_schedule", C.c_int32),
-                ("halo_unpack_fused", C.c_int32), ("readback_peeks", C.c_int64), ("readback_peek_tiles", C.c_int64), ("ticks_fused", C.c_int64), ("ticks_fused_kinematic", C.c_int64)]
+                ("halo_unpack_fused", C.c_int32), ("readback_peeks", C.c_int64), ("readback_peek_tiles", C.c_int64), ("ticks_fused", C.c_int64), ("ticks_fused_kinematic", C.c_int64), ("lane_packed_tiles", C.c_int64 * 2)]
 
     def as_dict(self):
         out = {}

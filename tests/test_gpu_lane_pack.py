@@ -1,0 +1,86 @@
+"""Lane-packed spring slots (kernels.hip.hpp kLanePack*): where every launch of a tiling runs 128-lane workgroups, a register-resident
+spring tile stores its slots as one 16-byte word per lane (six 21-bit fields) instead of 4 bytes per slot. Same constraints, same
+order, hence the same bits as the oracle; the validator reads the packed form with the kernel's decoding rules. Small meshes are forced
+onto the narrow launch (SB_NARROW_MIN_TILES=1) so that the packed path runs here; the 256^3 / 192^3 / 512^3 tests run it by default."""
+import numpy as np
+import pytest
+
+from helpers import make_oracle
+from softbodyunity_amd import Softbody, jelly_cube
+
+pytestmark = pytest.mark.gpu
+
+
+def _bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def _three_rest_lengths(n):
+    """A lattice whose springs have one rest length per axis (palette of 3: the palette field of the packed slots is used)."""
+    mesh = jelly_cube(n)
+    d = mesh.rest_pos[mesh.dist_ij[:, 1]] - mesh.rest_pos[mesh.dist_ij[:, 0]]
+    axis = np.abs(d).argmax(axis=1)
+    mesh.dist_rest = np.array([1.0, 1.07, 0.94], np.float32)[axis]
+    return mesh
+
+
+CASES = {
+    "cube24": lambda: (jelly_cube(24), dict(substeps=6), True),
+    "cube40_tile128_packs_of_rim_tiles": lambda: (jelly_cube(40), dict(substeps=4, tile_particles=128), True),
+    "cube20_three_rest_lengths_ground": lambda: (_three_rest_lengths(20), dict(substeps=6, ground_plane=(0, 1, 0, -3.0), damping=0.05), True),
+    "cube16_heterogeneous_not_packable": lambda: (jelly_cube(16, heterogeneous=True), dict(substeps=4), False),
+    "cube30_large_tiles_not_packable": lambda: (jelly_cube(30), dict(substeps=4, tile_particles=1000), False),
+}
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_lane_packed_tiles_match_the_oracle_and_validate(case, monkeypatch, oracle_mod):
+    mesh, kw, expect_packed = CASES[case]()
+    monkeypatch.setenv("SB_NARROW_MIN_TILES", "1")
+    monkeypatch.delenv("SB_NO_LANE_PACK", raising=False)
+    sb = Softbody(mesh, **kw).Start()
+    try:
+        st = sb.stats()
+        packed = sum(st["lane_packed_tiles"])
+        assert (packed > 0) == expect_packed, st["lane_packed_tiles"]
+        if expect_packed and "tile128" not in case:
+            assert st["lane_packed_tiles"][0] == st["n_tiles"][0]          # every full T0 tile qualifies
+        okw = {k: v for k, v in kw.items() if k in ("ground_plane", "damping")}
+        o = make_oracle(oracle_mod, mesh, sb.plan(), **okw)
+        for t in range(4):
+            sb.step(); o.step(0.02, kw["substeps"])
+            if t == 1:
+                assert np.array_equal(_bits(sb.get_positions()), _bits(o.x))      # (a read between ticks: flush or peek on the packed tiling)
+        assert np.array_equal(_bits(sb.get_positions()), _bits(o.x)) and np.array_equal(_bits(sb.get_velocities()), _bits(o.v))
+        rep = sb.validate()
+        assert rep["errors"] == [0] * 6 and rep["constraints_checked"] == len(mesh.dist_rest), rep
+        if expect_packed:
+            dup = sb.validate(inject_fault=1)
+            assert dup["errors"][1] >= 1 and dup["first_stage"] == 0, dup
+            assert sb.validate(inject_fault=2)["errors"][2] >= 1
+    finally:
+        sb.OnDestroy()
+
+
+def test_packed_and_unpacked_builds_of_one_mesh_agree_and_the_packed_one_is_smaller(monkeypatch):
+    mesh = jelly_cube(32)
+    monkeypatch.setenv("SB_NARROW_MIN_TILES", "1")
+
+    def run(pack):
+        if pack:
+            monkeypatch.delenv("SB_NO_LANE_PACK", raising=False)
+        else:
+            monkeypatch.setenv("SB_NO_LANE_PACK", "1")
+        sb = Softbody(mesh, substeps=8).Start()
+        try:
+            for _ in range(5):
+                sb.step()
+            return sb.get_positions().copy(), sb.get_velocities().copy(), sb.stats()
+        finally:
+            sb.OnDestroy()
+    xa, va, sa = run(True)
+    xb, vb, sb_ = run(False)
+    assert np.array_equal(_bits(xa), _bits(xb)) and np.array_equal(_bits(va), _bits(vb))
+    assert sum(sa["lane_packed_tiles"]) > 0 and sum(sb_["lane_packed_tiles"]) == 0
+    # 16 bytes per lane against 4 bytes per slot: a full 512-particle tile 2 KiB instead of 3 KiB
+    assert sa["launch_bytes"][0] < sb_["launch_bytes"][0] - 900 * sa["lane_packed_tiles"][0]
