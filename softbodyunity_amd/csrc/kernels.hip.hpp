@@ -44,7 +44,11 @@ constexpr int kInlineRuns = 10;
 // palette index. Stored as ONE 16-byte word per lane -- six 21-bit fields {i:9 | j:9 | palette:3}, field 2 r + u = the lane's slot u of
 // round r (constraint lane + 128 u of that round; beyond the round's count the field is 0) -- the tile's data is 2 KiB instead of 3 KiB
 // (4 bytes per slot), it arrives in the lane's first window load and never touches LDS. build_device decides per tile (solver.hip).
+// A tile whose slots are NOT dictionary-coded (per-spring rest lengths) packs the same way with its rest values behind the index words:
+// [128 x 16 B index word][128 x 16 B: rest of fields 0..3][128 x 8 B: rest of fields 4, 5] = 40 bytes per lane instead of 48
+// (n_pal == 0 marks this form; only in the kernels that read inverse masses as floats, WPAL = false -- the host packs accordingly).
 constexpr int kLanePackLanes = 128, kLanePackRounds = 3, kLanePackFieldBits = 21, kLanePackMaxPalette = 8;
+constexpr uint32_t kLanePackDwordsCompact = 4 * kLanePackLanes, kLanePackDwordsFull = 10 * kLanePackLanes;
 // Wave items (meshes with tets / hinges, 4-wave tiles): the host deals every group's work to the four waves ahead of time --
 // hinges first, then tets (16 four-lane constraints per wave), then springs (64 per wave), boustrophedon over the rows of
 // a group -- and stores for every wave one dword per STEP (= one row of one group): what to project, how many, where the
@@ -582,7 +586,10 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
 #endif
     constexpr int kW = SB_KW;
     const bool lane_packed = !QUADS && kTileThreads == kLanePackLanes && td.packed_lanes == (uint32_t)kLanePackLanes;     // (uniform)
-    const uint32_t n4_first = (min(win_lo + win, d_hi) - win_lo) >> 2;
+    const bool lane_packed_full = !WPAL && lane_packed && td.n_pal == 0;       // per-spring rest lengths behind the index words
+    // (a lane-packed tile never stages its data in LDS, so the tiling's window need not hold it: its loads are not cut at `win`)
+    const uint32_t n4_first = lane_packed ? (lane_packed_full ? 2u * (uint32_t)kLanePackLanes : (uint32_t)kLanePackLanes)
+                                          : (min(win_lo + win, d_hi) - win_lo) >> 2;
     const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(tstream + win_lo);
     u32x4 wv[kW];
 #pragma unroll
@@ -591,6 +598,12 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
         // idle lanes read the first 16 bytes of the tile's stream (its round words: always present and aligned)
         wv[q] = i < n4_first ? wsrc[i] : *reinterpret_cast<const u32x4 *>(tstream);
     }
+    // lane-packed full slots: the rest lengths of the lane's two round-2 slots (8 bytes per lane behind the two 16-byte sweeps); every
+    // other tile re-reads its header here (one address for all lanes)
+    typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
+    u32x2 wc = {0u, 0u};
+    if (!WPAL && !QUADS && kTileThreads == kLanePackLanes)
+        wc = *reinterpret_cast<const u32x2 *>(lane_packed_full ? tstream + win_lo + 8u * (uint32_t)kLanePackLanes + 2u * (uint32_t)tid : tstream);
     // One common use of every loaded value: the scheduler cannot sink a load below it, so all loads are issued
     // first and a single wait follows (left alone it emits load, wait, LDS write, load, wait, ... to save registers).
 #pragma unroll
@@ -602,6 +615,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
     }
 #pragma unroll
     for (int q = 0; q < kW; ++q) asm volatile("" ::"v"(wv[q].x));
+    if (!WPAL && !QUADS && kTileThreads == kLanePackLanes) asm volatile("" ::"v"(wc.x));
     asm volatile("" ::"v"(rw), "v"(palw), "v"(rwl), "v"(itreg));
 #pragma unroll
     for (int m = 0; m < PPT; ++m)
@@ -619,7 +633,8 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
             const uint32_t i = tid + q * kTileThreads;
             if (i < n4_first && !lane_packed) dst[i] = wv[q];      // (lane-packed slots stay in wv[0])
         }
-        for (uint32_t i = tid + kW * kTileThreads; i < n4_first; i += kTileThreads) dst[i] = wsrc[i];
+        if (!lane_packed)
+            for (uint32_t i = tid + kW * kTileThreads; i < n4_first; i += kTileThreads) dst[i] = wsrc[i];
     }
     __syncthreads();   // also covers the staging loads
 #if defined(SB_ABLATE) && SB_ABLATE == 5   // timing experiment only: dispatch + descriptor + every load of the tile, nothing else
@@ -693,7 +708,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
 #else
     constexpr bool kRegFullSlots = true;
 #endif
-    if (kRegRounds > 0 && !QUADS && n_rounds_all <= kRegRounds && n_rounds_all > 0 && (kRegFullSlots || n_pal > 0) && d_hi - d_lo <= win) {
+    if (kRegRounds > 0 && !QUADS && n_rounds_all <= kRegRounds && n_rounds_all > 0 && (kRegFullSlots || n_pal > 0) && (lane_packed || d_hi - d_lo <= win)) {
         const bool tile_compact = n_pal > 0;      // (uniform per tile: build_device codes all of a tile's groups one way)
         uint32_t rs[kRegRounds > 0 ? kRegRounds : 1][kCPL];
         float rl[kRegRounds > 0 ? kRegRounds : 1][kCPL];
@@ -714,6 +729,10 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
                             const uint32_t hi = (sh + kLanePackFieldBits > 32) ? (wv[0][w0 + 1 < 4 ? w0 + 1 : 3] << ((32 - sh) & 31)) : 0u;
                             const uint32_t f = (lo | hi) & ((1u << kLanePackFieldBits) - 1u);
                             rs[r][u] = (f & 511u) | (((f >> 9) & 511u) << 12) | ((f >> 18) << 24);
+                            if (!WPAL) {     // (full slots: the rest length travels beside the index word; compact tiles overwrite rl from the palette below)
+                                const int fld = 2 * r + u;
+                                rl[r][u] = __uint_as_float(fld < 4 ? wv[1][fld < 4 ? fld : 0] : wc[fld >= 4 ? fld - 4 : 0]);
+                            }
                         }
                     } else if (tile_compact) {
 #pragma unroll
@@ -1360,8 +1379,9 @@ __global__ __launch_bounds__(kValidateThreads) void validate_tiles_kernel(const 
     if (size_ok && td.packed_lanes) {
         // lane-packed slots (kLanePack*): one 16-byte word per lane, field 2 r + u = slot lane + 128 u of round r
         const uint32_t P = td.packed_lanes;
-        if (P != (uint32_t)kLanePackLanes || td.n_rounds > kLanePackRounds || td.n_pal <= 0 || td.n_pal > kLanePackMaxPalette || td.n_local > kSmallTile ||
-            td.s_hdr + 4u * P > td.s_len) { if (tid == 0) flag(3, -1); walk_ok = false; }
+        // (n_pal == 0: the full form, rest lengths behind the index words)
+        if (P != (uint32_t)kLanePackLanes || td.n_rounds > kLanePackRounds || td.n_pal < 0 || td.n_pal > kLanePackMaxPalette || td.n_local > kSmallTile ||
+            td.s_hdr + (td.n_pal > 0 ? kLanePackDwordsCompact : kLanePackDwordsFull) > td.s_len) { if (tid == 0) flag(3, -1); walk_ok = false; }
         for (int r = 0; walk_ok && r < td.n_rounds; ++r) {
             const uint32_t w = ts[r];
             const uint32_t cnt = w & 1023u;
@@ -1374,7 +1394,7 @@ __global__ __launch_bounds__(kValidateThreads) void validate_tiles_kernel(const 
                 uint64_t two = (uint64_t)wd[w0] | ((uint64_t)(w0 + 1 < 4 ? wd[w0 + 1] : 0u) << 32);
                 const uint32_t f = (uint32_t)(two >> sh) & ((1u << kLanePackFieldBits) - 1u);
                 const uint32_t p0 = f & 511u, p1 = (f >> 9) & 511u;
-                if ((f >> 18) >= (uint32_t)td.n_pal) flag(0, r);
+                if ((f >> 18) >= (uint32_t)max(td.n_pal, 1)) flag(0, r);
                 for (int e = 0; e < 2; ++e) {
                     const uint32_t p = e ? p1 : p0;
                     if (p >= (uint32_t)td.n_local) flag(0, r);

@@ -757,19 +757,21 @@ void build_device(sb_solver *s) {
                 }
             }
             td.s_hdr = (uint32_t)(stream.size() - s0);
-            bool lane_pack = D.packed_lanes == sbk::kLanePackLanes && compact && (int)pal.size() <= sbk::kLanePackMaxPalette && td.n_local <= sbk::kSmallTile &&
-                             !prog.empty() && (int)prog.size() <= sbk::kLanePackRounds;
+            // (dictionary-coded tiles with a palette of at most 8; tiles with per-spring rest lengths where the kernels read float inverse
+            // masses -- the WPAL = false instantiations carry the loads for that form)
+            bool lane_pack = D.packed_lanes == sbk::kLanePackLanes && (compact ? (int)pal.size() <= sbk::kLanePackMaxPalette : (!s->w_palette && n_dist > 0)) &&
+                             td.n_local <= sbk::kSmallTile && !prog.empty() && (int)prog.size() <= sbk::kLanePackRounds;
             for (const PackRound &R : prog) lane_pack = lane_pack && R.cnt[1] == 0 && R.cnt[2] == 0 && R.cnt[0] <= 2 * sbk::kLanePackLanes;
             if (lane_pack) {
                 // one 16-byte word per lane: six 21-bit fields {i:9 | j:9 | palette:3}, field 2 r + u = slot lane + 128 u of round r
-                std::vector<uint32_t> words(4 * (size_t)sbk::kLanePackLanes, 0u);
+                std::vector<uint32_t> words(compact ? sbk::kLanePackDwordsCompact : sbk::kLanePackDwordsFull, 0u);
                 for (size_t r = 0; r < prog.size(); ++r) {
                     int32_t c = 0;
                     for (const Part &pt : prog[r].parts) {
                         const uint32_t b = (uint32_t)base[pt.member], b2 = b | (b << 16);
                         for (int64_t k = pt.first_d; k < pt.first_d + pt.cnt[0]; ++k, ++c) {
                             const uint32_t idx = G.t_dist[k] + b2, rb = fbits(s->dist_rest[G.t_dist_id[k]]);
-                            const uint32_t pi = (uint32_t)(std::lower_bound(pal.begin(), pal.end(), rb) - pal.begin());
+                            const uint32_t pi = compact ? (uint32_t)(std::lower_bound(pal.begin(), pal.end(), rb) - pal.begin()) : 0u;
                             const uint32_t i = idx & 0xffffu, j = idx >> 16;
                             if (i > 511u || j > 511u || pi > 7u) throw std::runtime_error("internal: lane-packed slot out of range");
                             const uint64_t f = (uint64_t)(i | (j << 9) | (pi << 18));
@@ -778,6 +780,11 @@ void build_device(sb_solver *s) {
                             uint32_t *wd = &words[4 * (size_t)lane];
                             wd[w0] |= (uint32_t)(f << sh);
                             if (sh + sbk::kLanePackFieldBits > 32) wd[w0 + 1] |= (uint32_t)(f >> (32 - sh));
+                            if (!compact) {      // the slot's rest length: fields 0..3 in the second 16-byte sweep, 4 and 5 in the 8-byte one
+                                const int fld = 2 * (int)r + u;
+                                if (fld < 4) words[4 * (size_t)sbk::kLanePackLanes + 4 * (size_t)lane + (size_t)fld] = rb;
+                                else words[8 * (size_t)sbk::kLanePackLanes + 2 * (size_t)lane + (size_t)(fld - 4)] = rb;
+                            }
                         }
                     }
                 }
@@ -816,7 +823,7 @@ void build_device(sb_solver *s) {
                     }
             }
             td.s_len = (uint32_t)(stream.size() - s0);
-            max_data = std::max(max_data, td.s_len - td.s_hdr);
+            if (!td.packed_lanes) max_data = std::max(max_data, td.s_len - td.s_hdr);     // (lane-packed tiles never use the LDS window)
             tiles.push_back(td);
         }
         });

@@ -85,7 +85,7 @@ def test_bench_multi_rank_launch_on_one_gpu_through_the_peer_transport(het):
 
 def test_traffic_file_entries_match_the_compulsory_model_of_a_host_built_plan():
     # profiles/hbm_traffic.json must not go stale: every entry is within 3 % of 49 B per particle + the tile streams
-    # (4 B per dictionary-coded slot -- or 16 B per lane of a 128-lane workgroup where the slots are lane-packed: single-rank spring
+    # (4 B per dictionary-coded slot -- or 16 B (heterogeneous: 40 B) per lane of a 128-lane workgroup where the slots are lane-packed: single-rank spring
     # meshes whose launches are narrow, i.e. at least 10 240 tiles) + 128 B per tile of the plan the host-only planner builds
     import re
     from softbodyunity_amd import native
@@ -106,8 +106,8 @@ def test_traffic_file_entries_match_the_compulsory_model_of_a_host_built_plan():
             tiles = ph["task_end"] - ph["task_begin"]
             # headline layout: 48 B of particle state + ~1 B, 4-byte dictionary-coded slots; heterogeneous layout (bench.py
             # --heterogeneous): + a 4-byte inverse mass per particle, 8-byte slots
-            lane_packed = not het and tiles >= 10240          # kernels.hip.hpp kLanePack*, solver.hip build_device
-            stream = 16.0 * 128 * tiles if lane_packed else (8.0 if het else 4.0) * slots
+            lane_packed = tiles >= 10240                      # kernels.hip.hpp kLanePack*, solver.hip build_device
+            stream = (40.0 if het else 16.0) * 128 * tiles if lane_packed else (8.0 if het else 4.0) * slots
             model = (52.0 if het else 49.0) * mesh.n + stream + 128.0 * tiles
             assert abs(ent[slot] / model - 1) <= 0.03, (key, slot, ent[slot], model)
 
