@@ -95,3 +95,67 @@ def test_packed_and_unpacked_builds_of_one_mesh_agree_and_the_packed_one_is_smal
     assert sum(sa["lane_packed_tiles"]) > 0 and sum(sb_["lane_packed_tiles"]) == 0
     # 16 bytes per lane against 4 bytes per slot: a full 512-particle tile 2 KiB instead of 3 KiB
     assert sa["launch_bytes"][0] < sb_["launch_bytes"][0] - 900 * sa["lane_packed_tiles"][0]
+
+
+def _random_spring_cloud(seed, n, k, rest_levels, uniform_mass):
+    """A jittered cloud with k-nearest-neighbour springs: particle degrees (hence rounds per tile) vary, so that with the narrow launch
+    forced some tiles qualify for lane packing (at most three rounds) and others do not -- both kinds inside ONE launch."""
+    from scipy.spatial import cKDTree
+    from softbodyunity_amd.mesh import SoftbodyMesh
+    rng = np.random.default_rng(seed)
+    side = int(round(n ** (1 / 3)))
+    g = np.stack(np.meshgrid(*[np.arange(side, dtype=np.float64)] * 3, indexing="ij"), -1).reshape(-1, 3)
+    rest = (g + rng.uniform(-0.3, 0.3, g.shape)).astype(np.float32)
+    _, nb = cKDTree(rest).query(rest, k=k + 1)
+    pairs = set()
+    for i in range(len(rest)):
+        for j in nb[i, 1:]:
+            if rng.random() < 0.6:
+                pairs.add((min(i, int(j)), max(i, int(j))))
+    ij = np.array(sorted(pairs), np.int32)
+    L = np.linalg.norm(rest[ij[:, 1]].astype(np.float64) - rest[ij[:, 0]], axis=1)
+    if rest_levels:        # a handful of rest lengths: dictionary-coded tiles (palette <= 8 where a tile sees few of them)
+        L = np.round(L * rest_levels) / rest_levels
+        L[L == 0] = 1.0 / rest_levels
+    w = np.ones(len(rest), np.float32) if uniform_mass else rng.uniform(0.5, 2.0, len(rest)).astype(np.float32)
+    w[rng.random(len(rest)) < 0.02] = 0.0
+    pos = (rest + rng.normal(0, 0.03, rest.shape)).astype(np.float32)
+    return SoftbodyMesh(rest_pos=rest, pos=pos, vel=np.zeros_like(pos), inv_mass=w, dist_ij=ij, dist_rest=L.astype(np.float32))
+
+
+@pytest.mark.parametrize("seed,k,rest_levels,uniform_mass,tile", [(1, 3, 4, True, 64), (2, 4, 6, True, 128), (3, 3, 0, False, 64), (4, 5, 0, False, 256),
+                                                                   (5, 2, 3, False, 128)])
+def test_packed_and_unpacked_tiles_mixed_in_one_launch(seed, k, rest_levels, uniform_mass, tile, monkeypatch, oracle_mod):
+    mesh = _random_spring_cloud(seed, 4000, k, rest_levels, uniform_mass)
+    monkeypatch.setenv("SB_NARROW_MIN_TILES", "1")
+    monkeypatch.delenv("SB_NO_LANE_PACK", raising=False)
+    kw = dict(substeps=5, tile_particles=tile, distance_compliance=1e-6, ground_plane=(0, 1, 0, -1.0), damping=0.1)
+    sb = Softbody(mesh, **kw).Start()
+    try:
+        st = sb.stats()
+        o = make_oracle(oracle_mod, mesh, sb.plan(), damping=0.1, compliance=(1e-6, 0.0, 0.0), ground_plane=kw["ground_plane"])
+        for _ in range(4):
+            sb.step(); o.step(0.02, 5)
+        assert np.array_equal(_bits(sb.get_positions()), _bits(o.x)) and np.array_equal(_bits(sb.get_velocities()), _bits(o.v))
+        rep = sb.validate()
+        assert rep["errors"] == [0] * 6 and rep["constraints_checked"] == len(mesh.dist_rest), rep
+        print(f"seed {seed}: tiles {st['n_tiles']} lane-packed {st['lane_packed_tiles']} T2 layers {st['n_t2_layers']} global colours {st['n_global_colours']}")
+    finally:
+        sb.OnDestroy()
+
+
+def test_the_mixed_cases_really_mix(monkeypatch):
+    # at least one of the clouds above must put packed and unpacked tiles into the same launch (else the test above proves less than it says)
+    monkeypatch.setenv("SB_NARROW_MIN_TILES", "1")
+    monkeypatch.delenv("SB_NO_LANE_PACK", raising=False)
+    mixed = 0
+    for seed, k, rest_levels, uniform_mass, tile in [(4, 5, 0, False, 256), (2, 4, 6, True, 128)]:
+        sb = Softbody(_random_spring_cloud(seed, 4000, k, rest_levels, uniform_mass), substeps=5, tile_particles=tile).Start()
+        try:
+            st = sb.stats()
+            for tl in (0, 1):
+                if 0 < st["lane_packed_tiles"][tl] < st["n_tiles"][tl]:
+                    mixed += 1
+        finally:
+            sb.OnDestroy()
+    assert mixed >= 1
