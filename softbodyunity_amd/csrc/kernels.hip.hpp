@@ -601,9 +601,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
     // lane-packed full slots: the rest lengths of the lane's two round-2 slots (8 bytes per lane behind the two 16-byte sweeps); every
     // other tile re-reads its header here (one address for all lanes)
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
-    u32x2 wc = {0u, 0u};
-    if (!WPAL && !QUADS && kTileThreads == kLanePackLanes)
-        wc = *reinterpret_cast<const u32x2 *>(lane_packed_full ? tstream + win_lo + 8u * (uint32_t)kLanePackLanes + 2u * (uint32_t)tid : tstream);
+    u32x2 wc = {0u, 0u};       // (loaded behind the staging barrier, see there)
     // One common use of every loaded value: the scheduler cannot sink a load below it, so all loads are issued
     // first and a single wait follows (left alone it emits load, wait, LDS write, load, wait, ... to save registers).
 #pragma unroll
@@ -615,7 +613,6 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
     }
 #pragma unroll
     for (int q = 0; q < kW; ++q) asm volatile("" ::"v"(wv[q].x));
-    if (!WPAL && !QUADS && kTileThreads == kLanePackLanes) asm volatile("" ::"v"(wc.x));
     asm volatile("" ::"v"(rw), "v"(palw), "v"(rwl), "v"(itreg));
 #pragma unroll
     for (int m = 0; m < PPT; ++m)
@@ -637,6 +634,10 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
             for (uint32_t i = tid + kW * kTileThreads; i < n4_first; i += kTileThreads) dst[i] = wsrc[i];
     }
     __syncthreads();   // also covers the staging loads
+    // Issued HERE, not with the first batch: at that point every register of the budget (80 at six waves per SIMD) is in flight, and the
+    // two rest lengths are first needed by the tile's THIRD round -- the load's latency hides behind the first two.
+    if (!WPAL && !QUADS && kTileThreads == kLanePackLanes && lane_packed_full)
+        wc = *reinterpret_cast<const u32x2 *>(tstream + win_lo + 8u * (uint32_t)kLanePackLanes + 2u * (uint32_t)tid);
 #if defined(SB_ABLATE) && SB_ABLATE == 5   // timing experiment only: dispatch + descriptor + every load of the tile, nothing else
     if (n_local >= 0) { if (lds_pos[tid].x == 1.2345e-30f && cbuf[tid] == 0x12345678u) A.vel[0] = tp.h; return; }
 #endif
