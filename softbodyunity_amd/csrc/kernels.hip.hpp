@@ -530,7 +530,11 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile
         const uint32_t n4 = (min(lo + win, d_hi) - lo) >> 2;
         const uint4 *src = reinterpret_cast<const uint4 *>(tstream + lo);
         uint4 *dst = reinterpret_cast<uint4 *>(cbuf);
-        for (uint32_t i = tid; i < n4; i += 4 * kTileThreads) {
+        // (the lane's index is laundered: left alone, the compiler hoists the per-lane source address out of the rounds loop and
+        // holds it in two registers for the whole kernel -- in the 80-register kernels that was a spill to scratch; refills are rare)
+        uint32_t t0 = (uint32_t)tid;
+        asm volatile("" : "+v"(t0));
+        for (uint32_t i = t0; i < n4; i += 4 * kTileThreads) {
             uint4 v0 = src[i], v1, v2, v3;
             const bool b1 = i + kTileThreads < n4, b2 = i + 2 * kTileThreads < n4, b3 = i + 3 * kTileThreads < n4;
             if (b1) v1 = src[i + kTileThreads];
