@@ -446,7 +446,9 @@ __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(
 template <bool QUADS, int THREADS> constexpr int kWavesPerSimd = QUADS ? (THREADS == 64 ? 3 : (THREADS == 512 ? 2 : 4)) : (THREADS == 256 ? 8 : (THREADS == 128 ? 6 : 4));   // 128 lanes: 7 waves (72 VGPRs) measured 1 % slower, 8 spill
 // WPAL = inverse masses are read as one-byte palette indices (the palette entry comes from another lane by ds_bpermute).
 template <int KIND_, bool QUADS, int THREADS, int PPT, bool WPAL, int HALO = kHaloNone>
-__global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS>)) void tile_kernel(const TileDesc *tiles_at_base, int n_workgroups, TileArgs A) {
+// (KIND 5 -- one launch per tick, and only when kinematic targets are pending -- gets one wave per SIMD less: its MARK step holds more
+// live values, and under the ordinary bound it spilled 4 .. 14 registers)
+__global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS> - (KIND_ == 5 && !QUADS ? 1 : 0))) void tile_kernel(const TileDesc *tiles_at_base, int n_workgroups, TileArgs A) {
     // KIND 5 = KIND 1 whose MARK step also applies pending kinematic targets (see TileArgs::kin_map): an instantiation of its own, so the
     // ordinary mid-tick kernel carries nothing of it
     constexpr int KIND = KIND_ == 5 ? 1 : KIND_;
