@@ -1,4 +1,4 @@
-// SoftbodyNative.cs — P/Invoke layer over libsoftbody_mi355x.so (include/softbody.h, ABI version 7).
+// SoftbodyNative.cs — P/Invoke layer over libsoftbody_mi355x.so (include/softbody.h + softbody_group.h / softbody_plan.h / softbody_debug.h, ABI version 8).
 //
 // One [DllImport] per exported function, same name and argument order as the header; the Python twin
 // used by the test-suite is softbodyunity_amd/native.py (tests/test_abi.py keeps the three in sync).
@@ -94,6 +94,22 @@ namespace SoftbodyMI355X
         public int fourVertexConstraints, reserved;
     }
 
+    // include/softbody_debug.h: A/B measurement switches (a product host never sets them) and exchange timing
+    [StructLayout(LayoutKind.Sequential)]
+    public struct SbTuning
+    {
+        public uint flags;           // SoftbodyNative.Tune*
+        public int tileLanes, quadLanes, narrowMinTiles, storeThroughMaxTiles, storeThroughLarge, peekMinTiles, ldsPadBytes, winDwords;
+        public int reserved0, reserved1, reserved2, reserved3, reserved4, reserved5, reserved6;
+    }
+
+    [StructLayout(LayoutKind.Sequential)]
+    public struct SbExchangeTiming
+    {
+        public long exchanges;
+        public double packMs, transportMs, totalMs, exposedWaitMs;
+    }
+
     [StructLayout(LayoutKind.Sequential)]
     public struct SbPhaseInfo
     {
@@ -111,6 +127,7 @@ namespace SoftbodyMI355X
         public static uint PlanBalancedLists(int n) => (uint)n << 8;   // irregular meshes: 1..3 balanced extra lists; 0 = default (2)
         public const int TransportRccl = 0, TransportPeer = 1;
         public const int ScheduleAuto = 0, ScheduleSerialEager = 1, ScheduleSerialGraph = 2, ScheduleOverlapEager = 3, ScheduleOverlapGraph = 4;
+        public const uint GroupWalk = 1;       // sb_group_create flags: no plugin threads, the calling thread walks the tick across the ranks
 
         [DllImport(Lib, CallingConvention = CC)] public static extern void sb_desc_default(ref SbDesc d);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_create(ref SbDesc desc, out IntPtr solver);
@@ -131,7 +148,7 @@ namespace SoftbodyMI355X
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_get_positions(IntPtr s, IntPtr posXyzOut, int n);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_get_velocities(IntPtr s, IntPtr velXyzOut, int n);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_state(IntPtr s, IntPtr posXyz, IntPtr velXyz, int n);
-        // kinematic particles (attachments): move particles with inverse mass 0 between two ticks (SPEC.md 2); world == 1
+        // kinematic particles (attachments): move particles with inverse mass 0 between two ticks (SPEC.md 2); a rank applies the ones it owns
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_kinematic_positions(IntPtr s, IntPtr ids, IntPtr posXyz, int count);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_readback_begin(IntPtr s);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_readback_end(IntPtr s, out IntPtr posXyz);
@@ -173,6 +190,36 @@ namespace SoftbodyMI355X
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_halo(IntPtr plan, int slot, int peer, IntPtr sendIds, IntPtr recvIds);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_pair_hashes(IntPtr plan, IntPtr outPerRank);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_plan_get_local_order_mask(IntPtr plan, int parity, IntPtr maskOut);
+        // ---- one process, several GPUs (include/softbody_group.h): what Softbody.cs calls when deviceCount > 1 ----
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_create(ref SbDesc desc, int[] devices, int nDevices, uint flags, out IntPtr group);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_destroy(IntPtr g);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_set_particles(IntPtr g, IntPtr posXyz, IntPtr velXyz, IntPtr invMass, int n);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_set_rest_positions(IntPtr g, IntPtr restXyz, int n);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_set_distance_constraints(IntPtr g, IntPtr ij, IntPtr restLen, int m, float compliance);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_set_volume_constraints(IntPtr g, IntPtr ijkl, IntPtr restVol, int m, float compliance);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_set_bending_constraints(IntPtr g, IntPtr ijkl, IntPtr restCosSin, int m, float compliance);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_set_ground_plane(IntPtr g, float nx, float ny, float nz, float d, int enabled);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_finalize(IntPtr g);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_step(IntPtr g, float dt, int substeps);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_get_positions(IntPtr g, IntPtr posXyzOut, int n);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_get_velocities(IntPtr g, IntPtr velXyzOut, int n);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_set_state(IntPtr g, IntPtr posXyz, IntPtr velXyz, int n);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_set_kinematic_positions(IntPtr g, IntPtr ids, IntPtr posXyz, int count);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_set_render_triangles(IntPtr g, int[] triAbc, int m);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_set_readback_render_set_only(IntPtr g, int renderSetOnly);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_readback_begin(IntPtr g);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_readback_end(IntPtr g, out IntPtr posXyz);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_readback_get_normals(IntPtr g, out IntPtr normalXyz);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_readback_get_render_set(IntPtr g, out IntPtr ids, out int count);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_synchronize(IntPtr g);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_rank_count(IntPtr g);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_group_get_rank(IntPtr g, int rank, out IntPtr solver);
+        // ---- include/softbody_debug.h: measurement harnesses only ----
+        [DllImport(Lib, CallingConvention = CC)] public static extern void sb_tuning_default(ref SbTuning t);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_set_tuning(IntPtr s, ref SbTuning t);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_debug_exchange_timing(IntPtr s, int enabled);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_debug_exchange_timing_read(IntPtr s, out SbExchangeTiming t);
+        [DllImport(Lib, CallingConvention = CC)] public static extern int sb_debug_last_words(int fd, byte[] text, long len, int exitCode);
         [DllImport(Lib, CallingConvention = CC)] public static extern IntPtr sb_last_error();
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_abi_version();
 

@@ -20,6 +20,11 @@
  *    sb_get_*. There is NO CPU fallback: without a usable gfx950 device sb_create fails with
  *    SB_ERR_NO_DEVICE.
  *  - Semantics of one tick: SPEC.md.
+ *
+ * This header is the whole PRODUCT surface of a solver handle (32 functions). Beside it:
+ *   softbody_group.h  one process -- a Unity player -- driving several GPUs behind the same component (sb_group_*)
+ *   softbody_plan.h   host-only planner inspection (published order, tiles, halo lists; frame / window of sharded authoring)
+ *   softbody_debug.h  test hooks, the table validator, per-launch timing and the tuning switches of A/B measurements
  */
 #ifndef SOFTBODY_MI355X_H
 #define SOFTBODY_MI355X_H
@@ -30,7 +35,7 @@
 extern "C" {
 #endif
 
-#define SB_ABI_VERSION 7
+#define SB_ABI_VERSION 8
 
 typedef enum {
     SB_OK = 0,
@@ -44,7 +49,6 @@ typedef enum {
 } sb_status;
 
 typedef struct sb_solver sb_solver; /* opaque, plugin-owned */
-typedef struct sb_plan sb_plan;     /* opaque, plugin-owned */
 
 /* Spatial partition of a world > 1 solver (which rank owns which particles). Ownership is always by whole T0 cells. */
 #define SB_PARTITION_AUTO   0   /* block grid when it balances the ranks within 10 % (regular meshes), else RCB */
@@ -65,17 +69,14 @@ typedef struct sb_plan sb_plan;     /* opaque, plugin-owned */
 /* Ghost exchange of a world > 1 solver. */
 #define SB_TRANSPORT_RCCL 0            /* pack -> grouped ncclSend/ncclRecv -> unpack (default) */
 #define SB_TRANSPORT_PEER 1            /* peer-store mailboxes (opt-in; see sb_peer_connect) */
-#define SB_SCHEDULE_AUTO               0   /* an eager schedule (nothing is asked of the bound RCCL / HIP runtime beyond plain send/recv, see
-                                              sb_runtime_info): SB_SCHEDULE_OVERLAP_EAGER when the largest per-peer message of the exchange is
-                                              1 MiB or more (link-bound between devices), else SB_SCHEDULE_SERIAL_EAGER; sb_stats.halo_schedule */
+#define SB_SCHEDULE_AUTO               0   /* = SB_SCHEDULE_SERIAL_EAGER on every rank: nothing is asked of the bound RCCL / HIP runtime beyond plain
+                                              send/recv (sb_runtime_info), and it is the fastest eager schedule measured so far (one-device loopback
+                                              shares); the overlapped and captured schedules are opt-in until measured between devices
+                                              (bench.py --gpus N times every admitted one: config.schedule_ab) */
 #define SB_SCHEDULE_SERIAL_EAGER       1
 #define SB_SCHEDULE_SERIAL_GRAPH       2   /* the tick, exchange included, captured in a hipGraph */
 #define SB_SCHEDULE_OVERLAP_EAGER      3   /* exchange on a second stream beside the interior tiles */
 #define SB_SCHEDULE_OVERLAP_GRAPH      4   /* refused (SB_ERR_UNSUPPORTED) on a HIP runtime it is known to fault on */
-
-/* Test-only behaviour; a product host leaves this 0. */
-#define SB_DEBUG_NO_COMM  1u           /* world > 1 without any transport: the host carries the halo through sb_debug_* */
-#define SB_DEBUG_LOOPBACK 2u           /* every peer is this rank itself (size-1 communicator): one-GPU pipeline tests */
 
 /* Mirrors the [SerializeField] block of csharp/Softbody.cs. Zero-initialise (or sb_desc_default), then set fields. */
 typedef struct {
@@ -93,7 +94,7 @@ typedef struct {
     uint32_t plan_flags;     /* SB_PLAN_* */
     int32_t halo_transport;  /* SB_TRANSPORT_* */
     int32_t halo_schedule;   /* SB_SCHEDULE_* */
-    uint32_t debug_flags;    /* SB_DEBUG_* */
+    uint32_t debug_flags;    /* SB_DEBUG_* of softbody_debug.h (test-only behaviour); a product host leaves this 0 */
     int32_t reserved[3];     /* must be 0 */
 } sb_desc;
 
@@ -212,42 +213,9 @@ int sb_set_readback_render_set_only(sb_solver *s, int32_t render_set_only);
 int sb_readback_get_render_set(sb_solver *s, const int32_t **ids_out, int32_t *count_out);
 int sb_get_owner(sb_solver *s, int32_t *owner_rank_out, int32_t n);
 
-/* ---- measurement ----------------------------------------------------------------------------- */
-/* HIP-event timing on the solver's own stream (torch.cuda.Event cannot see it). */
-int sb_profile_begin(sb_solver *s);
-int sb_profile_end(sb_solver *s, float *elapsed_ms_out);
+
+/* ---- synchronisation, statistics ----------------------------------------------------------------- */
 int sb_synchronize(sb_solver *s);
-/* One tick launched eagerly with a HIP-event pair around every kernel launch on the solver's stream.
- * Slots: 0 / 1 = mid-tick tile kernels on tiling T0 / T1 (rounds + velocity/integrate + rounds),
- * 2+c = global colour c, 2+G = the first kernel of the tick, 3+G = the last, 4+G = the kernels of the T2 layers
- * (G = n_global_colours). n_slots must be 5 + n_global_colours (sb_get_stats). Same results as sb_step. */
-int sb_step_profiled(sb_solver *s, float dt, int32_t substeps, float *slot_ms_out, int32_t *slot_launches_out,
-                     int32_t n_slots);
-/* Test hooks (used by tests/test_gpu_multirank.py to check the multi-rank device path on a box with one
- * GPU, where RCCL cannot form a communicator): run ONE launch of a tick — tile kernel K_it (gcolour = -1),
- * global colour `gcolour` of the substep that K_it started, or T2 layer l of that substep (gcolour = -2 - l) — without any ghost exchange, and move one
- * halo slot's send / receive buffer through host memory. Buffer layout = what goes over the wire: peers in
- * increasing rank order, each peer's particles back to back, 3 floats (position) per particle, slot 1: 6 floats
- * (position, previous position). */
-int sb_debug_launch(sb_solver *s, float dt, int32_t substeps, int32_t it, int32_t gcolour);
-int sb_debug_halo_pack(sb_solver *s, int32_t slot, float *host_out, int64_t capacity_floats, int64_t *count_floats_out);
-int sb_debug_halo_unpack(sb_solver *s, int32_t slot, const float *host_in, int64_t count_floats);
-/* Table validator (debug; the "race detector" of this design): the only race the tile kernels can have is two constraints of one
- * group -- or two tiles of one launch -- touching the same particle. A GPU kernel re-reads everything the tile kernels read (the
- * uploaded descriptors, run tables / particle lists, group words, 4- and 8-byte spring slots, four-vertex slots, wave items: after
- * packing, lane dealing and cost ordering) with their own decoding rules and counts violations; the global colours likewise.
- * inject_fault != 0 runs the same check on a COPY of tiling T0's tables with one fault planted (1: a slot copied over its
- * neighbour = a particle twice in one group; 2: a descriptor copied over its neighbour = a particle staged by two tiles), so a host
- * can see the detector detect. The solver's own tables are never modified. Returns SB_OK when the check RAN; look at errors[]. */
-typedef struct {
-    int64_t tiles_checked, groups_checked, constraints_checked;
-    /* 0 index out of range, 1 a particle twice in one group (or one global colour), 2 a particle staged by two tiles of one launch,
-     * 3 a group's data leaves the tile's stream, 4 malformed run table / particle list, 5 wave items disagree with the group words */
-    int64_t errors[6];
-    int32_t first_stage;                            /* -1 none; 0 / 1 = tiling T0 / T1, 2 = a T2 layer, 3 = a global colour */
-    int32_t first_tile, first_group, first_kind;    /* device tile index of that tiling (global colour: -2 - its number), group (colour: constraint), errors[] index */
-} sb_validate_report;
-int sb_debug_validate(sb_solver *s, int32_t inject_fault, sb_validate_report *out);
 typedef struct {
     int64_t n_particles_owned, n_particles_local;   /* local = owned + ghost */
     int64_t n_constraints_local[3];                 /* distance, volume, bending (incl. redundant cut copies) */
@@ -287,76 +255,6 @@ typedef struct {
 } sb_stats;
 int sb_get_stats(sb_solver *s, sb_stats *out);
 
-/* ---- plan inspection (pure host code; works without a GPU) ------------------------------------ */
-/* The planner (SPEC.md §3) publishes one sequential constraint order per substep parity (0,1,0,1,...
- * restarting at 0 every tick). parity arguments below are 0 or 1. */
-typedef struct {
-    int32_t rank, world;
-    int32_t part_dims[3];
-    int32_t tile_particles;  /* as sb_desc.tile_particles (0 = automatic by the same rule); opts == NULL: all fields 0 */
-    int32_t partition;       /* SB_PARTITION_* */
-    uint32_t plan_flags;     /* SB_PLAN_* */
-    const sb_domain *domain;    /* NULL = the input is the whole mesh; else the input is this rank's window of it ... */
-    const int32_t *global_id;   /* ... and these are its particles' ids in the whole mesh, strictly ascending (n of them) */
-} sb_plan_opts;
-/* The frame of a whole mesh, measured exactly as a whole-mesh plan measures it (a lattice generator can also fill sb_domain in
- * closed form: lo / hi = the lattice's corners, spacing = the spring length). */
-int sb_domain_from_mesh(const float *rest_xyz, int32_t n, const int32_t *dist_ij, int32_t m_d, const int32_t *vol_ijkl, int32_t m_v,
-                        const int32_t *bend_ijkl, int32_t m_b, sb_domain *out);
-/* The box (rest coordinates, lo inclusive, hi exclusive; +-1e300 where the window reaches the rim of the grid) whose particles rank
- * opts->rank must hand over. Only rank, world, part_dims and tile_particles of opts are read. */
-int sb_domain_window(const sb_domain *domain, const sb_plan_opts *opts, double lo_out[3], double hi_out[3]);
-typedef struct {
-    int32_t kind;               /* 0 = global colour, 1 = a tiling's tiles, first phase of the substep, 2 = the other tiling's tiles,
-                                   last phase, 3 = the sparse tiles of one T2 layer (after kind 1, before the global colours) */
-    int32_t type;               /* kind 0: constraint type 0/1/2; else -1 */
-    int32_t tiling;             /* kind 1/2: 0 or 1; kind 0: -1 */
-    int32_t halo_slot;          /* -1 none; 1 = before the T1 tile kernel; 2+c = before global colour c;
-                                   2+G+l = before the kernel of T2 layer l (G = number of global colours) */
-    int64_t order_begin, order_end; /* slice of the parity's published order */
-    int64_t task_begin, task_end;   /* slice of the task table: tasks of one phase touch disjoint particles */
-} sb_phase_info;
-
-int sb_plan_build(const float *rest_xyz, int32_t n,
-                  const int32_t *dist_ij, int32_t m_d,
-                  const int32_t *vol_ijkl, int32_t m_v,
-                  const int32_t *bend_ijkl, int32_t m_b,
-                  const sb_plan_opts *opts, sb_plan **out);
-int sb_plan_destroy(sb_plan *p);
-/* Borrowed view of a finalized solver's plan (valid until sb_destroy). */
-int sb_get_plan(sb_solver *s, const sb_plan **out);
-
-int64_t sb_plan_order_count(const sb_plan *p);
-/* The published sequential order (SPEC.md §3): type 0/1/2 + index into that type's input arrays. */
-int sb_plan_get_order(const sb_plan *p, int32_t parity, uint8_t *type_out, int32_t *id_out);
-int32_t sb_plan_phase_count(const sb_plan *p, int32_t parity);
-int sb_plan_get_phases(const sb_plan *p, int32_t parity, sb_phase_info *out);
-int64_t sb_plan_task_count(const sb_plan *p, int32_t parity);
-int sb_plan_get_tasks(const sb_plan *p, int32_t parity, int64_t *task_off_out /* task_count+1 */);
-/* Finest independent sets (one round of one tile / one chunk of a global colour): constraints of one
- * group share no particle; the GPU runs a group's constraints concurrently. */
-int64_t sb_plan_group_count(const sb_plan *p, int32_t parity);
-int sb_plan_get_groups(const sb_plan *p, int32_t parity, int64_t *group_off_out /* group_count+1 */);
-int sb_plan_get_owner(const sb_plan *p, int32_t *owner_rank_out /* n */);
-/* Per-rank view: particles this rank keeps (owned first, then ghosts), in device order. */
-int64_t sb_plan_local_count(const sb_plan *p, int64_t *owned_out);
-int sb_plan_get_local_particles(const sb_plan *p, int32_t *global_id_out);
-/* Halo schedule of this rank for halo slot `slot` (sb_phase_info.halo_slot): for every peer, which of its
- * own particles it sends and which ghosts it receives (caller particle ids, identical order on both
- * sides). Slot 1 carries positions and previous positions, slots >= 2 positions only. */
-int32_t sb_plan_halo_slot_count(const sb_plan *p);
-int sb_plan_halo_counts(const sb_plan *p, int32_t slot, int32_t *send_count_per_rank /* world */,
-                        int32_t *recv_count_per_rank /* world */);
-int sb_plan_get_halo(const sb_plan *p, int32_t slot, int32_t peer, int32_t *send_ids, int32_t *recv_ids);
-/* Per peer rank: a hash of everything this rank and that peer must agree on -- the ghost lists between them (whole-mesh particle
- * ids, both directions, every slot) and the programs of the tiles both run (constraint sequences as whole-mesh particle ids).
- * Symmetric: rank a's entry for b equals rank b's entry for a exactly when the two planned consistently; sb_finalize (RCCL) and the
- * peer transport's link step compare them. out_per_rank: world entries, the own rank's is 0. */
-int sb_plan_get_pair_hashes(const sb_plan *p, uint64_t *out_per_rank);
-/* Which order entries this rank executes (1) or skips (0) — cut constraints run on every rank that owns
- * one of their particles. */
-int sb_plan_get_local_order_mask(const sb_plan *p, int32_t parity, uint8_t *mask_out);
-
 /* ---- what the plugin is running on -------------------------------------------------------------------- */
 /* The plugin links the HIP runtime and loads RCCL on first use (sb_comm_unique_id / sb_comm_init / this call) with dlopen: the
  * librccl.so.1 ALREADY IN THE PROCESS when there is one (a host that imported PyTorch first brings PyTorch's own RCCL and HIP
@@ -385,3 +283,4 @@ int sb_abi_version(void);
 }
 #endif
 #endif /* SOFTBODY_MI355X_H */
+

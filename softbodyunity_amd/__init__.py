@@ -6,4 +6,4 @@ generators (mesh.py). The CPU oracle lives in /oracle and is never imported from
 """
 from .mesh import (SoftbodyMesh, bunny_surrogate, from_tet_mesh, from_triangle_mesh, jelly_cube,  # noqa: F401
                    read_gmsh, read_tetgen)
-from .softbody import Softbody, comm_unique_id  # noqa: F401
+from .softbody import Softbody, SoftbodyGroup, comm_unique_id  # noqa: F401

@@ -23,6 +23,11 @@ SB_PLAN_NO_T2, SB_PLAN_NO_THIRD_LIST, SB_PLAN_NO_CLUSTER_LAYERS, SB_PLAN_NO_MIXE
 SB_TRANSPORT_RCCL, SB_TRANSPORT_PEER = 0, 1
 SB_SCHEDULE_AUTO, SB_SCHEDULE_SERIAL_EAGER, SB_SCHEDULE_SERIAL_GRAPH, SB_SCHEDULE_OVERLAP_EAGER, SB_SCHEDULE_OVERLAP_GRAPH = 0, 1, 2, 3, 4
 SB_DEBUG_NO_COMM, SB_DEBUG_LOOPBACK = 1, 2
+SB_GROUP_WALK = 1
+# sb_tuning.flags (include/softbody_debug.h): A/B measurement switches, same bits for every setting
+(SB_TUNE_NO_MASS_PALETTE, SB_TUNE_NO_UNIFORM_MASS, SB_TUNE_NO_PALETTE, SB_TUNE_NO_WAVE_ITEMS, SB_TUNE_NO_LANE_PACK, SB_TUNE_NO_COST_ORDER,
+ SB_TUNE_NO_FUSED_UNPACK, SB_TUNE_PEER_COARSE, SB_TUNE_NO_LAZY_TICK, SB_TUNE_NO_PACK, SB_TUNE_NO_PEEK, SB_TUNE_NO_KIN_FUSE,
+ SB_TUNE_NO_WIDE_SLOTS) = (1 << k for k in range(13))
 SB_ERR_INVALID_ARG, SB_ERR_STATE, SB_ERR_NO_DEVICE, SB_ERR_HIP, SB_ERR_RCCL, SB_ERR_NOMEM, SB_ERR_UNSUPPORTED = \
     -1, -2, -3, -4, -5, -6, -7
 
@@ -33,6 +38,16 @@ class SbDesc(C.Structure):
                 ("use_graph", C.c_int32), ("partition", C.c_int32), ("plan_flags", C.c_uint32),
                 ("halo_transport", C.c_int32), ("halo_schedule", C.c_int32), ("debug_flags", C.c_uint32),
                 ("reserved", C.c_int32 * 3)]
+
+
+class SbTuning(C.Structure):
+    _fields_ = [("flags", C.c_uint32), ("tile_lanes", C.c_int32), ("quad_lanes", C.c_int32), ("narrow_min_tiles", C.c_int32),
+                ("store_through_max_tiles", C.c_int32), ("store_through_large", C.c_int32), ("peek_min_tiles", C.c_int32),
+                ("lds_pad_bytes", C.c_int32), ("win_dwords", C.c_int32), ("reserved", C.c_int32 * 7)]
+
+
+class SbExchangeTiming(C.Structure):
+    _fields_ = [("exchanges", C.c_int64), ("pack_ms", C.c_double), ("transport_ms", C.c_double), ("total_ms", C.c_double), ("exposed_wait_ms", C.c_double)]
 
 
 class SbStats(C.Structure):
@@ -144,6 +159,35 @@ SIGNATURES = {
     "sb_plan_get_pair_hashes": (C.c_int, [_P, _P]),
     "sb_plan_get_local_order_mask": (C.c_int, [_P, C.c_int32, _P]),
     "sb_runtime_info": (C.c_int, [C.POINTER(SbRuntimeInfo)]),
+    "sb_tuning_default": (None, [C.POINTER(SbTuning)]),
+    "sb_set_tuning": (C.c_int, [_P, C.POINTER(SbTuning)]),
+    "sb_debug_exchange_timing": (C.c_int, [_P, C.c_int32]),
+    "sb_debug_exchange_timing_read": (C.c_int, [_P, C.POINTER(SbExchangeTiming)]),
+    "sb_debug_last_words": (C.c_int, [C.c_int32, C.c_char_p, C.c_int64, C.c_int32]),
+    # one process driving several devices (include/softbody_group.h)
+    "sb_group_create": (C.c_int, [C.POINTER(SbDesc), _P, C.c_int32, C.c_uint32, C.POINTER(_P)]),
+    "sb_group_destroy": (C.c_int, [_P]),
+    "sb_group_set_particles": (C.c_int, [_P, _P, _P, _P, C.c_int32]),
+    "sb_group_set_rest_positions": (C.c_int, [_P, _P, C.c_int32]),
+    "sb_group_set_distance_constraints": (C.c_int, [_P, _P, _P, C.c_int32, C.c_float]),
+    "sb_group_set_volume_constraints": (C.c_int, [_P, _P, _P, C.c_int32, C.c_float]),
+    "sb_group_set_bending_constraints": (C.c_int, [_P, _P, _P, C.c_int32, C.c_float]),
+    "sb_group_set_ground_plane": (C.c_int, [_P, C.c_float, C.c_float, C.c_float, C.c_float, C.c_int32]),
+    "sb_group_finalize": (C.c_int, [_P]),
+    "sb_group_step": (C.c_int, [_P, C.c_float, C.c_int32]),
+    "sb_group_get_positions": (C.c_int, [_P, _P, C.c_int32]),
+    "sb_group_get_velocities": (C.c_int, [_P, _P, C.c_int32]),
+    "sb_group_set_state": (C.c_int, [_P, _P, _P, C.c_int32]),
+    "sb_group_set_kinematic_positions": (C.c_int, [_P, _P, _P, C.c_int32]),
+    "sb_group_set_render_triangles": (C.c_int, [_P, C.POINTER(C.c_int32), C.c_int32]),
+    "sb_group_set_readback_render_set_only": (C.c_int, [_P, C.c_int32]),
+    "sb_group_readback_begin": (C.c_int, [_P]),
+    "sb_group_readback_end": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_float))]),
+    "sb_group_readback_get_normals": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_float))]),
+    "sb_group_readback_get_render_set": (C.c_int, [_P, C.POINTER(C.POINTER(C.c_int32)), C.POINTER(C.c_int32)]),
+    "sb_group_synchronize": (C.c_int, [_P]),
+    "sb_group_rank_count": (C.c_int32, [_P]),
+    "sb_group_get_rank": (C.c_int, [_P, C.c_int32, C.POINTER(_P)]),
     "sb_last_error": (C.c_char_p, []),
     "sb_abi_version": (C.c_int, []),
 }
@@ -218,6 +262,32 @@ def halo_schedule_from_env():
 
 def debug_flags_from_env():
     return (SB_DEBUG_NO_COMM if os.environ.get("SB_TEST_NO_COMM") else 0) | (SB_DEBUG_LOOPBACK if os.environ.get("SB_TEST_LOOPBACK") else 0)
+
+
+# tuning switches (sb_tuning): the SB_* names the A/B scripts of tools/ have always used; the plugin itself reads no environment variable
+_TUNE_FLAG_ENV = (("SB_NO_MASS_PALETTE", SB_TUNE_NO_MASS_PALETTE), ("SB_NO_UNIFORM_MASS", SB_TUNE_NO_UNIFORM_MASS), ("SB_NO_PALETTE", SB_TUNE_NO_PALETTE),
+                  ("SB_NO_WAVE_ITEMS", SB_TUNE_NO_WAVE_ITEMS), ("SB_NO_LANE_PACK", SB_TUNE_NO_LANE_PACK), ("SB_NO_COST_ORDER", SB_TUNE_NO_COST_ORDER),
+                  ("SB_NO_FUSED_UNPACK", SB_TUNE_NO_FUSED_UNPACK), ("SB_PEER_COARSE", SB_TUNE_PEER_COARSE), ("SB_NO_LAZY_TICK", SB_TUNE_NO_LAZY_TICK),
+                  ("SB_NO_PACK", SB_TUNE_NO_PACK), ("SB_NO_PEEK", SB_TUNE_NO_PEEK), ("SB_NO_KIN_FUSE", SB_TUNE_NO_KIN_FUSE),
+                  ("SB_NO_WIDE_SLOTS", SB_TUNE_NO_WIDE_SLOTS))
+_TUNE_INT_ENV = (("SB_TILE_LANES", "tile_lanes"), ("SB_QUAD_LANES", "quad_lanes"), ("SB_NARROW_MIN_TILES", "narrow_min_tiles"),
+                 ("SB_STORE_THROUGH_MAX_TILES", "store_through_max_tiles"), ("SB_STORE_THROUGH_LARGE", "store_through_large"),
+                 ("SB_PEEK_MIN_TILES", "peek_min_tiles"), ("SB_LDS_PAD", "lds_pad_bytes"), ("SB_WIN_DWORDS", "win_dwords"))
+
+
+def tuning_from_env():
+    """sb_tuning filled from the harness' SB_* environment switches, or None when none of them is set (sb_set_tuning is then not called)."""
+    t = SbTuning()
+    lib().sb_tuning_default(C.byref(t))
+    any_set = False
+    for name, bit in _TUNE_FLAG_ENV:
+        if os.environ.get(name):
+            t.flags |= bit; any_set = True
+    for name, field in _TUNE_INT_ENV:
+        v = os.environ.get(name)
+        if v not in (None, ""):
+            setattr(t, field, int(v)); any_set = True
+    return t if any_set else None
 
 
 def runtime_info():

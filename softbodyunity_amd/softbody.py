@@ -19,7 +19,7 @@ class Softbody:
     def __init__(self, mesh, substeps=20, fixed_delta_time=0.02, gravity=(0.0, -9.81, 0.0), damping=0.0,
                  distance_compliance=0.0, volume_compliance=0.0, bending_compliance=0.0, device=0, rank=0, world=1,
                  part_dims=(0, 0, 0), tile_particles=0, use_graph=True, unique_id=None, ground_plane=None, use_gpu=True,
-                 partition=native.SB_PARTITION_AUTO, plan_flags=None, halo_transport=None, halo_schedule=None, debug_flags=None):
+                 partition=native.SB_PARTITION_AUTO, plan_flags=None, halo_transport=None, halo_schedule=None, debug_flags=None, tuning=None):
         self.mesh = mesh
         self.substeps = int(substeps)
         self.fixed_delta_time = float(fixed_delta_time)
@@ -38,6 +38,7 @@ class Softbody:
         self.halo_schedule = native.halo_schedule_from_env() if halo_schedule is None else int(halo_schedule)
         self.debug_flags = native.debug_flags_from_env() if debug_flags is None else int(debug_flags)
         self.unique_id = unique_id
+        self.tuning = tuning               # native.SbTuning or None = from the harness' SB_* environment switches (A/B runs)
         self.ground_plane = ground_plane   # None or (nx, ny, nz, d): n.x >= d
         # use_gpu=False mirrors the C# component's CPU branch (csharp/Softbody.cs): no solver handle, no device; Start()
         # only fetches the schedule from the host-only planner. The CPU tick itself is C# (SoftbodyCpuSolver.cs); this
@@ -73,6 +74,9 @@ class Softbody:
         check(L.sb_create(C.byref(d), C.byref(h)))
         self._h = h
         try:
+            tune = native.tuning_from_env() if self.tuning is None else self.tuning
+            if tune is not None:      # A/B measurement switches (include/softbody_debug.h); a product host never calls this
+                check(L.sb_set_tuning(h, C.byref(tune)))
             self._author(L, h)
         except Exception:
             self.OnDestroy()      # do not leak the handle when authoring / finalize fails
@@ -251,6 +255,15 @@ class Softbody:
     def profile_begin(self):
         check(native.lib().sb_profile_begin(self._h))
 
+    def exchange_timing(self, enabled):
+        """HIP events around every ghost exchange of the eager schedules (sb_debug_exchange_timing); read with exchange_timing_read()."""
+        check(native.lib().sb_debug_exchange_timing(self._h, 1 if enabled else 0))
+
+    def exchange_timing_read(self):
+        t = native.SbExchangeTiming()
+        check(native.lib().sb_debug_exchange_timing_read(self._h, C.byref(t)))
+        return {"exchanges": t.exchanges, "pack_ms": t.pack_ms, "transport_ms": t.transport_ms, "total_ms": t.total_ms, "exposed_wait_ms": t.exposed_wait_ms}
+
     def profile_end(self):
         ms = C.c_float()
         check(native.lib().sb_profile_end(self._h, C.byref(ms)))
@@ -261,3 +274,156 @@ def comm_unique_id():
     buf = (C.c_uint8 * native.SB_UNIQUE_ID_BYTES)()
     check(native.lib().sb_comm_unique_id(buf))
     return bytes(buf)
+
+
+class SoftbodyGroup:
+    """ONE process driving several devices behind one component (include/softbody_group.h; csharp/Softbody.cs with deviceCount > 1):
+    the whole mesh authored once, one call per tick, state gathered in the caller's numbering. Same member names as Softbody."""
+
+    def __init__(self, mesh, devices, substeps=20, fixed_delta_time=0.02, gravity=(0.0, -9.81, 0.0), damping=0.0,
+                 distance_compliance=0.0, volume_compliance=0.0, bending_compliance=0.0, part_dims=(0, 0, 0), tile_particles=0,
+                 use_graph=True, ground_plane=None, partition=native.SB_PARTITION_AUTO, plan_flags=None,
+                 halo_transport=native.SB_TRANSPORT_RCCL, halo_schedule=native.SB_SCHEDULE_AUTO, debug_flags=0, walk=False, tuning=None):
+        self.mesh = mesh
+        self.devices = [int(d) for d in devices]
+        self.substeps, self.fixed_delta_time = int(substeps), float(fixed_delta_time)
+        self.gravity, self.damping = tuple(float(g) for g in gravity), float(damping)
+        self.compliance = (float(distance_compliance), float(volume_compliance), float(bending_compliance))
+        self.part_dims, self.tile_particles, self.use_graph = tuple(int(d) for d in part_dims), int(tile_particles), bool(use_graph)
+        self.ground_plane = ground_plane
+        self.partition = int(partition)
+        self.plan_flags = native.plan_flags_from_env() if plan_flags is None else int(plan_flags)
+        self.halo_transport, self.halo_schedule, self.debug_flags = int(halo_transport), int(halo_schedule), int(debug_flags)
+        self.walk = bool(walk)
+        self.tuning = tuning
+        self._g = None
+        self._render_set_only = False
+        self.vertices = None
+
+    def Start(self):
+        L = native.lib()
+        d = native.SbDesc()
+        L.sb_desc_default(C.byref(d))
+        d.part_dims[:] = self.part_dims
+        d.gravity[:] = self.gravity
+        d.damping, d.tile_particles, d.use_graph = self.damping, self.tile_particles, 1 if self.use_graph else 0
+        d.partition, d.plan_flags = self.partition, self.plan_flags
+        d.halo_transport, d.halo_schedule, d.debug_flags = self.halo_transport, self.halo_schedule, self.debug_flags
+        devs = (C.c_int32 * len(self.devices))(*self.devices)
+        g = C.c_void_p()
+        check(L.sb_group_create(C.byref(d), devs, len(self.devices), native.SB_GROUP_WALK if self.walk else 0, C.byref(g)))
+        self._g = g
+        try:
+            tune = native.tuning_from_env() if self.tuning is None else self.tuning
+            if tune is not None:
+                for r in range(len(self.devices)):
+                    check(L.sb_set_tuning(self._rank_handle(r), C.byref(tune)))
+            m = self.mesh
+            pos = f32(m.pos, (-1, 3)); vel = f32(m.vel, (-1, 3)); w = f32(m.inv_mass, (-1,))
+            self.n = pos.shape[0]
+            check(L.sb_group_set_particles(g, ptr(pos), ptr(vel), ptr(w), self.n))
+            if m.rest_pos is not None:
+                rest = f32(m.rest_pos, (-1, 3))
+                check(L.sb_group_set_rest_positions(g, ptr(rest), self.n))
+            if len(m.dist_rest):
+                ij = i32(m.dist_ij, (-1, 2)); r = f32(m.dist_rest, (-1,))
+                check(L.sb_group_set_distance_constraints(g, ptr(ij), ptr(r), r.shape[0], self.compliance[0]))
+            if len(m.vol_rest):
+                q = i32(m.vol_ijkl, (-1, 4)); r = f32(m.vol_rest, (-1,))
+                check(L.sb_group_set_volume_constraints(g, ptr(q), ptr(r), r.shape[0], self.compliance[1]))
+            if len(m.bend_rest):
+                q = i32(m.bend_ijkl, (-1, 4)); r = f32(m.bend_rest, (-1, 2))
+                check(L.sb_group_set_bending_constraints(g, ptr(q), ptr(r), r.shape[0], self.compliance[2]))
+            if self.ground_plane is not None:
+                check(L.sb_group_set_ground_plane(g, *[float(c) for c in self.ground_plane], 1))
+            check(L.sb_group_finalize(g))
+            self.vertices = pos.copy()
+        except Exception:
+            self.OnDestroy()
+            raise
+        return self
+
+    def FixedUpdate(self, readback=True):
+        check(native.lib().sb_group_step(self._g, self.fixed_delta_time, self.substeps))
+        if readback:
+            self.get_positions(self.vertices)
+        return self.vertices
+
+    def OnDestroy(self):
+        if self._g is not None:
+            native.lib().sb_group_destroy(self._g)
+            self._g = None
+
+    def __enter__(self):
+        return self.Start()
+
+    def __exit__(self, *a):
+        self.OnDestroy()
+
+    def step(self, dt=None, substeps=None):
+        check(native.lib().sb_group_step(self._g, self.fixed_delta_time if dt is None else dt, self.substeps if substeps is None else substeps))
+
+    def synchronize(self):
+        check(native.lib().sb_group_synchronize(self._g))
+
+    def get_positions(self, out=None):
+        out = np.zeros((self.n, 3), np.float32) if out is None else out
+        check(native.lib().sb_group_get_positions(self._g, ptr(out), self.n))
+        return out
+
+    def get_velocities(self, out=None):
+        out = np.zeros((self.n, 3), np.float32) if out is None else out
+        check(native.lib().sb_group_get_velocities(self._g, ptr(out), self.n))
+        return out
+
+    def set_state(self, pos, vel):
+        pos = f32(pos, (-1, 3)); vel = f32(vel, (-1, 3))
+        check(native.lib().sb_group_set_state(self._g, ptr(pos), ptr(vel), self.n))
+
+    def set_kinematic_positions(self, ids, pos):
+        ids = i32(ids); pos = f32(pos, (-1, 3))
+        assert pos.shape[0] == ids.shape[0]
+        check(native.lib().sb_group_set_kinematic_positions(self._g, ptr(ids), ptr(pos), int(ids.shape[0])))
+
+    def set_render_triangles(self, tri):
+        tri = np.ascontiguousarray(tri, dtype=np.int32).reshape(-1, 3)
+        check(native.lib().sb_group_set_render_triangles(self._g, tri.ctypes.data_as(C.POINTER(C.c_int32)), tri.shape[0]))
+
+    def set_readback_render_set_only(self, on=True):
+        check(native.lib().sb_group_set_readback_render_set_only(self._g, 1 if on else 0))
+        self._render_set_only = bool(on)
+
+    def readback_begin(self):
+        check(native.lib().sb_group_readback_begin(self._g))
+
+    def render_set(self):
+        ids = C.POINTER(C.c_int32)(); cnt = C.c_int32()
+        check(native.lib().sb_group_readback_get_render_set(self._g, C.byref(ids), C.byref(cnt)))
+        return np.ctypeslib.as_array(ids, shape=(cnt.value,)) if cnt.value else np.zeros(0, np.int32)
+
+    def readback_end(self, normals=False):
+        p = C.POINTER(C.c_float)()
+        check(native.lib().sb_group_readback_end(self._g, C.byref(p)))
+        rows = len(self.render_set()) if self._render_set_only else self.n
+        pos = np.ctypeslib.as_array(p, shape=(rows, 3))
+        if not normals:
+            return pos
+        q = C.POINTER(C.c_float)()
+        check(native.lib().sb_group_readback_get_normals(self._g, C.byref(q)))
+        return pos, np.ctypeslib.as_array(q, shape=(rows, 3))
+
+    def _rank_handle(self, r):
+        h = C.c_void_p()
+        check(native.lib().sb_group_get_rank(self._g, int(r), C.byref(h)))
+        return h
+
+    def rank(self, r):
+        """Borrowed Softbody view of rank r (inspection only: stats, owner, validate, plan)."""
+        sb = Softbody.__new__(Softbody)
+        sb._h = self._rank_handle(r)
+        sb.world, sb.rank = len(self.devices), int(r)
+        st = native.SbStats()
+        check(native.lib().sb_get_stats(sb._h, C.byref(st)))
+        sb.n = None       # (the rank's own numbering may be its window's: use stats / validate, which need no n)
+        sb._cpu_plan = None
+        return sb

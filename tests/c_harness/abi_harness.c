@@ -1,4 +1,4 @@
-/* Plain-C consumer of include/softbody.h (SURVEY.md §4 iv): proves the header compiles as C, the library links
+/* Plain-C consumer of include/softbody.h + softbody_group.h / softbody_plan.h / softbody_debug.h (SURVEY.md §4 iv): proves the header compiles as C, the library links
  * from C, and the host-side entry points behave with plain pointers. With a GPU (argv[1] == "gpu") it also runs
  * the hot path once. Exit code 0 = all checks passed; prints one line per check. */
 #include <math.h>
@@ -7,6 +7,9 @@
 #include <string.h>
 
 #include "softbody.h"
+#include "softbody_debug.h"
+#include "softbody_group.h"
+#include "softbody_plan.h"
 
 #define CHECK(cond, what)                                        \
     do {                                                         \
@@ -75,6 +78,37 @@ int main(int argc, char **argv) {
         CHECK(sb_set_kinematic_positions(s, &free_id, target, 1) == SB_ERR_INVALID_ARG, "a free particle cannot be moved kinematically");
         CHECK(sb_set_kinematic_positions(s, NULL, NULL, 0) == SB_OK, "an empty kinematic list is accepted");
         CHECK(sb_destroy(s) == SB_OK, "sb_destroy");
+        /* one process driving every rank (softbody_group.h): two ranks on this box's one device, the calling thread walking the tick
+         * (SB_GROUP_WALK: no plugin thread), mailboxes connected by pointer. The gathered result must equal the single solver's above.
+         * (two ranks on ONE device: the waiting kernel of one rank must not sit in front of the other's in a shared hardware queue:
+         * the test starts this harness with GPU_MAX_HW_QUEUES set) */
+        {
+            sb_desc gd; sb_desc_default(&gd);
+            gd.halo_transport = SB_TRANSPORT_PEER; gd.tile_particles = 64;
+            int32_t devs[2] = {0, 0};
+            sb_group *g = NULL;
+            CHECK(sb_group_create(&gd, devs, 2, SB_GROUP_WALK, &g) == SB_OK && g, "sb_group_create (2 ranks, walk mode)");
+            CHECK(sb_group_rank_count(g) == 2, "sb_group_rank_count");
+            CHECK(sb_group_set_particles(g, pos, NULL, w, N) == SB_OK, "sb_group_set_particles");
+            CHECK(sb_group_set_distance_constraints(g, ij, rest, m, 0.0f) == SB_OK, "sb_group_set_distance_constraints");
+            CHECK(sb_group_step(g, 0.02f, 10) == SB_ERR_STATE, "sb_group_step before sb_group_finalize is refused");
+            CHECK(sb_group_finalize(g) == SB_OK, "sb_group_finalize");
+            CHECK(sb_group_step(g, 0.02f, 10) == SB_OK, "sb_group_step");
+            float *gout = malloc(sizeof(float) * 3 * N);
+            CHECK(sb_group_get_positions(g, gout, N) == SB_OK, "sb_group_get_positions (gathered, caller numbering)");
+            /* the single solver above planned with the automatic tile size, this group with 64: same physics, another Gauss-Seidel order --
+             * so compare against a single solver with the same tile size */
+            sb_solver *one = NULL; sb_desc od; sb_desc_default(&od); od.tile_particles = 64;
+            CHECK(sb_create(&od, &one) == SB_OK && sb_set_particles(one, pos, NULL, w, N) == SB_OK &&
+                  sb_set_distance_constraints(one, ij, rest, m, 0.0f) == SB_OK && sb_finalize(one) == SB_OK && sb_step(one, 0.02f, 10) == SB_OK &&
+                  sb_get_positions(one, out, N) == SB_OK, "the same mesh on one solver");
+            CHECK(memcmp(gout, out, sizeof(float) * 3 * N) == 0, "two ranks behind the group == one solver, bit for bit");
+            sb_solver *r1 = NULL; sb_stats st;
+            CHECK(sb_group_get_rank(g, 1, &r1) == SB_OK && sb_get_stats(r1, &st) == SB_OK && st.n_particles_owned > 0 && st.n_particles_owned < N &&
+                  st.n_particles_local > st.n_particles_owned, "rank 1 owns a part of the mesh and holds ghosts");
+            CHECK(sb_destroy(one) == SB_OK && sb_group_destroy(g) == SB_OK, "sb_group_destroy");
+            free(gout);
+        }
         free(out);
     } else {
         CHECK(rc == SB_ERR_NO_DEVICE || rc == SB_OK, "sb_create without a GPU fails with SB_ERR_NO_DEVICE");

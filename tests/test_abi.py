@@ -13,11 +13,32 @@ from softbodyunity_amd import native
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared():
-    src = open(os.path.join(ROOT, "include", "softbody.h")).read()
-    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
-    names = re.findall(r"\b(sb_[a-z0-9_]+)\s*\(", src)
-    return sorted(set(names))
+HEADERS = ("softbody.h", "softbody_group.h", "softbody_plan.h", "softbody_debug.h")
+
+
+def _declared(headers=HEADERS):
+    names = set()
+    for h in headers:
+        src = open(os.path.join(ROOT, "include", h)).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names |= set(re.findall(r"\b(sb_[a-z0-9_]+)\s*\(", src))
+    return sorted(names)
+
+
+def test_the_product_header_stays_thin():
+    # what a Unity maintainer reads: the solver handle's product surface; test hooks, the validator, per-launch timing and the tuning
+    # switches live in softbody_debug.h, the planner inspection in softbody_plan.h, the single-process multi-device host in softbody_group.h
+    core = _declared(("softbody.h",))
+    assert len(core) <= 40, core
+    assert not [n for n in core if n.startswith(("sb_debug_", "sb_plan_", "sb_group_", "sb_profile_"))]
+    assert not [n for n in _declared(("softbody_group.h",)) if not n.startswith("sb_group_")]
+    # the plugin reads no environment variable that selects kernels or table layouts (sb_tuning replaces them): what is left prints
+    csrc = os.path.join(ROOT, "softbodyunity_amd", "csrc")
+    left = []
+    for f in os.listdir(csrc):
+        if f.endswith((".hip", ".hpp")) and not f.startswith("_old"):
+            left += re.findall(r'getenv\("(\w+)"\)', open(os.path.join(csrc, f)).read())
+    assert sorted(set(left)) == ["SB_PLAN_TIMING", "SB_PRINT_ALLOC"], left
 
 
 def test_every_declared_symbol_is_exported_and_bound():
@@ -52,13 +73,16 @@ def test_struct_layouts_match_header():
 def test_header_structs_compile_to_the_same_sizes(tmp_path):
     # the ctypes twin against the header itself, through the C compiler
     src = tmp_path / "sizes.c"
-    src.write_text('#include <stdio.h>\n#include "softbody.h"\nint main(void){printf("%zu %zu %zu %zu %zu %zu %zu\\n", sizeof(sb_desc), sizeof(sb_plan_opts), '
-                   'sizeof(sb_phase_info), sizeof(sb_stats), sizeof(sb_runtime_info_t), sizeof(sb_domain), sizeof(sb_validate_report)); return 0;}\n')
+    src.write_text('#include <stdio.h>\n#include "softbody.h"\n#include "softbody_group.h"\n#include "softbody_plan.h"\n#include "softbody_debug.h"\n'
+                   'int main(void){printf("%zu %zu %zu %zu %zu %zu %zu %zu %zu\\n", sizeof(sb_desc), sizeof(sb_plan_opts), '
+                   'sizeof(sb_phase_info), sizeof(sb_stats), sizeof(sb_runtime_info_t), sizeof(sb_domain), sizeof(sb_validate_report), sizeof(sb_tuning), '
+                   'sizeof(sb_exchange_timing)); return 0;}\n')
     exe = tmp_path / "sizes"
     subprocess.check_call(["gcc", "-I", os.path.join(ROOT, "include"), str(src), "-o", str(exe)])
     got = [int(x) for x in subprocess.check_output([str(exe)], text=True).split()]
     assert got == [C.sizeof(native.SbDesc), C.sizeof(native.SbPlanOpts), C.sizeof(native.SbPhaseInfo), C.sizeof(native.SbStats),
-                   C.sizeof(native.SbRuntimeInfo), C.sizeof(native.SbDomain), C.sizeof(native.SbValidateReport)]
+                   C.sizeof(native.SbRuntimeInfo), C.sizeof(native.SbDomain), C.sizeof(native.SbValidateReport), C.sizeof(native.SbTuning),
+                   C.sizeof(native.SbExchangeTiming)]
 
 
 def test_runtime_info_names_the_bound_libraries():
@@ -75,7 +99,7 @@ def test_runtime_info_names_the_bound_libraries():
 
 def test_loads_without_gpu_and_fails_loudly():
     L = native.lib()
-    assert L.sb_abi_version() == 7
+    assert L.sb_abi_version() == 8
     d = native.SbDesc()
     L.sb_desc_default(C.byref(d))
     assert d.world == 1 and d.tile_particles == 0 and d.use_graph == 1 and abs(d.gravity[1] + 9.81) < 1e-6

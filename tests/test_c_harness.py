@@ -26,5 +26,5 @@ def test_c_harness_host_side(tmp_path):
 
 @pytest.mark.gpu
 def test_c_harness_gpu(tmp_path):
-    out = subprocess.run([_build(tmp_path), "gpu"], capture_output=True, text=True)
+    out = subprocess.run([_build(tmp_path), "gpu"], capture_output=True, text=True, env=dict(os.environ, GPU_MAX_HW_QUEUES="8"))
     assert out.returncode == 0 and "ALL OK" in out.stdout, out.stdout + out.stderr

@@ -91,12 +91,26 @@ def test_only_pinned_particles_are_kinematic_and_nothing_changes_on_error():
         sb.OnDestroy()
 
 
-def test_partitioned_solvers_refuse():
-    mesh = jelly_cube(12)
-    mesh.inv_mass[:10] = 0.0
-    sb = Softbody(mesh, substeps=4, rank=0, world=2, debug_flags=native.SB_DEBUG_NO_COMM).Start()
-    try:
-        with pytest.raises(native.SoftbodyError, match="single-rank"):
-            sb.set_kinematic_positions([0], np.zeros((1, 3), np.float32))
-    finally:
-        sb.OnDestroy()
+def test_a_rank_of_a_partitioned_solver_moves_the_pins_it_owns(oracle_mod):
+    # every rank is handed the whole list; it applies the entries it owns (the ghost copies on its neighbours arrive with the next
+    # exchange) -- here 8 ranks of one mesh on the one GPU, the host as the wire (tests/hosted.py), against the oracle
+    from hosted import HostedRanks
+    mesh = jelly_cube(24)
+    pins = np.nonzero(mesh.pos[:, 1] > mesh.pos[:, 1].max() - 0.5)[0].astype(np.int32)
+    mesh.inv_mass[pins] = 0.0
+    rest = mesh.pos[pins].copy()
+    with HostedRanks(mesh, 8, 6, tile_particles=64, damping=0.05) as H:
+        o = make_oracle(oracle_mod, mesh, H.ranks[0].plan(), damping=0.05)
+        owners = H.ranks[0].owner()
+        assert len(np.unique(owners[pins])) >= 4                     # the pinned layer is spread over several ranks
+        for t in range(4):
+            target = rest + np.array([0.2 * np.sin(0.5 * t), -0.05 * t, 0.1 * t], np.float32)
+            for sb in H.ranks:
+                sb.set_kinematic_positions(pins, target)
+            o.set_kinematic_positions(pins, target)
+            H.tick(); o.step(0.02, 6)
+        x, v, _ = H.merged_state()
+        assert np.array_equal(_bits(x), _bits(o.x)) and np.array_equal(_bits(v), _bits(o.v))
+        assert np.array_equal(_bits(x[pins]), _bits(target))
+        with pytest.raises(native.SoftbodyError, match="twice"):
+            H.ranks[0].set_kinematic_positions([int(pins[0]), int(pins[0])], np.zeros((2, 3), np.float32))

@@ -266,10 +266,11 @@ def test_ranks_that_own_nothing_on_the_device(oracle_mod, partition):
     assert np.array_equal(x.view(np.uint32), ref.x.view(np.uint32)) and np.array_equal(v.view(np.uint32), ref.v.view(np.uint32))
 
 
-def test_auto_schedule_follows_the_size_of_the_exchange():
-    """SB_SCHEDULE_AUTO: the overlapped eager schedule when the largest per-peer message of the T1 exchange is >= 1 MiB (between devices
-    the exchange is then bound by the one xGMI link it crosses), the serialised eager one below; either way the bits of the explicit
-    serialised schedule (RCCL self-exchange on a size-1 communicator)."""
+def test_auto_schedule_is_the_serialised_eager_one_whatever_the_size():
+    """SB_SCHEDULE_AUTO = SB_SCHEDULE_SERIAL_EAGER on every rank alike (round 3 switched to the overlapped schedule above 1 MiB per peer on
+    a link-bandwidth model; every measurement that exists has the serialised one faster, so the overlapped schedule is opt-in until it
+    has been timed between two devices: bench.py --gpus N, config.schedule_ab). The explicit overlapped schedule gives the same bits
+    (RCCL self-exchange on a size-1 communicator)."""
     import hashlib
     from softbodyunity_amd import Softbody, comm_unique_id, native
     from softbodyunity_amd.mesh import jelly_cube
@@ -287,9 +288,9 @@ def test_auto_schedule_follows_the_size_of_the_exchange():
             sb.OnDestroy()
 
     small, large = jelly_cube(32), jelly_cube(112)
-    sched, nbytes, h_auto = run(small, native.SB_SCHEDULE_AUTO)
+    sched, nbytes, _ = run(small, native.SB_SCHEDULE_AUTO)
     assert sched == native.SB_SCHEDULE_SERIAL_EAGER and nbytes < (1 << 20)
     sched, nbytes, h_auto = run(large, native.SB_SCHEDULE_AUTO)
-    assert sched == native.SB_SCHEDULE_OVERLAP_EAGER and nbytes >= (1 << 20)
-    sched, _, h_serial = run(large, native.SB_SCHEDULE_SERIAL_EAGER)
-    assert sched == native.SB_SCHEDULE_SERIAL_EAGER and h_serial == h_auto
+    assert sched == native.SB_SCHEDULE_SERIAL_EAGER and nbytes >= (1 << 20)
+    sched, _, h_overlap = run(large, native.SB_SCHEDULE_OVERLAP_EAGER)
+    assert sched == native.SB_SCHEDULE_OVERLAP_EAGER and h_overlap == h_auto

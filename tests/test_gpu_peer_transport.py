@@ -78,6 +78,107 @@ def test_ranks_as_processes_through_the_peer_transport(tmp_path, oracle_mod, wor
     assert np.array_equal(v.view(np.uint32), ref.v.view(np.uint32))
 
 
+def _worker_features(rank, world, port, out_dir):
+    """A rank of a partitioned solver has what a single rank has: kinematic targets (it applies the pins it owns), position reads and a
+    render-set readback that PEEK while its tick's last kernel is held back -- through the real tick path, ranks as processes."""
+    import ctypes as C
+
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from readback_bench import surface_triangles
+    from softbodyunity_amd import Softbody, native
+    from softbodyunity_amd.mesh import jelly_cube
+    n = 24
+    mesh = jelly_cube(n)
+    pins = np.nonzero(mesh.pos[:, 1] > mesh.pos[:, 1].max() - 0.5)[0].astype(np.int32)
+    mesh.inv_mass[pins] = 0.0
+    rest = mesh.pos[pins].copy()
+    tune = native.SbTuning(); native.lib().sb_tuning_default(C.byref(tune)); tune.peek_min_tiles = 0
+    sb = Softbody(mesh, substeps=6, device=0, rank=rank, world=world, tile_particles=64, damping=0.05, halo_transport=native.SB_TRANSPORT_PEER,
+                  halo_schedule=native.SB_SCHEDULE_SERIAL_EAGER, tuning=tune).Start()
+    L = native.lib()
+    mine = np.zeros(native.SB_IPC_HANDLE_BYTES, np.uint8)
+    native.check(L.sb_peer_mailbox_handle(sb._h, native.ptr(mine)))
+    handles = [torch.zeros(native.SB_IPC_HANDLE_BYTES, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(handles, torch.from_numpy(mine))
+    for r in range(world):
+        if r != rank:
+            h = handles[r].numpy().copy()
+            native.check(L.sb_peer_connect(sb._h, r, native.ptr(h), None))
+    dist.barrier()
+    sb.set_render_triangles(surface_triangles(n))
+    sb.set_readback_render_set_only(True)
+    owned = sb.owner() == rank
+    snaps, reads = [], []
+    for t in range(6):
+        target = rest + np.array([0.3 * np.sin(0.4 * t), 0.1 * np.cos(0.7 * t) - 0.1, 0.05 * t], np.float32)
+        sb.set_kinematic_positions(pins, target)                 # the whole list on every rank
+        if t & 1:
+            reads.append(sb.get_positions()[owned].copy())       # between the move and the step
+        sb.step()
+        sb.readback_begin()
+        snaps.append(sb.readback_end().copy())
+    ids = sb.render_set().copy()
+    st = sb.stats()
+    np.savez(os.path.join(out_dir, f"rank{rank}.npz"), x=sb.get_positions(), v=sb.get_velocities(), owned=owned, ids=ids,
+             snaps=np.stack(snaps), reads=np.stack(reads), peeks=np.array(st["readback_peeks"]), fused=np.array(st["ticks_fused"]),
+             kin=np.array(st["ticks_fused_kinematic"]))
+    try:
+        sb.readback_begin(); sb.readback_end(normals=True)
+        refused = False
+    except native.SoftbodyError as e:
+        refused = "sb_group_readback_get_normals" in str(e)
+    assert refused, "per-rank vertex normals of a partitioned solver must be refused with a pointer to the group API"
+    sb.synchronize()
+    dist.barrier()
+    sb.OnDestroy()
+    dist.destroy_process_group()
+
+
+def test_ranks_as_processes_kinematic_peek_and_render_set(tmp_path, oracle_mod):
+    from softbodyunity_amd.mesh import jelly_cube
+    from helpers import build_plan, make_oracle
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    from readback_bench import surface_triangles
+    world = 4
+    port = 29300 + (os.getpid() % 1500) + 977
+    mp.spawn(_worker_features, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    n = 24
+    mesh = jelly_cube(n)
+    pins = np.nonzero(mesh.pos[:, 1] > mesh.pos[:, 1].max() - 0.5)[0].astype(np.int32)
+    mesh.inv_mass[pins] = 0.0
+    rest = mesh.pos[pins].copy()
+    surf = np.unique(surface_triangles(n))
+    ref = make_oracle(oracle_mod, mesh, build_plan(mesh, tile_particles=64), damping=0.05)
+    d = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    seen = np.zeros(mesh.n, int)
+    for r in range(world):       # a rank's render set = the surface particles it owns
+        assert np.array_equal(d[r]["ids"], surf[d[r]["owned"][surf]])
+        seen[d[r]["ids"]] += 1
+    assert np.array_equal(np.nonzero(seen)[0], surf) and seen.max() == 1
+    k_read = 0
+    for t in range(6):
+        target = rest + np.array([0.3 * np.sin(0.4 * t), 0.1 * np.cos(0.7 * t) - 0.1, 0.05 * t], np.float32)
+        ref.set_kinematic_positions(pins, target)
+        if t & 1:
+            for r in range(world):
+                assert np.array_equal(d[r]["reads"][k_read].view(np.uint32), ref.x[d[r]["owned"]].view(np.uint32)), f"read before tick {t}, rank {r}"
+            k_read += 1
+        ref.step(0.02, 6)
+        for r in range(world):
+            assert np.array_equal(d[r]["snaps"][t].view(np.uint32), ref.x[d[r]["ids"]].view(np.uint32)), f"render-set snapshot of tick {t}, rank {r}"
+    x = np.zeros_like(ref.x); v = np.zeros_like(ref.v)
+    for r in range(world):
+        x[d[r]["owned"]] = d[r]["x"][d[r]["owned"]]; v[d[r]["owned"]] = d[r]["v"][d[r]["owned"]]
+    assert np.array_equal(x.view(np.uint32), ref.x.view(np.uint32)) and np.array_equal(v.view(np.uint32), ref.v.view(np.uint32))
+    # nothing completed a tick early: every snapshot and read peeked, every tick after the first fused with the one before, and the
+    # ranks that own pins took their targets inside the fused kernel
+    assert all(int(q["peeks"]) >= 8 for q in d) and all(int(q["fused"]) >= 5 for q in d) and sum(int(q["kin"]) for q in d) >= 5
+
+
 def test_peer_transport_loopback_schedules_agree():
     # rank 0's share with every neighbour replaced by itself: serialised / overlapped x eager / captured, one process each
     out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "lb_combo_check.py"), "peer"], capture_output=True, text=True, timeout=900)
