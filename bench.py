@@ -13,6 +13,17 @@ Launch: `python bench.py` (N=1) or
 control plane (unique-id broadcast, barriers, max-over-ranks); the ghost exchange itself is RCCL
 send/recv inside the plugin on its own HIP stream.
 
+N > 1 (the one run a multi-GPU node makes): the line's `value` is the DEFAULT variant's figure (--transport / --schedule, default RCCL with
+SB_SCHEDULE_AUTO); after it, inside the same launch, every other admitted (transport, schedule) pair is timed on the same inputs with a
+fresh solver -- RCCL serial-eager / overlap-eager / serial-graph / overlap-graph (where sb_runtime_info admits them), the peer-store
+transport eager and captured -- each followed by the golden-checksum check, with per-exchange HIP-event times (pack, transport, exposed
+wait) and per-rank owned / ghost counts: `config.schedule_ab`. A variant that fails is reported there, never fatal; the line as it
+stands is registered with the plugin (sb_debug_last_words) before every further variant and written by a watchdog should one hang, so
+ONE line comes out whatever a variant does. --no-ab skips the extra variants.
+
+Sustained figure: after the timed region and the parity legs the state is reset and the same tick runs for >= 2 s (`sustained_ms_per_step`,
+`config.sustained`, with the card's clocks and power sampled over THAT window); `value` stays the driver-parameterised region.
+
 Self-verification (outside the timed region, `config.parity`):
   golden : an order-independent checksum of the positions + velocities the timed run ended with (after warmup + steps
            ticks; ranks add their partial sums) against tests/golden/state_checksums.json, which
@@ -144,7 +155,12 @@ def _pci_bus_id(torch, device):
         return None
 
 
-def main():
+
+SCHEDULES = {"auto": 0, "serial-eager": 1, "serial-graph": 2, "overlap-eager": 3, "overlap-graph": 4}
+SCHEDULE_NAMES = {1: "serial-eager", 2: "serial-graph", 3: "overlap-eager", 4: "overlap-graph"}
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
@@ -157,6 +173,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity", action="store_true", help="skip the self-verification legs (profiling runs)")
     ap.add_argument("--no-gpu-state", action="store_true", help="do not sample the card's clocks and power (sysfs) while measuring")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the >= 2 s sustained leg behind the timed region")
+    ap.add_argument("--sustained-seconds", type=float, default=2.0)
     ap.add_argument("--cpu-sample-n", type=int, default=0, help="cube edge for the CPU baseline sample (0 = the workload itself)")
     ap.add_argument("--strict-traffic", action="store_true",
                     help="fail (instead of falling back to the compulsory-bytes model and saying so) when profiles/hbm_traffic.json is "
@@ -166,16 +184,60 @@ def main():
                     help="the data-layout worst case beside the headline's best case: per-particle masses and per-spring rest lengths "
                          "(4-byte inverse masses, 8-byte constraint slots; mesh.jelly_cube(heterogeneous=True))")
     ap.add_argument("--transport", choices=["rccl", "peer"], default="rccl",
-                    help="ghost exchange for --gpus N > 1: RCCL send/recv (default) or the opt-in peer-store mailboxes (DESIGN.md 7; "
-                         "never run between two devices)")
+                    help="ghost exchange of the DEFAULT variant for --gpus N > 1: RCCL send/recv (default) or the opt-in peer-store mailboxes "
+                         "(DESIGN.md 7; never run between two devices)")
     ap.add_argument("--whole-mesh", action="store_true", help="N > 1: every rank generates and plans the whole mesh (round-2 behaviour) instead of its window")
-    ap.add_argument("--schedule", choices=["auto", "serial-eager", "serial-graph", "overlap-eager", "overlap-graph"], default="auto",
-                    help="halo schedule for N > 1 (sb_desc.halo_schedule); auto = eager launches, the exchange overlapped with the interior tiles when its "
-                         "largest per-peer message is >= 1 MiB, serialised below (config.halo_schedule says which)")
+    ap.add_argument("--schedule", choices=list(SCHEDULES), default="auto",
+                    help="halo schedule of the DEFAULT variant for N > 1 (sb_desc.halo_schedule); auto = serial-eager")
+    ap.add_argument("--no-ab", action="store_true", help="N > 1: time the default (transport, schedule) only, not every admitted pair (config.schedule_ab)")
+    ap.add_argument("--ab-steps", type=int, default=0, help="N > 1: timed ticks of the A/B variants (0 = --steps)")
+    ap.add_argument("--variant-timeout", type=float, default=150.0, help="N > 1: seconds one variant may take before the watchdog writes the line as it stands and ends the run")
     ap.add_argument("--loopback-world", type=int, default=0,
                     help="diagnostic: run as rank 0 of this many ranks with SB_TEST_LOOPBACK (RCCL self-exchange on one GPU); "
                          "the reported value counts only the particles this rank owns")
-    args = ap.parse_args()
+    return ap.parse_args()
+
+
+class LastWords:
+    """ONE line leaves this process whatever happens (rank 0 of an N > 1 run): the line as it stands is registered with the plugin, whose
+    signal handler writes it should the process die (a GPU fault ends in abort(); a launcher tearing the job down sends SIGTERM), and a
+    watchdog thread writes it should a variant hang."""
+
+    def __init__(self, fd, native):
+        self.fd, self.native, self.line = fd, native, None
+        self.deadline, self.what = None, ""
+        self._th = None
+
+    def stash(self, line_dict):
+        self.line = (json.dumps(line_dict) + "\n").encode()
+        self.native.lib().sb_debug_last_words(self.fd, self.line, len(self.line), 70)
+
+    def clear(self):
+        self.deadline = None
+        self.native.lib().sb_debug_last_words(self.fd, None, 0, 0)
+
+    def arm(self, seconds, what):
+        import threading
+        self.deadline, self.what = time.time() + seconds, what
+        if self._th is None:
+            def watch():
+                while True:
+                    time.sleep(1.0)
+                    d = self.deadline
+                    if d is not None and time.time() > d:
+                        print(f"bench.py: '{self.what}' exceeded its time limit: writing the line as it stands and ending the run", file=sys.stderr, flush=True)
+                        if self.line:
+                            os.write(self.fd, self.line)
+                        os._exit(71)
+            self._th = threading.Thread(target=watch, daemon=True)
+            self._th.start()
+
+    def disarm(self):
+        self.deadline = None
+
+
+def main():
+    args = parse_args()
 
     # stdout carries exactly one JSON line: native libraries (RCCL prints a version banner on communicator
     # creation) write to fd 1, so park fd 1 on stderr until the result is ready
@@ -209,9 +271,8 @@ def main():
 
     # torch is imported BEFORE the plugin on purpose and always: the plugin then binds the HIP runtime and the RCCL torch brought
     # (one ROCm stack per process); which ones is recorded in the line (config.runtime, from sb_runtime_info)
-    from softbodyunity_amd import Softbody, comm_unique_id, jelly_cube, native
-    from softbodyunity_amd.verify import add_checksums, schedule_hash, state_checksum
-    runtime = native.runtime_info() if (world > 1 or args.loopback_world > 1) else None
+    from softbodyunity_amd import jelly_cube, native
+    ctx = dict(args=args, rank=rank, world=world, device=device, n_dev=n_dev, torch=torch, dist=dist, native=native)
 
     t_setup = time.time()
     # N > 1: sharded authoring -- every rank generates, hands over and plans only ITS WINDOW of the cube (its block + two cells
@@ -224,250 +285,12 @@ def main():
         mesh = jelly_cube_window(args.n, rank, part_world, _dims(part_world), args.tile, heterogeneous=args.heterogeneous)
     else:
         mesh = jelly_cube(args.n, heterogeneous=args.heterogeneous)
-    mesh_s = time.time() - t_setup
-    N = args.n ** 3
-    M = 3 * args.n * args.n * (args.n - 1)
-    gid = mesh.global_id if sharded else None        # whole-cube id of every particle this rank handed over
-    uid = None
-    peer = args.transport == "peer"
-    if world > 1 and not peer:       # (the peer transport needs no RCCL communicator: the mailbox handles travel over gloo below)
-        buf = torch.zeros(128, dtype=torch.uint8)
-        if rank == 0:
-            buf = torch.tensor(list(comm_unique_id()), dtype=torch.uint8)
-        dist.broadcast(buf, src=0)
-        uid = bytes(buf.tolist())
-    dt = 0.02
-    sb_world = world
-    debug_flags = 0
-    if args.loopback_world > 1:
-        assert world == 1, "--loopback-world is a single-process diagnostic"
-        debug_flags = native.SB_DEBUG_LOOPBACK
-        sb_world = args.loopback_world
-        uid = comm_unique_id()
-    schedule = {"auto": native.SB_SCHEDULE_AUTO, "serial-eager": native.SB_SCHEDULE_SERIAL_EAGER, "serial-graph": native.SB_SCHEDULE_SERIAL_GRAPH,
-                "overlap-eager": native.SB_SCHEDULE_OVERLAP_EAGER, "overlap-graph": native.SB_SCHEDULE_OVERLAP_GRAPH}[args.schedule]
-    sb = Softbody(mesh, substeps=args.substeps, fixed_delta_time=dt, device=device, rank=rank, world=sb_world,
-                  tile_particles=args.tile, use_graph=not args.no_graph, unique_id=uid, plan_flags=0, debug_flags=debug_flags,
-                  halo_transport=native.SB_TRANSPORT_PEER if peer else native.SB_TRANSPORT_RCCL, halo_schedule=schedule).Start()
-    try:
-        if world > 1 and peer:
-            handles = [torch.zeros(64, dtype=torch.uint8) for _ in range(world)]
-            dist.all_gather(handles, torch.from_numpy(sb.peer_mailbox_handle().copy()))
-            for r in range(world):
-                if r != rank:
-                    sb.peer_connect(r, handles[r].numpy())
-            dist.barrier()
-        stats = sb.stats()
-        setup_s = time.time() - t_setup
+    ctx.update(mesh=mesh, mesh_s=time.time() - t_setup, sharded=sharded, t_setup=t_setup)
 
-        def barrier():
-            sb.synchronize()
-            if torch.cuda.is_available():
-                torch.cuda.synchronize()
-            if dist is not None:
-                dist.barrier()
-
-        sampler = None
-        if rank == 0 and not args.no_gpu_state:
-            sampler = GpuStateSampler(_pci_bus_id(torch, device) if n_dev > 0 else None).start()
-        for _ in range(args.warmup):
-            sb.step()
-        barrier()
-        t0 = time.perf_counter()
-        sb.profile_begin()
-        for _ in range(args.steps):
-            sb.step()
-        ev_ms = sb.profile_end()
-        barrier()
-        elapsed = time.perf_counter() - t0
-        gpu_state = sampler.stop() if sampler is not None else None
-        if dist is not None:
-            t = torch.tensor([elapsed], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
-
-        # ---- self-verification, leg 1: the state the timed run ended with, against the oracle's golden checksum ------
-        total_ticks = args.warmup + args.steps
-        parity = {"ticks": total_ticks}
-        loopback = args.loopback_world > 1
-        if not args.no_parity and not loopback:
-            owned_mask = sb.owner() == rank
-            ids = np.nonzero(owned_mask)[0]
-            x_end = sb.get_positions(); v_end = sb.get_velocities()
-            finite = bool(np.isfinite(x_end[ids]).all())
-            part = state_checksum(x_end[ids], v_end[ids], ids if gid is None else gid[ids])
-            if dist is not None:
-                parts = [None] * world
-                dist.all_gather_object(parts, part)
-                fin = [None] * world
-                dist.all_gather_object(fin, finite)
-                finite = all(fin)
-            else:
-                parts = [part]
-            checksum = add_checksums(parts)
-            golden = _golden_entry(args.n, args.substeps, args.tile, args.heterogeneous)
-            want = golden["ticks"].get(str(total_ticks)) if golden else None
-            parity["golden"] = {"n": N, "checksum": f"0x{checksum:016x}", "expected": want,
-                                "bitwise": (int(want, 16) == checksum) if want else None,
-                                "source": "tests/golden/state_checksums.json (CPU oracle, tests/golden/make_checksums.py)"}
-            if golden and world == 1 and rank == 0:
-                parity["golden"]["schedule_matches"] = schedule_hash(sb.plan()) == golden["schedule"]
-            del x_end, v_end
-        else:
-            finite = bool(np.isfinite(sb.get_positions()[sb.owner() == rank]).all())
-
-        # the tables the timed launches read, re-read by the validator kernel (sb_debug_validate): a group or a launch that touched a
-        # particle twice would be a race, whatever the state looks like
-        if not args.no_parity:
-            rep = sb.validate()
-            parity["tables"] = {"constraints_checked": rep["constraints_checked"], "tiles_checked": rep["tiles_checked"], "errors": rep["errors"],
-                                "clean": rep["errors"] == [0] * 6}
-
-        # per-kernel HIP-event timing on the solver's stream: a few extra eager ticks, outside the timed region
-        prof_ticks = 2
-        slot_ms = None
-        for _ in range(prof_ticks):
-            ms, cnt = sb.step_profiled()
-            slot_ms = ms.astype(np.float64) if slot_ms is None else slot_ms + ms
-            slot_cnt = cnt
-        slot_ms /= prof_ticks
-
-        if loopback:
-            N = int(stats["n_particles_owned"])      # diagnostic mode: only this rank's share is simulated
-        value = N * args.substeps * args.steps / elapsed
-        ms_per_step = 1e3 * elapsed / args.steps
-        out = None
-        if rank == 0:
-            G = stats["n_global_colours"]
-            owned = stats["n_particles_owned"]
-            names = ["tile_kernel<1> on T0 (rounds + collide/velocity/integrate + rounds)",
-                     "tile_kernel<1> on T1 (rounds + collide/velocity/integrate + rounds)"]
-            names += [f"global colour {c}" for c in range(G)]
-            names += ["tile_kernel<0> (first kernel of a tick)", "tile_kernel<2> (last kernel of a tick)",
-                      "tile_kernel<3> on the T2 layers (constraints inside neither T0 nor T1)"]
-            # ALGORITHMIC bytes per launch: a mid-tick tile kernel does one velocity update (36 B)
-            # + one integrate (52 B) per particle and projects every constraint it stores TWICE (before and after
-            # the MARK step: the tail of one substep and the head of the next), 68 B each time
-            alg_bytes = [88.0 * owned + 2 * 68.0 * stats["tile_constraints"][t] for t in (0, 1)]
-            # compulsory HBM bytes per launch from the tables actually uploaded (sb_get_stats): the model the PMC figure is checked against
-            lb = stats["launch_bytes"]
-            model_bytes = [float(lb[0]), float(lb[1])]
-            mask0 = None
-            for c in range(G):
-                if mask0 is None:
-                    plan = sb.plan(); mask0 = plan.local_order_mask(0).astype(bool); ph0 = [p for p in plan.phases(0) if p["kind"] == 0]
-                cnt_c = int(mask0[ph0[c]["order_begin"]:ph0[c]["order_end"]].sum())
-                alg_bytes.append(68.0 * cnt_c)
-                model_bytes.append(68.0 * cnt_c)      # global colours gather/scatter straight on HBM: no on-chip reuse to model
-            last = (args.substeps & 1) if stats["n_tilings"] == 2 else 0
-            alg_bytes += [52.0 * owned + 68.0 * stats["tile_constraints"][0], 36.0 * owned + 68.0 * stats["tile_constraints"][last]]
-            alg_bytes.append(68.0 * stats["t2_constraints"])
-            model_bytes += [float(lb[2]), float(lb[3]) if last == 0 else float(lb[1] - (lb[0] - lb[3])), float(lb[4])]
-            k_dom = int(np.argmax(slot_ms))
-            launches = max(int(slot_cnt[k_dom]), 1)
-            dom_ms = float(slot_ms[k_dom]) / launches          # HIP-event pair around every launch of an eager tick
-            dom_ms_pairs = dom_ms
-            # When the timed region consists of launches of ONE kernel only -- the lattice workloads: tile_kernel<1>, T0 and T1
-            # launches alternating, `substeps` of them per tick once the lazy tick boundary has fused the first and last kernels --
-            # its average launch duration is the HIP-event time of the timed region itself divided by the launches in it (the
-            # event pairs of the eager ticks add ~4 % of dispatch gap per launch).
-            region_avg = (world == 1 and not loopback and not args.no_graph and G == 0 and stats["n_t2_layers"] == 0
-                          and stats["n_tilings"] == 2 and args.substeps % 2 == 0 and k_dom in (0, 1) and args.steps >= 2)
-            if region_avg:
-                dom_ms = ev_ms / (args.steps * args.substeps)
-                launches = args.substeps
-                for arr in (alg_bytes, model_bytes):
-                    arr[0] = arr[1] = 0.5 * (arr[0] + arr[1])
-                dom_name = "tile_kernel<1>, mid-tick (rounds + collide/velocity/integrate + rounds), T0 and T1 launches alternating"
-            else:
-                dom_name = names[k_dom]
-            # HBM traffic per launch of the dominant kernel: PMC counters (profiles/hbm_traffic.json, produced by
-            # tools/prof_summary.py from separate FETCH_SIZE / WRITE_SIZE passes) -- accepted only when within 3 % of the
-            # compulsory-bytes model of THIS build's tables, so the file cannot go stale unnoticed
-            traffic, traffic_src, traffic_meta = None, None, None
-            key = f"n{args.n}{'het' if args.heterogeneous else ''}_tile{args.tile}_gpus{world}"
-            tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-            tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
-            problem = None
-            if not loopback and key in tj and str(k_dom) in tj[key]:
-                traffic = float(tj[key][str(k_dom)])
-                if region_avg and "0" in tj[key] and "1" in tj[key]:
-                    traffic = 0.5 * (float(tj[key]["0"]) + float(tj[key]["1"]))     # the two launch shapes alternate
-                traffic_meta = tj[key].get("meta")
-                dev = abs(traffic - model_bytes[k_dom]) / model_bytes[k_dom]
-                if dev > 0.03:    # the entry was measured on another kernel / data layout: say so, use the model
-                    problem = (f"profiles/hbm_traffic.json[{key}][{k_dom}] = {traffic:.4g} B disagrees with the compulsory-bytes model "
-                               f"{model_bytes[k_dom]:.4g} B of this build by {100 * dev:.1f} %: re-measure (tools/profile_round.sh)")
-                    traffic_src = f"stale ({100 * dev:.1f} % off the model of this build's tables): achieved/frac use the compulsory-bytes model"
-                    traffic = None
-                else:
-                    traffic_src = "pmc"
-            elif args.n == 256 and args.tile == 512 and world == 1 and not loopback:
-                problem = f"profiles/hbm_traffic.json has no PMC entry for {key} slot {k_dom}"
-            if problem:
-                if args.strict_traffic:
-                    raise RuntimeError("bench.py: " + problem)
-                print("WARNING: " + problem, file=sys.stderr)
-            hbm_bytes = traffic if traffic is not None else model_bytes[k_dom]
-            achieved = hbm_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-            alg_rate = alg_bytes[k_dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
-            job_alg = b_alg(N, M) * value / N   # algorithmic B/s of the whole job
-            parity["finite"] = finite
-            out = {
-                "metric": "particle-substeps/sec", "value": value, "unit": "particle-substeps/s",
-                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
-                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                "config": {"workload": f"{args.n}^3 jelly cube, structural springs (N={N}, M={M}), {args.substeps} substeps/tick, "
-                                       f"dt=0.02, explicit index-array graph, tile_particles={args.tile}" +
-                                       (", HETEROGENEOUS masses and rest lengths (4-byte inverse masses, 8-byte constraint slots)" if args.heterogeneous else ""),
-                           "partition": "x".join(str(d) for d in _dims(world)), "graph_replay": (not args.no_graph) and world == 1,
-                       "authoring": ("sharded: each rank hands over and plans its window only (sb_set_domain)" if sharded else "whole mesh on every rank"),
-                           "halo_transport": args.transport if (world > 1 or loopback) else None,
-                           "halo_schedule": {1: "serial-eager", 2: "serial-graph", 3: "overlap-eager", 4: "overlap-graph"}.get(stats["halo_schedule"]) if (world > 1 or loopback) else None,
-                           "runtime": runtime, "gpu_state": gpu_state,
-                           "finite": finite, "parity": parity},
-                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                             "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
-                             "traffic_source": traffic_src or "none for this configuration: achieved/frac use the compulsory-bytes model",
-                             "traffic_measured_on": traffic_meta,
-                             "model_bytes_per_launch": model_bytes[k_dom],
-                             "traffic_over_model": (traffic / model_bytes[k_dom]) if traffic else None,
-                             "kernel": dom_name, "kernel_avg_ms": dom_ms, "kernel_launches_per_tick": launches,
-                             "kernel_avg_ms_source": ("HIP events over the timed region / launches in it" if region_avg
-                                                      else "HIP-event pair around every launch of an eager tick"),
-                             "kernel_avg_ms_event_pairs": dom_ms_pairs,
-                             "algorithmic_bytes_per_launch": alg_bytes[k_dom],
-                             "algorithmic_GBps": alg_rate, "frac_algorithmic": alg_rate / (HBM_PEAK / 1e9),
-                             "reuse_factor": alg_bytes[k_dom] / hbm_bytes,
-                             "note": "achieved/frac = HBM bytes per launch (PMC FETCH_SIZE/WRITE_SIZE where measured for this "
-                                     "configuration, else the compulsory-bytes model of the uploaded tables) / kernel time, against "
-                                     "8 TB/s. frac_algorithmic uses the SURVEY 8d figure (88 B/particle + 68 B per projected "
-                                     "constraint per mid-tick launch); it exceeds 1 because the tile kernel serves those accesses "
-                                     "from LDS (reuse_factor = algorithmic / HBM bytes)",
-                             "job_algorithmic_GBps": job_alg / 1e9, "job_frac_algorithmic": job_alg / (HBM_PEAK * world),
-                             "B_alg_per_particle_substep": b_alg(N, M) / N,
-                             "tick_ms_hip_events": ev_ms / args.steps,
-                             "per_slot_ms_per_tick": {names[k]: float(slot_ms[k]) for k in range(len(names))},
-                             "per_slot_launches_per_tick": {names[k]: int(slot_cnt[k]) for k in range(len(names))}},
-                "setup_seconds": setup_s, "setup_breakdown": {"mesh_generation": mesh_s, "Start (author + plan + upload)": setup_s - mesh_s},
-                "plan": stats,
-            }
-            if world == 1 and not loopback and not args.no_parity:
-                parity["small"] = small_parity(total_ticks, args, device)
-            if world == 1 and not loopback and not args.no_cpu_baseline:
-                out["cpu_baseline"], live = cpu_baseline(mesh, sb, args)
-                if live is not None:
-                    parity["live"] = live
-    finally:
-        # teardown order: every rank drains its own stream, then all ranks meet, THEN the solvers go -- under the peer transport
-        # sb_destroy frees the mailbox the neighbours' kernels store into (include/softbody.h)
-        try:
-            sb.synchronize()
-        except Exception as e:      # (report, but still meet the other ranks and free the solver)
-            print(f"bench.py: sb_synchronize at teardown: {e}", file=sys.stderr)
-        if dist is not None:
-            dist.barrier()
-        sb.OnDestroy()
+    if world > 1:
+        out = multi_rank(ctx, real_stdout)
+    else:
+        out = single_rank(ctx)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -475,6 +298,487 @@ def main():
     os.dup2(real_stdout, 1)
     if rank == 0:
         print(json.dumps(out), flush=True)
+
+
+def make_solver(ctx, transport="rccl", schedule="auto", sb_world=None, debug_flags=0):
+    """A fresh solver of the workload's mesh for this rank (+ the transport's set-up across the ranks)."""
+    from softbodyunity_amd import Softbody, comm_unique_id
+    args, rank, world, dist, torch, native = ctx["args"], ctx["rank"], ctx["world"], ctx["dist"], ctx["torch"], ctx["native"]
+    peer = transport == "peer"
+    uid = None
+    if world > 1 and not peer:       # (the peer transport needs no RCCL communicator: the mailbox handles travel over gloo below)
+        buf = torch.zeros(128, dtype=torch.uint8)
+        if rank == 0:
+            buf = torch.tensor(list(comm_unique_id()), dtype=torch.uint8)
+        dist.broadcast(buf, src=0)
+        uid = bytes(buf.tolist())
+    if sb_world is None:
+        sb_world = world
+    elif debug_flags & native.SB_DEBUG_LOOPBACK:
+        uid = comm_unique_id()
+    sb = Softbody(ctx["mesh"], substeps=args.substeps, fixed_delta_time=0.02, device=ctx["device"], rank=rank, world=sb_world,
+                  tile_particles=args.tile, use_graph=not args.no_graph, unique_id=uid, plan_flags=0, debug_flags=debug_flags,
+                  halo_transport=native.SB_TRANSPORT_PEER if peer else native.SB_TRANSPORT_RCCL, halo_schedule=SCHEDULES[schedule])
+    sb.Start()
+    return sb
+
+
+def connect_peers(ctx, sb):
+    torch, dist, rank, world = ctx["torch"], ctx["dist"], ctx["rank"], ctx["world"]
+    handles = [torch.zeros(64, dtype=torch.uint8) for _ in range(world)]
+    dist.all_gather(handles, torch.from_numpy(sb.peer_mailbox_handle().copy()))
+    for r in range(world):
+        if r != rank:
+            sb.peer_connect(r, handles[r].numpy())
+    dist.barrier()
+
+
+def make_barrier(ctx, sb):
+    torch, dist = ctx["torch"], ctx["dist"]
+
+    def barrier():
+        sb.synchronize()
+        if torch.cuda.is_available():
+            torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+    return barrier
+
+
+def timed_region(ctx, sb, warmup, steps, sampler=None):
+    """W untimed ticks, then exactly K ticks between barriers (+ synchronize on both sides); max over the ranks."""
+    torch, dist = ctx["torch"], ctx["dist"]
+    barrier = make_barrier(ctx, sb)
+    for _ in range(warmup):
+        sb.step()
+    barrier()
+    t0 = time.perf_counter()
+    sb.profile_begin()
+    for _ in range(steps):
+        sb.step()
+    ev_ms = sb.profile_end()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, ev_ms
+
+
+def golden_leg(ctx, sb, total_ticks):
+    """The state the run ended with against the oracle's golden checksum (ranks add their partial sums)."""
+    from softbodyunity_amd.verify import add_checksums, schedule_hash, state_checksum
+    args, rank, world, dist, mesh = ctx["args"], ctx["rank"], ctx["world"], ctx["dist"], ctx["mesh"]
+    gid = mesh.global_id if ctx["sharded"] else None
+    owned_mask = sb.owner() == rank
+    ids = np.nonzero(owned_mask)[0]
+    x_end = sb.get_positions(); v_end = sb.get_velocities()
+    finite = bool(np.isfinite(x_end[ids]).all())
+    part = state_checksum(x_end[ids], v_end[ids], ids if gid is None else gid[ids])
+    if dist is not None:
+        parts = [None] * world
+        dist.all_gather_object(parts, part)
+        fin = [None] * world
+        dist.all_gather_object(fin, finite)
+        finite = all(fin)
+    else:
+        parts = [part]
+    checksum = add_checksums(parts)
+    golden = _golden_entry(args.n, args.substeps, args.tile, args.heterogeneous)
+    want = golden["ticks"].get(str(total_ticks)) if golden else None
+    out = {"n": args.n ** 3, "checksum": f"0x{checksum:016x}", "expected": want, "bitwise": (int(want, 16) == checksum) if want else None,
+           "source": "tests/golden/state_checksums.json (CPU oracle, tests/golden/make_checksums.py)"}
+    if golden and world == 1 and rank == 0:
+        out["schedule_matches"] = schedule_hash(sb.plan()) == golden["schedule"]
+    return out, finite
+
+
+def sustained_leg(ctx, sb, ms_per_step_hint):
+    """The same tick for >= --sustained-seconds from the initial state, the card's clocks and power sampled over THAT window: the
+    headline region is a fraction of a second, too short for the package power cap to bite (256^3: 20 ticks = 58 ms)."""
+    args, rank, mesh, torch = ctx["args"], ctx["rank"], ctx["mesh"], ctx["torch"]
+    ticks = int(min(max(np.ceil(1e3 * args.sustained_seconds / max(ms_per_step_hint, 1e-3)), args.steps), 20000))
+    if ctx["dist"] is not None:      # every rank the same count
+        t = torch.tensor([ticks], dtype=torch.int64)
+        ctx["dist"].broadcast(t, src=0)
+        ticks = int(t.item())
+    sb.set_state(mesh.pos, mesh.vel)
+    sampler = None
+    if rank == 0 and not args.no_gpu_state:
+        sampler = GpuStateSampler(_pci_bus_id(torch, ctx["device"]) if ctx["n_dev"] > 0 else None).start()
+    elapsed, ev_ms = timed_region(ctx, sb, 2, ticks)
+    state = sampler.stop() if sampler is not None else None
+    if state:
+        state["window"] = "the sustained leg"
+    return {"ticks": ticks, "seconds": elapsed, "ms_per_step": 1e3 * elapsed / ticks, "ms_per_step_hip_events": ev_ms / ticks, "gpu_state": state,
+            "note": "state reset to the initial one, 2 untimed ticks, then `ticks` ticks between barriers"}
+
+
+def exchange_leg(ctx, sb, ticks=3):
+    """Per-exchange HIP-event times of `ticks` extra eager ticks (outside every timed region): pack kernel, transport, the whole exchange,
+    and what the compute stream waited for it."""
+    st = sb.stats()
+    if st["halo_schedule"] not in (1, 3):       # captured schedules: events inside a capture have no host-visible time
+        return None
+    sb.exchange_timing(True)
+    for _ in range(ticks):
+        sb.step()
+    t = sb.exchange_timing_read()
+    sb.exchange_timing(False)
+    n = max(t["exchanges"], 1)
+    return {"exchanges_timed": t["exchanges"], "exchanges_per_tick": t["exchanges"] / ticks, "ticks": ticks,
+            "per_exchange_us": {"pack": 1e3 * t["pack_ms"] / n, "transport": 1e3 * t["transport_ms"] / n, "total": 1e3 * t["total_ms"] / n,
+                                "exposed_wait": 1e3 * t["exposed_wait_ms"] / n}}
+
+
+def teardown(ctx, sb):
+    # teardown order: every rank drains its own stream, then all ranks meet, THEN the solvers go -- under the peer transport
+    # sb_destroy frees the mailbox the neighbours' kernels store into (include/softbody.h)
+    try:
+        sb.synchronize()
+    except Exception as e:      # (report, but still meet the other ranks and free the solver)
+        print(f"bench.py: sb_synchronize at teardown: {e}", file=sys.stderr)
+    if ctx["dist"] is not None:
+        ctx["dist"].barrier()
+    sb.OnDestroy()
+
+
+def all_ok(ctx, ok, msg=""):
+    """Every rank learns whether every rank got through a phase (a variant that fails on one rank is abandoned by all, together)."""
+    dist = ctx["dist"]
+    if dist is None:
+        return ok, [msg] if msg else []
+    got = [None] * ctx["world"]
+    dist.all_gather_object(got, (bool(ok), msg))
+    return all(g[0] for g in got), [f"rank {r}: {g[1]}" for r, g in enumerate(got) if not g[0]]
+
+
+def run_variant(ctx, name, transport, schedule, steps, warmup, is_default):
+    """One (transport, schedule) pair on a fresh solver of the same inputs: timed region, golden checksum, exchange timing."""
+    args, rank, world, native = ctx["args"], ctx["rank"], ctx["world"], ctx["native"]
+    rec = {"name": name, "transport": transport, "schedule_requested": schedule}
+    sb, err = None, ""
+    t0 = time.time()
+    try:
+        sb = make_solver(ctx, transport, schedule)
+    except Exception as e:       # refused (SB_ERR_UNSUPPORTED), RCCL could not form the communicator, ...
+        err = f"{type(e).__name__}: {e}"
+    ok, errs = all_ok(ctx, sb is not None, err)
+    if not ok:
+        if sb is not None:
+            sb.OnDestroy()
+        rec["error"] = "; ".join(errs)[:600]
+        return rec, None
+    result = None
+    try:
+        if transport == "peer":
+            connect_peers(ctx, sb)
+        stats = sb.stats()
+        rec["schedule"] = SCHEDULE_NAMES.get(stats["halo_schedule"])
+        rec["setup_seconds"] = time.time() - t0
+        sampler = None
+        if is_default and rank == 0 and not args.no_gpu_state:
+            sampler = GpuStateSampler(_pci_bus_id(ctx["torch"], ctx["device"]) if ctx["n_dev"] > 0 else None).start()
+        elapsed, ev_ms = timed_region(ctx, sb, warmup, steps)
+        gpu_state = sampler.stop() if sampler is not None else None
+        N = args.n ** 3
+        rec.update({"steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "value": N * args.substeps * steps / elapsed,
+                    "tick_ms_hip_events_rank0": ev_ms / steps})
+        if not args.no_parity:
+            g, finite = golden_leg(ctx, sb, warmup + steps)
+            rec["golden"] = {"checksum": g["checksum"], "expected": g["expected"], "bitwise": g["bitwise"]}
+            rec["finite"] = finite
+        else:
+            g, finite = None, None
+        ex = exchange_leg(ctx, sb)
+        if ctx["dist"] is not None:
+            allx = [None] * world
+            ctx["dist"].all_gather_object(allx, ex)
+            if ex is not None:
+                keys = ("pack", "transport", "total", "exposed_wait")
+                ex = dict(ex, per_exchange_us_max_over_ranks={k: max(a["per_exchange_us"][k] for a in allx if a) for k in keys},
+                          per_exchange_us_rank0=ex["per_exchange_us"])
+                ex.pop("per_exchange_us")
+        rec["exchange"] = ex
+        result = dict(sb=sb, stats=stats, elapsed=elapsed, ev_ms=ev_ms, golden=g, finite=finite, gpu_state=gpu_state)
+    except Exception as e:
+        err = f"{type(e).__name__}: {e}"
+    ok, errs = all_ok(ctx, result is not None, err)
+    if not ok:
+        rec["error"] = "; ".join(errs)[:600]
+        try:
+            teardown(ctx, sb)
+        except Exception as e:
+            print(f"bench.py: teardown of variant {name}: {e}", file=sys.stderr)
+        return rec, None
+    return rec, result
+
+
+def multi_rank(ctx, real_stdout):
+    """--gpus N > 1: the default variant gives `value`; every other admitted (transport, schedule) pair follows in the same launch."""
+    args, rank, world, dist, native, mesh = ctx["args"], ctx["rank"], ctx["world"], ctx["dist"], ctx["native"], ctx["mesh"]
+    runtime = native.runtime_info()
+    words = LastWords(real_stdout, native) if rank == 0 else None
+    N = args.n ** 3
+    M = 3 * args.n * args.n * (args.n - 1)
+    default_name = f"{args.transport}/{args.schedule}"
+    if words:
+        words.arm(4 * args.variant_timeout, "the default variant (set-up included)")
+    rec, res = run_variant(ctx, default_name, args.transport, args.schedule, args.steps, args.warmup, True)
+    if res is None:
+        raise SystemExit(f"bench.py: the default variant {default_name} failed: {rec.get('error')}")
+    sb, stats = res["sb"], res["stats"]
+    setup_s = time.time() - ctx["t_setup"]
+    # per-kernel HIP-event timing on the solver's stream: two extra eager ticks, outside the timed region
+    slot_ms, slot_cnt = profiled_ticks(sb, 2)
+    parity = {"ticks": args.warmup + args.steps}
+    if res["golden"] is not None:
+        parity["golden"] = res["golden"]
+    if not args.no_parity:
+        rep = sb.validate()
+        parity["tables"] = {"constraints_checked": rep["constraints_checked"], "tiles_checked": rep["tiles_checked"], "errors": rep["errors"],
+                            "clean": rep["errors"] == [0] * 6}
+    finite = res["finite"] if res["finite"] is not None else bool(np.isfinite(sb.get_positions()[sb.owner() == rank]).all())
+    parity["finite"] = finite
+    per_rank = [None] * world
+    dist.all_gather_object(per_rank, {"rank": rank, "owned": stats["n_particles_owned"], "ghosts": stats["n_particles_local"] - stats["n_particles_owned"],
+                                      "halo_peers": stats["halo_peers"], "halo_particles_sent_per_exchange": stats["halo_particles_t1"],
+                                      "halo_particles_recv_per_exchange": stats["halo_particles_recv"], "tiles": stats["n_tiles"],
+                                      "lane_packed_tiles": stats["lane_packed_tiles"], "device_bytes": stats["device_bytes"]})
+    sustained = None
+    if not args.no_sustained:
+        sustained = sustained_leg(ctx, sb, rec["ms_per_step"])
+    out = None
+    if rank == 0:
+        out = build_line(ctx, sb, stats, res["elapsed"], res["ev_ms"], slot_ms, slot_cnt, parity, finite, res["gpu_state"], runtime, setup_s, False, N, M)
+        out["config"]["halo_transport"] = args.transport
+        if sustained:
+            out["sustained_ms_per_step"] = sustained["ms_per_step"]
+            out["config"]["sustained"] = sustained
+        out["config"]["schedule_ab"] = {"default": default_name, "variants": [rec], "per_rank": per_rank,
+                                        "note": "every variant: fresh solver, same mesh windows, same warmup/steps protocol (barrier + synchronize on both sides, "
+                                                "max over ranks), then the golden-checksum check; per-exchange times are HIP events of 3 extra eager ticks"}
+        words.stash(out)
+    teardown(ctx, sb)
+    if not args.no_ab:
+        # safest first: what only differs in launch order, then captured RCCL calls, last the transport that has never run between two devices
+        plan = [("rccl", "serial-eager"), ("rccl", "overlap-eager")]
+        if runtime["capture_serial_ok"] and not args.no_graph:
+            plan.append(("rccl", "serial-graph"))
+        if runtime["capture_overlap_ok"] and not args.no_graph:
+            plan.append(("rccl", "overlap-graph"))
+        plan += [("peer", "serial-eager")] + ([("peer", "serial-graph")] if not args.no_graph else [])
+        resolved_default = (args.transport, rec.get("schedule"))
+        ab_steps = args.ab_steps or args.steps
+        for transport, schedule in plan:
+            name = f"{transport}/{schedule}"
+            if (transport, schedule) == resolved_default or name == default_name:
+                if rank == 0:
+                    out["config"]["schedule_ab"]["variants"].append({"name": name, "same_as": default_name})
+                continue
+            if words:
+                words.arm(args.variant_timeout, f"variant {name}")
+            vrec, vres = run_variant(ctx, name, transport, schedule, ab_steps, args.warmup, False)
+            if vres is not None:
+                teardown(ctx, vres["sb"])
+            if rank == 0:
+                out["config"]["schedule_ab"]["variants"].append(vrec)
+                ok = [v for v in out["config"]["schedule_ab"]["variants"] if "value" in v and (v.get("golden") or {}).get("bitwise") is not False]
+                best = max(ok, key=lambda v: v["value"])
+                out["config"]["schedule_ab"]["fastest_verified"] = {"name": best["name"], "ms_per_step": best["ms_per_step"], "value": best["value"]}
+                words.stash(out)
+        if words:
+            words.disarm()
+    if words:
+        words.clear()
+    return out
+
+
+def profiled_ticks(sb, prof_ticks=2):
+    slot_ms = None
+    for _ in range(prof_ticks):
+        ms, cnt = sb.step_profiled()
+        slot_ms = ms.astype(np.float64) if slot_ms is None else slot_ms + ms
+        slot_cnt = cnt
+    return slot_ms / prof_ticks, slot_cnt
+
+
+def single_rank(ctx):
+    args, rank, native, mesh, torch = ctx["args"], ctx["rank"], ctx["native"], ctx["mesh"], ctx["torch"]
+    loopback = args.loopback_world > 1
+    runtime = native.runtime_info() if loopback else None
+    N = args.n ** 3
+    M = 3 * args.n * args.n * (args.n - 1)
+    if loopback:
+        sb = make_solver(ctx, args.transport, args.schedule, sb_world=args.loopback_world, debug_flags=native.SB_DEBUG_LOOPBACK)
+    else:
+        sb = make_solver(ctx)
+    out = None
+    try:
+        stats = sb.stats()
+        setup_s = time.time() - ctx["t_setup"]
+        sampler = None
+        if not args.no_gpu_state:
+            sampler = GpuStateSampler(_pci_bus_id(torch, ctx["device"]) if ctx["n_dev"] > 0 else None).start()
+        elapsed, ev_ms = timed_region(ctx, sb, args.warmup, args.steps)
+        gpu_state = sampler.stop() if sampler is not None else None
+
+        # ---- self-verification, leg 1: the state the timed run ended with, against the oracle's golden checksum ------
+        total_ticks = args.warmup + args.steps
+        parity = {"ticks": total_ticks}
+        if not args.no_parity and not loopback:
+            parity["golden"], finite = golden_leg(ctx, sb, total_ticks)
+        else:
+            finite = bool(np.isfinite(sb.get_positions()[sb.owner() == rank]).all())
+        # the tables the timed launches read, re-read by the validator kernel (sb_debug_validate): a group or a launch that touched a
+        # particle twice would be a race, whatever the state looks like
+        if not args.no_parity:
+            rep = sb.validate()
+            parity["tables"] = {"constraints_checked": rep["constraints_checked"], "tiles_checked": rep["tiles_checked"], "errors": rep["errors"],
+                                "clean": rep["errors"] == [0] * 6}
+        slot_ms, slot_cnt = profiled_ticks(sb, 2)
+        if loopback:
+            N = int(stats["n_particles_owned"])      # diagnostic mode: only this rank's share is simulated
+        out = build_line(ctx, sb, stats, elapsed, ev_ms, slot_ms, slot_cnt, parity, finite, gpu_state, runtime, setup_s, loopback, N, M)
+        if loopback:
+            out["config"]["halo_transport"] = args.transport
+            out["config"]["exchange"] = exchange_leg(ctx, sb)
+        if not loopback and not args.no_parity:
+            parity["small"] = small_parity(total_ticks, args, ctx["device"])
+        if not loopback and not args.no_cpu_baseline:
+            out["cpu_baseline"], live = cpu_baseline(mesh, sb, args)
+            if live is not None:
+                parity["live"] = live
+        if not args.no_sustained and not loopback:
+            sus = sustained_leg(ctx, sb, out["ms_per_step"])
+            out["sustained_ms_per_step"] = sus["ms_per_step"]
+            out["config"]["sustained"] = sus
+    finally:
+        teardown(ctx, sb)
+    return out
+
+
+def build_line(ctx, sb, stats, elapsed, ev_ms, slot_ms, slot_cnt, parity, finite, gpu_state, runtime, setup_s, loopback, N, M):
+    """The JSON line of the contract from one measured solver (rank 0)."""
+    args, world, sharded = ctx["args"], ctx["world"], ctx["sharded"]
+    value = N * args.substeps * args.steps / elapsed
+    ms_per_step = 1e3 * elapsed / args.steps
+    G = stats["n_global_colours"]
+    owned = stats["n_particles_owned"]
+    names = ["tile_kernel<1> on T0 (rounds + collide/velocity/integrate + rounds)",
+             "tile_kernel<1> on T1 (rounds + collide/velocity/integrate + rounds)"]
+    names += [f"global colour {c}" for c in range(G)]
+    names += ["tile_kernel<0> (first kernel of a tick)", "tile_kernel<2> (last kernel of a tick)",
+              "tile_kernel<3> on the T2 layers (constraints inside neither T0 nor T1)"]
+    # ALGORITHMIC bytes per launch (SURVEY.md §8d): a mid-tick tile kernel does one velocity update (36 B)
+    # + one integrate (52 B) per particle and projects every constraint it stores TWICE (before and after
+    # the MARK step: the tail of one substep and the head of the next), 68 B each time
+    alg_bytes = [88.0 * owned + 2 * 68.0 * stats["tile_constraints"][t] for t in (0, 1)]
+    # compulsory HBM bytes per launch from the tables actually uploaded (sb_get_stats): the model the PMC figure is checked against
+    lb = stats["launch_bytes"]
+    model_bytes = [float(lb[0]), float(lb[1])]
+    mask0 = None
+    for c in range(G):
+        if mask0 is None:
+            plan = sb.plan(); mask0 = plan.local_order_mask(0).astype(bool); ph0 = [p for p in plan.phases(0) if p["kind"] == 0]
+        cnt_c = int(mask0[ph0[c]["order_begin"]:ph0[c]["order_end"]].sum())
+        alg_bytes.append(68.0 * cnt_c)
+        model_bytes.append(68.0 * cnt_c)      # global colours gather/scatter straight on HBM: no on-chip reuse to model
+    last = (args.substeps & 1) if stats["n_tilings"] == 2 else 0
+    alg_bytes += [52.0 * owned + 68.0 * stats["tile_constraints"][0], 36.0 * owned + 68.0 * stats["tile_constraints"][last]]
+    alg_bytes.append(68.0 * stats["t2_constraints"])
+    model_bytes += [float(lb[2]), float(lb[3]) if last == 0 else float(lb[1] - (lb[0] - lb[3])), float(lb[4])]
+    k_dom = int(np.argmax(slot_ms))
+    launches = max(int(slot_cnt[k_dom]), 1)
+    dom_ms = float(slot_ms[k_dom]) / launches          # HIP-event pair around every launch of an eager tick
+    dom_ms_pairs = dom_ms
+    # When the timed region consists of launches of ONE kernel only -- the lattice workloads: tile_kernel<1>, T0 and T1
+    # launches alternating, `substeps` of them per tick once the lazy tick boundary has fused the first and last kernels --
+    # its average launch duration is the HIP-event time of the timed region itself divided by the launches in it (the
+    # event pairs of the eager ticks add ~4 % of dispatch gap per launch).
+    region_avg = (world == 1 and not loopback and not args.no_graph and G == 0 and stats["n_t2_layers"] == 0
+                  and stats["n_tilings"] == 2 and args.substeps % 2 == 0 and k_dom in (0, 1) and args.steps >= 2)
+    if region_avg:
+        dom_ms = ev_ms / (args.steps * args.substeps)
+        launches = args.substeps
+        for arr in (alg_bytes, model_bytes):
+            arr[0] = arr[1] = 0.5 * (arr[0] + arr[1])
+        dom_name = "tile_kernel<1>, mid-tick (rounds + collide/velocity/integrate + rounds), T0 and T1 launches alternating"
+    else:
+        dom_name = names[k_dom]
+    # HBM traffic per launch of the dominant kernel: PMC counters (profiles/hbm_traffic.json, produced by
+    # tools/prof_summary.py from separate FETCH_SIZE / WRITE_SIZE passes) -- accepted only when within 3 % of the
+    # compulsory-bytes model of THIS build's tables, so the file cannot go stale unnoticed
+    traffic, traffic_src, traffic_meta = None, None, None
+    key = f"n{args.n}{'het' if args.heterogeneous else ''}_tile{args.tile}_gpus{world}"
+    tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+    tj = json.load(open(tpath)) if os.path.exists(tpath) else {}
+    problem = None
+    if not loopback and key in tj and str(k_dom) in tj[key]:
+        traffic = float(tj[key][str(k_dom)])
+        if region_avg and "0" in tj[key] and "1" in tj[key]:
+            traffic = 0.5 * (float(tj[key]["0"]) + float(tj[key]["1"]))     # the two launch shapes alternate
+        traffic_meta = tj[key].get("meta")
+        dev = abs(traffic - model_bytes[k_dom]) / model_bytes[k_dom]
+        if dev > 0.03:    # the entry was measured on another kernel / data layout: say so, use the model
+            problem = (f"profiles/hbm_traffic.json[{key}][{k_dom}] = {traffic:.4g} B disagrees with the compulsory-bytes model "
+                       f"{model_bytes[k_dom]:.4g} B of this build by {100 * dev:.1f} %: re-measure (tools/profile_round.sh)")
+            traffic_src = f"stale ({100 * dev:.1f} % off the model of this build's tables): achieved/frac use the compulsory-bytes model"
+            traffic = None
+        else:
+            traffic_src = "pmc"
+    elif args.n == 256 and args.tile == 512 and world == 1 and not loopback:
+        problem = f"profiles/hbm_traffic.json has no PMC entry for {key} slot {k_dom}"
+    if problem:
+        if args.strict_traffic:
+            raise RuntimeError("bench.py: " + problem)
+        print("WARNING: " + problem, file=sys.stderr)
+    hbm_bytes = traffic if traffic is not None else model_bytes[k_dom]
+    achieved = hbm_bytes / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    alg_rate = alg_bytes[k_dom] / (dom_ms * 1e-3) / 1e9 if dom_ms > 0 else 0.0
+    job_alg = b_alg(N, M) * value / N   # algorithmic B/s of the whole job
+    parity["finite"] = finite
+    mesh_s = ctx["mesh_s"]
+    return {
+        "metric": "particle-substeps/sec", "value": value, "unit": "particle-substeps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms_per_step,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.n}^3 jelly cube, structural springs (N={N}, M={M}), {args.substeps} substeps/tick, "
+                               f"dt=0.02, explicit index-array graph, tile_particles={args.tile}" +
+                               (", HETEROGENEOUS masses and rest lengths (4-byte inverse masses, 8-byte constraint slots)" if args.heterogeneous else ""),
+                   "partition": "x".join(str(d) for d in _dims(world)), "graph_replay": (not args.no_graph) and (world == 1 or stats["halo_schedule"] in (2, 4)),
+                   "authoring": ("sharded: each rank hands over and plans its window only (sb_set_domain)" if sharded else "whole mesh on every rank"),
+                   "halo_transport": None,
+                   "halo_schedule": SCHEDULE_NAMES.get(stats["halo_schedule"]) if (world > 1 or loopback) else None,
+                   "runtime": runtime, "gpu_state": gpu_state,
+                   "finite": finite, "parity": parity},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                     "frac": achieved / (HBM_PEAK / 1e9), "traffic": traffic,
+                     "traffic_source": traffic_src or "none for this configuration: achieved/frac use the compulsory-bytes model",
+                     "traffic_measured_on": traffic_meta,
+                     "model_bytes_per_launch": model_bytes[k_dom],
+                     "traffic_over_model": (traffic / model_bytes[k_dom]) if traffic else None,
+                     "kernel": dom_name, "kernel_avg_ms": dom_ms, "kernel_launches_per_tick": launches,
+                     "kernel_avg_ms_source": ("HIP events over the timed region / launches in it" if region_avg
+                                              else "HIP-event pair around every launch of an eager tick"),
+                     "kernel_avg_ms_event_pairs": dom_ms_pairs,
+                     "algorithmic_bytes_per_launch": alg_bytes[k_dom],
+                     "algorithmic_GBps": alg_rate, "frac_algorithmic": alg_rate / (HBM_PEAK / 1e9),
+                     "reuse_factor": alg_bytes[k_dom] / hbm_bytes,
+                     "note": "achieved/frac = HBM bytes per launch (PMC FETCH_SIZE/WRITE_SIZE where measured for this "
+                             "configuration, else the compulsory-bytes model of the uploaded tables) / kernel time, against "
+                             "8 TB/s. frac_algorithmic uses the SURVEY 8d figure (88 B/particle + 68 B per projected "
+                             "constraint per mid-tick launch); it exceeds 1 because the tile kernel serves those accesses "
+                             "from LDS (reuse_factor = algorithmic / HBM bytes)",
+                     "job_algorithmic_GBps": job_alg / 1e9, "job_frac_algorithmic": job_alg / (HBM_PEAK * world),
+                     "B_alg_per_particle_substep": b_alg(N, M) / N,
+                     "tick_ms_hip_events": ev_ms / args.steps,
+                     "per_slot_ms_per_tick": {names[k]: float(slot_ms[k]) for k in range(len(names))},
+                     "per_slot_launches_per_tick": {names[k]: int(slot_cnt[k]) for k in range(len(names))}},
+        "setup_seconds": setup_s, "setup_breakdown": {"mesh_generation": mesh_s, "Start (author + plan + upload)": setup_s - mesh_s},
+        "plan": stats,
+    }
 
 
 def _dims(world):

@@ -1,9 +1,14 @@
 // Softbody.cs — the Unity component whose FixedUpdate path this repository accelerates.
 //
-// Start()       -> sb_create + sb_set_particles/sb_set_*_constraints + sb_finalize   (plan, upload, capture)
-// FixedUpdate() -> sb_step(Time.fixedDeltaTime, substeps) + sb_get_positions         (one tick, SPEC.md §2)
-//                  asyncReadback: sb_readback_begin/end + GPU vertex normals instead (one tick of latency, no stall)
-// OnDestroy()   -> sb_destroy
+// Start()       -> sb_group_create + sb_group_set_particles/sb_group_set_*_constraints + sb_group_finalize   (plan, partition, upload)
+// FixedUpdate() -> sb_group_step(Time.fixedDeltaTime, substeps) + sb_group_get_positions                     (one tick, SPEC.md §2)
+//                  asyncReadback: sb_group_readback_begin/end + GPU vertex normals instead (one tick of latency, no stall)
+// OnDestroy()   -> sb_group_destroy
+//
+// A Unity player is ONE process: the component talks to the plugin through include/softbody_group.h, where `deviceCount` GPUs sit
+// behind one handle (the mesh authored once, one call per tick, positions gathered in the component's numbering); deviceCount = 1 is
+// a plain single-GPU solver behind the same calls. (The per-rank entry points of softbody.h -- sb_create with rank / world,
+// sb_comm_init -- are what a one-process-per-GPU job uses: bench.py.)
 //
 // `useGpu = false` never creates a solver handle and needs no GPU: the schedule comes from the host-only
 // planner (sb_plan_build / sb_plan_get_order / sb_plan_destroy) and the tick runs in SoftbodyCpuSolver (the C#
@@ -34,7 +39,14 @@ namespace SoftbodyMI355X
         [SerializeField] float groundOffset = 0f;
         [Header("Device")]
         [SerializeField] bool useGpu = true;
+        [Tooltip("First HIP device ordinal; with deviceCount > 1 the body is split spatially over devices device .. device + deviceCount - 1.")]
         [SerializeField] int device = 0;
+        [Tooltip("GPUs of this node the body is partitioned over (1, 2, 4, 8): ghost particles travel over xGMI every substep (RCCL).")]
+        [SerializeField] int deviceCount = 1;
+        [Tooltip("Ghost exchange between the GPUs: 0 = RCCL send/recv (default), 1 = peer-store mailboxes (SoftbodyNative.Transport*).")]
+        [SerializeField] int haloTransport = SoftbodyNative.TransportRccl;
+        [Tooltip("Hand every GPU only its block of a lattice-like mesh (block partition) instead of letting every GPU plan the whole mesh.")]
+        [SerializeField] bool blockPartition = false;
         [Tooltip("Target particles per LDS tile; 0 = automatic (512, or 256 when the mesh has volume or bending constraints).")]
         [SerializeField] int tileParticles = 0;
         [Tooltip("Render from the previous tick's snapshot: the D2H copy and the normals (computed on the GPU) overlap the next tick.")]
@@ -99,37 +111,41 @@ namespace SoftbodyMI355X
 
             var d = new SbDesc();
             SoftbodyNative.sb_desc_default(ref d);
-            d.device = device; d.rank = 0; d.world = 1;
+            // (device / rank / world of the descriptor are filled in per GPU by the group)
             d.gravityX = gravity.x; d.gravityY = gravity.y; d.gravityZ = gravity.z;
             d.damping = damping; d.tileParticles = tileParticles;
-            SoftbodyNative.Check(SoftbodyNative.sb_create(ref d, out handle), "sb_create");
+            d.haloTransport = haloTransport;
+            d.partition = blockPartition ? SoftbodyNative.PartitionBlocks : SoftbodyNative.PartitionAuto;
+            var devices = new int[Math.Max(deviceCount, 1)];
+            for (int r = 0; r < devices.Length; ++r) devices[r] = device + r;
+            SoftbodyNative.Check(SoftbodyNative.sb_group_create(ref d, devices, devices.Length, 0, out handle), "sb_group_create");
 
             // Vector3 is a blittable sequential struct of 3 floats: Vector3[] pins directly to float xyz
             Pin(positions, p => Pin(velocities, v => Pin(inverseMass, w =>
-                SoftbodyNative.Check(SoftbodyNative.sb_set_particles(handle, p, v, w, n), "sb_set_particles"))));
+                SoftbodyNative.Check(SoftbodyNative.sb_group_set_particles(handle, p, v, w, n), "sb_group_set_particles"))));
             if (restPositions != null)
-                Pin(restPositions, r => SoftbodyNative.Check(SoftbodyNative.sb_set_rest_positions(handle, r, n), "sb_set_rest_positions"));
+                Pin(restPositions, r => SoftbodyNative.Check(SoftbodyNative.sb_group_set_rest_positions(handle, r, n), "sb_group_set_rest_positions"));
             if (distanceRest != null && distanceRest.Length > 0)
                 Pin(distanceIJ, i => Pin(distanceRest, r => SoftbodyNative.Check(
-                    SoftbodyNative.sb_set_distance_constraints(handle, i, r, distanceRest.Length, distanceCompliance), "sb_set_distance_constraints")));
+                    SoftbodyNative.sb_group_set_distance_constraints(handle, i, r, distanceRest.Length, distanceCompliance), "sb_group_set_distance_constraints")));
             if (volumeRest != null && volumeRest.Length > 0)
                 Pin(volumeIJKL, i => Pin(volumeRest, r => SoftbodyNative.Check(
-                    SoftbodyNative.sb_set_volume_constraints(handle, i, r, volumeRest.Length, volumeCompliance), "sb_set_volume_constraints")));
+                    SoftbodyNative.sb_group_set_volume_constraints(handle, i, r, volumeRest.Length, volumeCompliance), "sb_group_set_volume_constraints")));
             if (bendingRestCosSin != null && bendingRestCosSin.Length > 0)
                 Pin(bendingIJKL, i => Pin(bendingRestCosSin, r => SoftbodyNative.Check(
-                    SoftbodyNative.sb_set_bending_constraints(handle, i, r, bendingRestCosSin.Length / 2, bendingCompliance), "sb_set_bending_constraints")));
+                    SoftbodyNative.sb_group_set_bending_constraints(handle, i, r, bendingRestCosSin.Length / 2, bendingCompliance), "sb_group_set_bending_constraints")));
             if (groundPlane)
-                SoftbodyNative.Check(SoftbodyNative.sb_set_ground_plane(handle, groundNormal.x, groundNormal.y, groundNormal.z, groundOffset, 1), "sb_set_ground_plane");
-            SoftbodyNative.Check(SoftbodyNative.sb_finalize(handle), "sb_finalize");
+                SoftbodyNative.Check(SoftbodyNative.sb_group_set_ground_plane(handle, groundNormal.x, groundNormal.y, groundNormal.z, groundOffset, 1), "sb_group_set_ground_plane");
+            SoftbodyNative.Check(SoftbodyNative.sb_group_finalize(handle), "sb_group_finalize");
             posPin = GCHandle.Alloc(positions, GCHandleType.Pinned);
             if (asyncReadback && renderTriangles != null && renderTriangles.Length >= 3)
             {
-                SoftbodyNative.Check(SoftbodyNative.sb_set_render_triangles(handle, renderTriangles, renderTriangles.Length / 3), "sb_set_render_triangles");
+                SoftbodyNative.Check(SoftbodyNative.sb_group_set_render_triangles(handle, renderTriangles, renderTriangles.Length / 3), "sb_group_set_render_triangles");
                 normals = new Vector3[positions.Length];
                 if (renderSetOnly)
                 {
                     // the plugin's render set = the particles the triangles use, ascending: rebuild the mesh over exactly that set
-                    SoftbodyNative.Check(SoftbodyNative.sb_set_readback_render_set_only(handle, 1), "sb_set_readback_render_set_only");
+                    SoftbodyNative.Check(SoftbodyNative.sb_group_set_readback_render_set_only(handle, 1), "sb_group_set_readback_render_set_only");
                     var used = new System.Collections.Generic.SortedSet<int>(renderTriangles);
                     var compactOf = new System.Collections.Generic.Dictionary<int, int>();
                     var compactPos = new Vector3[used.Count];
@@ -150,15 +166,15 @@ namespace SoftbodyMI355X
             {
                 // show the snapshot taken after the PREVIOUS tick (its copy and its normals ran beside this tick's kernels),
                 // then queue this tick's snapshot: the main thread never waits for the GPU to finish a tick
-                SoftbodyNative.Check(SoftbodyNative.sb_step(handle, Time.fixedDeltaTime, substeps), "sb_step");
-                SoftbodyNative.Check(SoftbodyNative.sb_readback_begin(handle), "sb_readback_begin");
+                SoftbodyNative.Check(SoftbodyNative.sb_group_step(handle, Time.fixedDeltaTime, substeps), "sb_group_step");
+                SoftbodyNative.Check(SoftbodyNative.sb_group_readback_begin(handle), "sb_group_readback_begin");
                 if (snapshotPending)
                 {
-                    SoftbodyNative.Check(SoftbodyNative.sb_readback_end(handle, out IntPtr pos), "sb_readback_end");
+                    SoftbodyNative.Check(SoftbodyNative.sb_group_readback_end(handle, out IntPtr pos), "sb_group_readback_end");
                     CopyVectors(pos, positions);
                     if (normals != null)
                     {
-                        SoftbodyNative.Check(SoftbodyNative.sb_readback_get_normals(handle, out IntPtr nrm), "sb_readback_get_normals");
+                        SoftbodyNative.Check(SoftbodyNative.sb_group_readback_get_normals(handle, out IntPtr nrm), "sb_group_readback_get_normals");
                         CopyVectors(nrm, normals);
                     }
                 }
@@ -169,8 +185,8 @@ namespace SoftbodyMI355X
             }
             if (useGpu)
             {
-                SoftbodyNative.Check(SoftbodyNative.sb_step(handle, Time.fixedDeltaTime, substeps), "sb_step");
-                SoftbodyNative.Check(SoftbodyNative.sb_get_positions(handle, posPin.AddrOfPinnedObject(), positions.Length), "sb_get_positions");
+                SoftbodyNative.Check(SoftbodyNative.sb_group_step(handle, Time.fixedDeltaTime, substeps), "sb_group_step");
+                SoftbodyNative.Check(SoftbodyNative.sb_group_get_positions(handle, posPin.AddrOfPinnedObject(), positions.Length), "sb_group_get_positions");
             }
             else
             {
@@ -183,11 +199,11 @@ namespace SoftbodyMI355X
         void OnDestroy()
         {
             if (posPin.IsAllocated) posPin.Free();
-            if (handle != IntPtr.Zero) { SoftbodyNative.sb_destroy(handle); handle = IntPtr.Zero; }
+            if (handle != IntPtr.Zero) { SoftbodyNative.sb_group_destroy(handle); handle = IntPtr.Zero; }
         }
 
         /// <summary>Attachments: move pinned particles (inverse mass 0) to new positions before the next FixedUpdate; their constrained
-        /// neighbours are pulled along (SPEC.md 2, sb_set_kinematic_positions). ids index the particle arrays.</summary>
+        /// neighbours are pulled along (SPEC.md 2, sb_group_set_kinematic_positions: every GPU takes the pins it owns). ids index the particle arrays.</summary>
         public void MoveKinematic(int[] ids, Vector3[] targets)
         {
             if (ids.Length != targets.Length) throw new ArgumentException("ids and targets differ in length");
@@ -203,7 +219,7 @@ namespace SoftbodyMI355X
             }
             Pin(ids, pi => Pin(targets, pt =>
             {
-                int rc = SoftbodyNative.sb_set_kinematic_positions(handle, pi, pt, ids.Length);
+                int rc = SoftbodyNative.sb_group_set_kinematic_positions(handle, pi, pt, ids.Length);
                 if (rc != 0) throw new InvalidOperationException(SoftbodyNative.LastError());
             }));
         }
@@ -215,9 +231,16 @@ namespace SoftbodyMI355X
         {
             report = default(SbValidateReport);
             if (handle == IntPtr.Zero) return true;          // CPU branch: nothing uploaded
-            int rc = SoftbodyNative.sb_debug_validate(handle, 0, out report);
-            if (rc != 0) throw new InvalidOperationException(SoftbodyNative.LastError());
-            return report.errors0 + report.errors1 + report.errors2 + report.errors3 + report.errors4 + report.errors5 == 0;
+            bool clean = true;
+            for (int r = 0; r < SoftbodyNative.sb_group_rank_count(handle); ++r)       // every GPU's tables
+            {
+                SoftbodyNative.Check(SoftbodyNative.sb_group_get_rank(handle, r, out IntPtr solver), "sb_group_get_rank");
+                int rc = SoftbodyNative.sb_debug_validate(solver, 0, out report);
+                if (rc != 0) throw new InvalidOperationException(SoftbodyNative.LastError());
+                clean &= report.errors0 + report.errors1 + report.errors2 + report.errors3 + report.errors4 + report.errors5 == 0;
+                if (!clean) break;
+            }
+            return clean;
         }
 
         // accessors for SoftbodyCpuSolver

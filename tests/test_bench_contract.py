@@ -39,6 +39,8 @@ def test_bench_json_line_contract():
     assert p["ticks"] == 4 and p["finite"] is True
     assert p["small"]["bitwise"] is True and p["small"]["rel"] == 0.0 and p["small"]["ticks"] == 4
     assert p["golden"]["expected"] is None          # no golden entry for a 32^3 cube
+    # the sustained figure: the same tick for >= 2 s from the initial state, the card's state sampled over that window
+    assert j["sustained_ms_per_step"] > 0 and j["config"]["sustained"]["seconds"] >= 1.9 and j["config"]["sustained"]["ticks"] >= 3
     c = j["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in c, k
@@ -71,7 +73,7 @@ def test_bench_multi_rank_launch_on_one_gpu_through_the_peer_transport(het):
     port = 29700 + os.getpid() % 200 + (200 if het else 0)
     out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "peer", "--cube-edge", "64",
-                          "--steps", "4", "--warmup", "2"] + (["--heterogeneous"] if het else []), capture_output=True, text=True, timeout=900, env=env)
+                          "--steps", "4", "--warmup", "2", "--no-ab"] + (["--heterogeneous"] if het else []), capture_output=True, text=True, timeout=900, env=env)
     assert out.returncode == 0, out.stderr[-3000:]
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
     assert len(lines) == 1, out.stdout[-2000:]
@@ -81,6 +83,47 @@ def test_bench_multi_rank_launch_on_one_gpu_through_the_peer_transport(het):
     g = j["config"]["parity"]["golden"]
     assert g["n"] == 64 ** 3 and g["bitwise"] is True and g["expected"] is not None
     assert j["config"]["finite"] is True and j["value"] > 0 and "cpu_baseline" not in j
+
+
+@pytest.mark.gpu
+def test_bench_multi_rank_times_every_admitted_schedule_in_one_launch():
+    # The one launch a multi-GPU node makes must be decisive: `value` is the default variant's figure, and config.schedule_ab carries every
+    # other admitted (transport, schedule) pair, each on a fresh solver of the same inputs, each verified on the golden checksum, with
+    # per-exchange HIP-event times and per-rank owned / ghost counts. A variant that cannot run is reported, never fatal: on this box's ONE
+    # GPU RCCL refuses two ranks on a device, so the RCCL variants carry an error and the peer-store ones the numbers.
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    port = 29950 + os.getpid() % 40
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "peer", "--cube-edge", "64",
+                          "--steps", "4", "--warmup", "2", "--sustained-seconds", "0.3"], capture_output=True, text=True, timeout=1200, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    ab = j["config"]["schedule_ab"]
+    v = {x["name"]: x for x in ab["variants"]}
+    assert ab["default"] == "peer/auto" and ab["variants"][0]["name"] == "peer/auto"
+    assert {"rccl/serial-eager", "rccl/overlap-eager", "peer/serial-eager", "peer/serial-graph"} <= set(v)
+    d = v["peer/auto"]
+    assert d["schedule"] == "serial-eager" and abs(d["value"] - j["value"]) / j["value"] < 1e-9 and abs(d["ms_per_step"] - j["ms_per_step"]) < 1e-9
+    assert v["peer/serial-eager"].get("same_as") == "peer/auto"             # what AUTO resolves to is not timed twice
+    measured = [x for x in ab["variants"] if "value" in x]
+    assert len(measured) >= 2 and "peer/serial-graph" in [x["name"] for x in measured]
+    for x in measured:
+        assert x["golden"]["bitwise"] is True and x["golden"]["expected"] is not None and x["finite"] is True and x["steps"] == 4 and x["warmup"] == 2
+        if x["schedule"] in ("serial-eager", "overlap-eager"):
+            e = x["exchange"]
+            assert e["exchanges_per_tick"] == 10 and e["per_exchange_us_rank0"]["total"] > 0
+            assert set(e["per_exchange_us_max_over_ranks"]) == {"pack", "transport", "total", "exposed_wait"}
+        else:
+            assert x["exchange"] is None
+    for name in ("rccl/serial-eager", "rccl/overlap-eager"):               # reported, never fatal
+        assert "value" in v[name] or ("error" in v[name] and "rank" in v[name]["error"])
+    assert ab["fastest_verified"]["name"] in [x["name"] for x in measured]
+    pr = ab["per_rank"]
+    assert [q["rank"] for q in pr] == [0, 1] and sum(q["owned"] for q in pr) == 64 ** 3 and all(q["ghosts"] > 0 and q["halo_peers"] == 1 for q in pr)
+    assert j["sustained_ms_per_step"] > 0 and j["config"]["sustained"]["seconds"] >= 0.3 and j["config"]["sustained"]["ticks"] >= 4
+    assert j["config"]["parity"]["golden"]["bitwise"] is True and "cpu_baseline" not in j
 
 
 def test_traffic_file_entries_match_the_compulsory_model_of_a_host_built_plan():
