@@ -403,14 +403,18 @@ def sustained_leg(ctx, sb, ms_per_step_hint):
         t = torch.tensor([ticks], dtype=torch.int64)
         ctx["dist"].broadcast(t, src=0)
         ticks = int(t.item())
-    sb.set_state(mesh.pos, mesh.vel)
-    sampler = None
-    if rank == 0 and not args.no_gpu_state:
-        sampler = GpuStateSampler(_pci_bus_id(torch, ctx["device"]) if ctx["n_dev"] > 0 else None).start()
-    elapsed, ev_ms = timed_region(ctx, sb, 2, ticks)
-    state = sampler.stop() if sampler is not None else None
-    if state:
-        state["window"] = "the sustained leg"
+    for attempt in range(3):      # (the hint comes from a short region that may hold a graph capture: lengthen until the window is long enough)
+        sb.set_state(mesh.pos, mesh.vel)
+        sampler = None
+        if rank == 0 and not args.no_gpu_state:
+            sampler = GpuStateSampler(_pci_bus_id(torch, ctx["device"]) if ctx["n_dev"] > 0 else None).start()
+        elapsed, ev_ms = timed_region(ctx, sb, 2, ticks)
+        state = sampler.stop() if sampler is not None else None
+        if state:
+            state["window"] = "the sustained leg"
+        if elapsed >= 0.97 * args.sustained_seconds or ticks >= 20000:
+            break
+        ticks = int(min(np.ceil(1.15 * ticks * args.sustained_seconds / max(elapsed, 1e-6)), 20000))       # (elapsed is the max over the ranks: same count everywhere)
     return {"ticks": ticks, "seconds": elapsed, "ms_per_step": 1e3 * elapsed / ticks, "ms_per_step_hip_events": ev_ms / ticks, "gpu_state": state,
             "note": "state reset to the initial one, 2 untimed ticks, then `ticks` ticks between barriers"}
 

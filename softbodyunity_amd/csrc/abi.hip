@@ -311,7 +311,7 @@ int finalize_local(sb_solver *s) {
         bool t1_halo = false;
         if (L.halo.size() > 1) for (int r = 0; r < L.world; ++r) t1_halo |= !L.halo[1].send_idx[(size_t)r].empty() || !L.halo[1].recv_idx[(size_t)r].empty();
         const bool want_overlap = sched == SB_SCHEDULE_OVERLAP_EAGER || sched == SB_SCHEDULE_OVERLAP_GRAPH;
-        s->overlap_halo = want_overlap && s->desc.world > 1 && (s->comm || s->group_walk) && !s->peer.enabled && P.tiling && P.gcolours.empty() && P.t2_layers.empty() && t1_halo;
+        s->overlap_halo = want_overlap && s->desc.world > 1 && (s->comm || s->group_walk) && P.tiling && P.gcolours.empty() && P.t2_layers.empty() && t1_halo;
         if (want_overlap && !s->overlap_halo)      // T2 layers / global colours (irregular mesh) or no T1 halo: the serialised form
             sched = sched == SB_SCHEDULE_OVERLAP_GRAPH ? SB_SCHEDULE_SERIAL_GRAPH : SB_SCHEDULE_SERIAL_EAGER;
     }

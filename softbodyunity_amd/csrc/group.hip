@@ -254,8 +254,9 @@ void walk_exchange(sb_group *g, const TickStep &st) {
             HIP_CHECK(hipStreamWaitEvent(s->comm_stream, s->ev_boundary, 0));
         }
         if (s->xtimer.enabled) s->xtimer.mark(stream);
-        halo_exchange_pre(s, st.index, stream);
+        if (!s->peer.enabled) halo_exchange_pre(s, st.index, stream);
         if (s->xtimer.enabled) s->xtimer.mark(stream);
+        if (s->peer.enabled) halo_exchange_pre(s, st.index, stream);
         rccl_needed = rccl_needed || (!s->peer.enabled && halo_slot_active(s, st.index));
     }
     if (rccl_needed) {

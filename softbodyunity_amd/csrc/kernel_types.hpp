@@ -28,7 +28,7 @@ struct TileDesc {
     uint32_t s_begin;          // dword offset of the tile's stream
     uint32_t s_hdr;            // dwords of round words + palette (each padded to 4): round data starts at s_begin + s_hdr
     uint32_t s_len;            // total dwords (multiple of 4)
-    uint32_t packed_lanes;     // 0, or 128: LANE-PACKED slots (see kLanePack*) for workgroups of that many lanes -- the launch must use that width
+    uint32_t packed_lanes;     // 0, or 128 / 256: LANE-PACKED slots (see kLanePack* / kWidePack*) for workgroups of that many lanes -- the launch must use that width
     int32_t run_overflow;      // runs beyond kInlineRuns live at runs_overflow[run_overflow ...]
     int32_t n_pal;             // palette entries (0 = no dictionary coding), stored after the round words
     int32_t n_steps;           // wave items per wave (meshes with tets / hinges; 0 = none), see kItem* below
@@ -46,6 +46,13 @@ constexpr int kInlineRuns = 10;
 // (n_pal == 0 marks this form; only in the kernels that read inverse masses as floats, WPAL = false -- the host packs accordingly).
 constexpr int kLanePackLanes = 128, kLanePackRounds = 3, kLanePackFieldBits = 21, kLanePackMaxPalette = 8;
 constexpr uint32_t kLanePackDwordsCompact = 4 * kLanePackLanes, kLanePackDwordsFull = 10 * kLanePackLanes;
+// The same for 256-lane workgroups (round 4): a lane has ONE slot per round, so three 21-bit fields = ONE 8-byte word per lane, field r = the
+// lane's slot of round r (constraint `lane` of that round) -- again 2 KiB per 512-particle tile instead of 3 KiB, loaded by the lane itself
+// with the first batch, never staged in LDS. Dictionary-coded tiles only. For the launches between the 512-lane and the 128-lane regimes:
+// mid-size meshes (128^3: 4 096 tiles) and the ranks of a partitioned solver (256^3 on 8 ranks: 4 096 tiles each).
+constexpr int kWidePackLanes = 256;
+constexpr uint32_t kWidePackDwords = 2 * kWidePackLanes;
+constexpr int kWide8MaxTiles = 768;     // launches of at most this many spring-only small tiles run 512-lane workgroups (schedule.hip launch_tile)
 // Register-resident programs (tile_kernel): a tile of at most this many distance rounds keeps its slots and rest lengths in registers.
 // Build switches of A/B timing variants (make EXTRA=-D...): the HOST reads the same constants when it decides which tiles to lane-pack
 // (tables.hip) -- a lane-packed tile is never staged in LDS, so only the register-resident path can decode it.

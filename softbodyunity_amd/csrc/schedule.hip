@@ -187,9 +187,11 @@ void halo_exchange(sb_solver *s, int slot, hipStream_t st) {
     if (!halo_slot_active(s, slot)) return;
     // (events inside a capture would become graph nodes without a host-visible time: timing applies to the eager schedules)
     const bool timed = s->xtimer.enabled && !s->capturing;
+    // (peer transport: push + unpack kernels ARE the transport, there is no pack step of its own)
     if (timed) s->xtimer.mark(st);
-    halo_exchange_pre(s, slot, st);
+    if (!s->peer.enabled) halo_exchange_pre(s, slot, st);
     if (timed) s->xtimer.mark(st);
+    if (s->peer.enabled) halo_exchange_pre(s, slot, st);
     if (!s->peer.enabled) {
         NCCL_CHECK(rccl().GroupStart());
         try {
@@ -227,13 +229,14 @@ void launch_tile(sb_solver *s, DevTiling &D, int tile_begin = 0, int tile_end = 
     const bool small = D.max_local <= sbk::kSmallTile;   // every tile <= 512 particles
     // narrow (2-wave) workgroups once the launch oversubscribes the chip; wide ones while every tile is resident at once
     // (a tiling with lane-packed slots runs 128-lane workgroups in EVERY launch, also the peek's subset of its tiles)
-    const bool narrow = small && (D.packed_lanes ? true : (s->tile_lanes ? s->tile_lanes == sbk::kNarrowTileThreads : tile_end - tile_begin >= s->narrow_min_tiles));
+    // (a tiling with 8-byte wide-packed slots likewise runs 256-lane workgroups in every launch)
+    const bool narrow = small && (D.packed_lanes ? D.packed_lanes == sbk::kLanePackLanes : (s->tile_lanes ? s->tile_lanes == sbk::kNarrowTileThreads : tile_end - tile_begin >= s->narrow_min_tiles));
     // tiles with tets / hinges: optionally 8 waves, so that a group's wave slots (16 four-lane constraints or 64 springs each) fit one row
     const bool quad8 = D.has_quads && s->quad_lanes == sbk::kQuadTileThreads;
     // spring-only small tiles on 8 waves (one particle per lane in the load / MARK / store phases; the rounds use half the lanes) while
     // every workgroup of the launch is resident even at that width (4 per compute unit): 64^3 0.1244 -> 0.1213, 48^3 0.1027 -> 0.1005 ms
     // per tick; 96^3 (1 728 tiles) 0.206 -> 0.230, so only launches of at most kWide8MaxTiles (profiles/r03o_lanes512_small_cubes.txt)
-    constexpr int kWide8MaxTiles = 768;
+    constexpr int kWide8MaxTiles = sbk::kWide8MaxTiles;
     const bool wide8 = small && !D.has_quads && !D.packed_lanes && (s->tile_lanes ? s->tile_lanes == 512 : tile_end - tile_begin <= kWide8MaxTiles);
     const dim3 grid(tile_end - tile_begin), block(quad8 || wide8 ? sbk::kQuadTileThreads : (narrow ? sbk::kNarrowTileThreads : sbk::kWideTileThreads));
 #define SB_LAUNCH_TILE(Q, W, G)                                                                                               \

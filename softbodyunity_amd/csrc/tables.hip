@@ -254,9 +254,16 @@ void build_device(sb_solver *s) {
         D.packed_lanes = 0;
         bool all_small = true;       // (a tiling with a tile above 512 particles launches the 1 024-particle kernels)
         for (size_t ci = 0; ci < n_plan_tiles; ++ci) all_small = all_small && G.tiles[LT.tile_ids[ci]].n_local <= sbk::kSmallTile;
-        if (tl < 2 && L.world == 1 && all_small && s->vol_rest.empty() && s->bend_rest.empty() && !no_palette && !(s->tune_flags & SB_TUNE_NO_LANE_PACK) &&
-            (s->tile_lanes == 0 || s->tile_lanes == sbk::kLanePackLanes) && (int64_t)packs.size() >= (int64_t)s->narrow_min_tiles)
+        // (round 4: also for the ranks of a partitioned solver -- a packed tiling forces its width on every launch, the boundary / interior
+        // pieces of the overlapped schedule included -- and, in the 8-byte form for 256-lane workgroups (kWidePack*), for tilings between the
+        // 512-lane and the 128-lane regimes: 128^3 on one GPU, a rank's 4 096 tiles of 256^3 on 8)
+        const bool packable = tl < 2 && all_small && s->vol_rest.empty() && s->bend_rest.empty() && !no_palette;
+        if (packable && !(s->tune_flags & SB_TUNE_NO_LANE_PACK) && (s->tile_lanes == 0 || s->tile_lanes == sbk::kLanePackLanes) &&
+            (int64_t)packs.size() >= (int64_t)s->narrow_min_tiles)
             D.packed_lanes = sbk::kLanePackLanes;
+        else if (packable && !(s->tune_flags & SB_TUNE_NO_WIDE_SLOTS) && (s->tile_lanes == 0 || s->tile_lanes == sbk::kWidePackLanes) &&
+                 (int64_t)packs.size() > (int64_t)sbk::kWide8MaxTiles && (int64_t)packs.size() < (int64_t)s->narrow_min_tiles && sbk::kRegRoundsWide >= sbk::kLanePackRounds)
+            D.packed_lanes = sbk::kWidePackLanes;
         std::atomic<int64_t> n_packed_tiles{0};
         constexpr int64_t kPacksPerChunk = 128;
         const int64_t n_chunks = ((int64_t)packs.size() + kPacksPerChunk - 1) / kPacksPerChunk;
@@ -402,6 +409,13 @@ void build_device(sb_solver *s) {
                              (compact ? (int)pal.size() <= sbk::kLanePackMaxPalette : (sbk::kRegFullSlots && !s->w_palette && n_dist > 0)) &&
                              td.n_local <= sbk::kSmallTile && !prog.empty() && (int)prog.size() <= sbk::kLanePackRounds;
             for (const PackRound &R : prog) lane_pack = lane_pack && R.cnt[1] == 0 && R.cnt[2] == 0 && R.cnt[0] <= 2 * sbk::kLanePackLanes;
+            bool wide_pack = D.packed_lanes == sbk::kWidePackLanes && compact && (int)pal.size() <= sbk::kLanePackMaxPalette &&
+                             td.n_local <= sbk::kSmallTile && !prog.empty() && (int)prog.size() <= sbk::kLanePackRounds;
+            {   // (the packed form is 2 KiB whatever the tile holds: only where that is LESS than 4 bytes per slot -- full-size tiles, not rim packs)
+                uint32_t unpacked = 0;
+                for (const PackRound &R : prog) { wide_pack = wide_pack && R.cnt[1] == 0 && R.cnt[2] == 0 && R.cnt[0] <= sbk::kWidePackLanes; unpacked += ((uint32_t)R.cnt[0] + 3u) & ~3u; }
+                wide_pack = wide_pack && unpacked > sbk::kWidePackDwords;
+            }
             if (lane_pack) {
                 // one 16-byte word per lane: six 21-bit fields {i:9 | j:9 | palette:3}, field 2 r + u = slot lane + 128 u of round r
                 std::vector<uint32_t> words(compact ? sbk::kLanePackDwordsCompact : sbk::kLanePackDwordsFull, 0u);
@@ -430,6 +444,28 @@ void build_device(sb_solver *s) {
                 }
                 stream.insert(stream.end(), words.begin(), words.end());
                 td.packed_lanes = (uint32_t)sbk::kLanePackLanes;
+                n_packed_tiles.fetch_add(1, std::memory_order_relaxed);
+            }
+            else if (wide_pack) {
+                // one 8-byte word per lane: three 21-bit fields {i:9 | j:9 | palette:3}, field r = slot `lane` of round r
+                std::vector<uint32_t> words(sbk::kWidePackDwords, 0u);
+                for (size_t r = 0; r < prog.size(); ++r) {
+                    int32_t c = 0;
+                    for (const Part &pt : prog[r].parts) {
+                        const uint32_t b = (uint32_t)base[pt.member], b2 = b | (b << 16);
+                        for (int64_t k = pt.first_d; k < pt.first_d + pt.cnt[0]; ++k, ++c) {
+                            const uint32_t idx = G.t_dist[k] + b2, rb = fbits(s->dist_rest[G.t_dist_id[k]]);
+                            const uint32_t pi = (uint32_t)(std::lower_bound(pal.begin(), pal.end(), rb) - pal.begin());
+                            const uint32_t i = idx & 0xffffu, j = idx >> 16;
+                            if (i > 511u || j > 511u || pi > 7u || c >= sbk::kWidePackLanes) throw std::runtime_error("internal: wide-packed slot out of range");
+                            const uint64_t f = (uint64_t)(i | (j << 9) | (pi << 18)) << (sbk::kLanePackFieldBits * (int)r);
+                            words[2 * (size_t)c] |= (uint32_t)f;
+                            words[2 * (size_t)c + 1] |= (uint32_t)(f >> 32);
+                        }
+                    }
+                }
+                stream.insert(stream.end(), words.begin(), words.end());
+                td.packed_lanes = (uint32_t)sbk::kWidePackLanes;
                 n_packed_tiles.fetch_add(1, std::memory_order_relaxed);
             }
             else for (const PackRound &R : prog) {

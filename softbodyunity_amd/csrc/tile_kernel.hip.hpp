@@ -177,8 +177,11 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS> - (KIND_ ==
     constexpr int kW = SB_KW;
     const bool lane_packed = !QUADS && kTileThreads == kLanePackLanes && td.packed_lanes == (uint32_t)kLanePackLanes;     // (uniform)
     const bool lane_packed_full = !WPAL && lane_packed && td.n_pal == 0;       // per-spring rest lengths behind the index words
+    // 256-lane workgroups: one 8-byte word per lane (kWidePack*), loaded by the lane itself below
+    const bool wide_packed = !QUADS && kTileThreads == kWidePackLanes && td.packed_lanes == (uint32_t)kWidePackLanes;       // (uniform)
+    const bool any_packed = lane_packed || wide_packed;
     // (a lane-packed tile never stages its data in LDS, so the tiling's window need not hold it: its loads are not cut at `win`)
-    const uint32_t n4_first = lane_packed ? (lane_packed_full ? 2u * (uint32_t)kLanePackLanes : (uint32_t)kLanePackLanes)
+    const uint32_t n4_first = wide_packed ? 0u : lane_packed ? (lane_packed_full ? 2u * (uint32_t)kLanePackLanes : (uint32_t)kLanePackLanes)
                                           : (min(win_lo + win, d_hi) - win_lo) >> 2;
     const u32x4 *wsrc = reinterpret_cast<const u32x4 *>(tstream + win_lo);
     u32x4 wv[kW];
@@ -192,6 +195,10 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS> - (KIND_ ==
     // other tile re-reads its header here (one address for all lanes)
     typedef uint32_t u32x2 __attribute__((ext_vector_type(2)));
     u32x2 wc = {0u, 0u};       // (loaded behind the staging barrier, see there)
+    // wide-packed slots: the lane's own 8-byte word, issued with the first batch (every other tile re-reads its header: one address for all lanes)
+    u32x2 wp = {0u, 0u};
+    if (!QUADS && kTileThreads == kWidePackLanes)
+        wp = *reinterpret_cast<const u32x2 *>(wide_packed ? tstream + win_lo + 2u * (uint32_t)tid : tstream);
     // One common use of every loaded value: the scheduler cannot sink a load below it, so all loads are issued
     // first and a single wait follows (left alone it emits load, wait, LDS write, load, wait, ... to save registers).
 #pragma unroll
@@ -204,6 +211,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS> - (KIND_ ==
 #pragma unroll
     for (int q = 0; q < kW; ++q) asm volatile("" ::"v"(wv[q].x));
     asm volatile("" ::"v"(rw), "v"(palw), "v"(rwl), "v"(itreg));
+    if (!QUADS && kTileThreads == kWidePackLanes) asm volatile("" ::"v"(wp.x));
 #pragma unroll
     for (int m = 0; m < PPT; ++m)
         if (g[m] >= 0) *reinterpret_cast<f32x4 *>(lds_pos + tid + m * kTileThreads) = X[m];
@@ -218,9 +226,9 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS> - (KIND_ ==
 #pragma unroll
         for (int q = 0; q < kW; ++q) {
             const uint32_t i = tid + q * kTileThreads;
-            if (i < n4_first && !lane_packed) dst[i] = wv[q];      // (lane-packed slots stay in wv[0])
+            if (i < n4_first && !any_packed) dst[i] = wv[q];      // (lane-packed slots stay in wv[0], wide-packed ones in wp)
         }
-        if (!lane_packed)
+        if (!any_packed)
             for (uint32_t i = tid + kW * kTileThreads; i < n4_first; i += kTileThreads) dst[i] = wsrc[i];
     }
     __syncthreads();   // also covers the staging loads
@@ -288,7 +296,7 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS> - (KIND_ ==
     constexpr int kRegRounds = THREADS >= 256 ? kRegRoundsWide : kRegRoundsNarrow;       // (kernel_types.hpp: the host packs lanes by the same constants)
     // (round 3: also for tiles whose slots are NOT dictionary-coded -- per-spring rest lengths, {i | j<<16, rest} pairs: the same 2
     // registers per constraint, only the decode differs -- so that a mesh with varied rest lengths keeps the short path)
-    if (kRegRounds > 0 && !QUADS && n_rounds_all <= kRegRounds && n_rounds_all > 0 && (kRegFullSlots || n_pal > 0) && (lane_packed || d_hi - d_lo <= win)) {
+    if (kRegRounds > 0 && !QUADS && n_rounds_all <= kRegRounds && n_rounds_all > 0 && (kRegFullSlots || n_pal > 0) && (any_packed || d_hi - d_lo <= win)) {
         const bool tile_compact = n_pal > 0;      // (uniform per tile: build_device codes all of a tile's groups one way)
         uint32_t rs[kRegRounds > 0 ? kRegRounds : 1][kCPL];
         float rl[kRegRounds > 0 ? kRegRounds : 1][kCPL];
@@ -314,6 +322,11 @@ __global__ __launch_bounds__(THREADS, (kWavesPerSimd<QUADS, THREADS> - (KIND_ ==
                                 rl[r][u] = __uint_as_float(fld < 4 ? wv[1][fld < 4 ? fld : 0] : wc[fld >= 4 ? fld - 4 : 0]);
                             }
                         }
+                    } else if (kCPL == 1 && wide_packed) {
+                        // the lane's own 8-byte word: field r (three 21-bit fields)
+                        const uint64_t two = (uint64_t)wp.x | ((uint64_t)wp.y << 32);
+                        const uint32_t f = (uint32_t)(two >> (kLanePackFieldBits * (r < kLanePackRounds ? r : 0))) & ((1u << kLanePackFieldBits) - 1u);
+                        rs[r][0] = (f & 511u) | (((f >> 9) & 511u) << 12) | ((f >> 18) << 24);
                     } else if (tile_compact) {
 #pragma unroll
                         for (int u = 0; u < kCPL; ++u) {

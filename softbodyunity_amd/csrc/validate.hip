@@ -58,7 +58,8 @@ int sb_debug_validate(sb_solver *s, int32_t inject_fault, sb_validate_report *ou
                     uint32_t off = td.s_hdr;
                     if (td.packed_lanes && td.n_rounds > 0 && (words[0] & 1023u) >= 2) {      // lane-packed: lane 0's word over lane 1's
                         uint32_t *base = s_copy.p + td.s_begin + off;
-                        HIP_CHECK(hipMemcpy(base + 4, base, 4 * sizeof(uint32_t), hipMemcpyDeviceToDevice));
+                        const size_t lane_dwords = td.packed_lanes == (uint32_t)sbk::kWidePackLanes ? 2 : 4;
+                        HIP_CHECK(hipMemcpy(base + lane_dwords, base, lane_dwords * sizeof(uint32_t), hipMemcpyDeviceToDevice));
                         planted = true;
                     }
                     for (int r = 0; r < td.n_rounds && !planted && !td.packed_lanes; ++r) {

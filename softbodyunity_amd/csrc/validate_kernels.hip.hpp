@@ -61,21 +61,25 @@ __global__ __launch_bounds__(kValidateThreads) void validate_tiles_kernel(const 
     uint32_t off = td.s_hdr;
     bool walk_ok = size_ok;
     if (size_ok && td.packed_lanes) {
-        // lane-packed slots (kLanePack*): one 16-byte word per lane, field 2 r + u = slot lane + 128 u of round r
+        // lane-packed slots: 128 lanes (kLanePack*) -- one 16-byte word per lane, field 2 r + u = slot lane + 128 u of round r; 256 lanes
+        // (kWidePack*) -- one 8-byte word per lane, field r = slot lane of round r
         const uint32_t P = td.packed_lanes;
-        // (n_pal == 0: the full form, rest lengths behind the index words)
-        if (P != (uint32_t)kLanePackLanes || td.n_rounds > kLanePackRounds || td.n_pal < 0 || td.n_pal > kLanePackMaxPalette || td.n_local > kSmallTile ||
-            td.s_hdr + (td.n_pal > 0 ? kLanePackDwordsCompact : kLanePackDwordsFull) > td.s_len) { if (tid == 0) flag(3, -1); walk_ok = false; }
+        const bool wide = P == (uint32_t)kWidePackLanes;
+        const uint32_t lane_dwords = wide ? 2u : 4u;
+        // (n_pal == 0: the full form of the 128-lane packing, rest lengths behind the index words)
+        if ((P != (uint32_t)kLanePackLanes && !wide) || td.n_rounds > kLanePackRounds || td.n_pal < 0 || td.n_pal > kLanePackMaxPalette || td.n_local > kSmallTile ||
+            (wide && td.n_pal == 0) ||
+            td.s_hdr + (wide ? kWidePackDwords : (td.n_pal > 0 ? kLanePackDwordsCompact : kLanePackDwordsFull)) > td.s_len) { if (tid == 0) flag(3, -1); walk_ok = false; }
         for (int r = 0; walk_ok && r < td.n_rounds; ++r) {
             const uint32_t w = ts[r];
             const uint32_t cnt = w & 1023u;
-            if (cnt > 2u * P || ((w >> 10) & 0xfffffu) != 0u) { if (tid == 0) flag(3, r); walk_ok = false; break; }
+            if (cnt > (wide ? P : 2u * P) || ((w >> 10) & 0xfffffu) != 0u) { if (tid == 0) flag(3, r); walk_ok = false; break; }
             for (int q = tid; q < kLargeTile / 32; q += kValidateThreads) bitmap[q] = 0;
             __syncthreads();
             for (uint32_t c = tid; c < cnt; c += kValidateThreads) {
-                const uint32_t lane = c % P, u = c / P, bit = (uint32_t)kLanePackFieldBits * (2u * (uint32_t)r + u), w0 = bit >> 5, sh = bit & 31u;
-                const uint32_t *wd = ts + td.s_hdr + 4u * lane;
-                uint64_t two = (uint64_t)wd[w0] | ((uint64_t)(w0 + 1 < 4 ? wd[w0 + 1] : 0u) << 32);
+                const uint32_t lane = c % P, u = c / P, bit = (uint32_t)kLanePackFieldBits * (wide ? (uint32_t)r : 2u * (uint32_t)r + u), w0 = bit >> 5, sh = bit & 31u;
+                const uint32_t *wd = ts + td.s_hdr + lane_dwords * lane;
+                uint64_t two = (uint64_t)wd[w0] | ((uint64_t)(w0 + 1 < lane_dwords ? wd[w0 + 1] : 0u) << 32);
                 const uint32_t f = (uint32_t)(two >> sh) & ((1u << kLanePackFieldBits) - 1u);
                 const uint32_t p0 = f & 511u, p1 = (f >> 9) & 511u;
                 if ((f >> 18) >= (uint32_t)max(td.n_pal, 1)) flag(0, r);

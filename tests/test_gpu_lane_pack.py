@@ -41,20 +41,33 @@ CASES = {
     # per-spring rest lengths but ONE mass: those kernels (inverse masses as palette indices) do not carry the full form
     "cube16_distinct_rest_uniform_mass_not_packable": lambda: (_distinct_rest(16), dict(substeps=4), False),
     "cube30_large_tiles_not_packable": lambda: (jelly_cube(30), dict(substeps=4, tile_particles=1000), False),
+    # round 4: the 8-byte form for 256-lane workgroups (kWidePack*: three 21-bit fields per lane) -- tilings of more than 768 and fewer than
+    # 10 240 workgroups, i.e. mid-size meshes and the ranks of a partitioned solver; no switch forced here, these meshes get it by default
+    # (a tile is packed only where 2 KiB is LESS than its 4-byte slots: the full 512-particle tiles, not the rim packs of the shifted tiling)
+    "wide_cube80": lambda: (jelly_cube(80), dict(substeps=4), True),
+    "wide_cube80_three_rest_lengths_ground": lambda: (_three_rest_lengths(80), dict(substeps=4, ground_plane=(0, 1, 0, -3.0), damping=0.05), True),
+    "wide_cube80_heterogeneous_not_packable": lambda: (jelly_cube(80, heterogeneous=True), dict(substeps=4), False),
+    "wide_cube48_tile128_small_tiles_stay_unpacked": lambda: (jelly_cube(48), dict(substeps=4, tile_particles=128), False),
 }
 
 
 @pytest.mark.parametrize("case", sorted(CASES))
 def test_lane_packed_tiles_match_the_oracle_and_validate(case, monkeypatch, oracle_mod):
     mesh, kw, expect_packed = CASES[case]()
-    monkeypatch.setenv("SB_NARROW_MIN_TILES", "1")
+    if case.startswith("wide_"):
+        monkeypatch.delenv("SB_NARROW_MIN_TILES", raising=False)
+    else:
+        monkeypatch.setenv("SB_NARROW_MIN_TILES", "1")
+    monkeypatch.delenv("SB_NO_WIDE_SLOTS", raising=False)
     monkeypatch.delenv("SB_NO_LANE_PACK", raising=False)
     sb = Softbody(mesh, **kw).Start()
     try:
         st = sb.stats()
         packed = sum(st["lane_packed_tiles"])
         assert (packed > 0) == expect_packed, st["lane_packed_tiles"]
-        if expect_packed and "tile128" not in case:      # (tile 128: some rim packs zip into more than three rounds)
+        if case.startswith("wide_"):
+            assert 768 < st["n_tiles"][0] < 10240                            # the regime of the 256-lane launches
+        if expect_packed and "tile128" not in case and "tile64" not in case:      # (small tiles: some rim packs zip into more than three rounds)
             assert st["lane_packed_tiles"][0] == st["n_tiles"][0]          # every full T0 tile qualifies
         okw = {k: v for k, v in kw.items() if k in ("ground_plane", "damping")}
         o = make_oracle(oracle_mod, mesh, sb.plan(), **okw)
@@ -94,6 +107,30 @@ def test_packed_and_unpacked_builds_of_one_mesh_agree_and_the_packed_one_is_smal
     assert np.array_equal(_bits(xa), _bits(xb)) and np.array_equal(_bits(va), _bits(vb))
     assert sum(sa["lane_packed_tiles"]) > 0 and sum(sb_["lane_packed_tiles"]) == 0
     # 16 bytes per lane against 4 bytes per slot: a full 512-particle tile 2 KiB instead of 3 KiB
+    assert sa["launch_bytes"][0] < sb_["launch_bytes"][0] - 900 * sa["lane_packed_tiles"][0]
+
+
+def test_wide_packed_and_unpacked_builds_agree_and_the_packed_one_is_smaller(monkeypatch):
+    mesh = jelly_cube(80)
+    monkeypatch.delenv("SB_NARROW_MIN_TILES", raising=False)
+
+    def run(pack):
+        if pack:
+            monkeypatch.delenv("SB_NO_WIDE_SLOTS", raising=False)
+        else:
+            monkeypatch.setenv("SB_NO_WIDE_SLOTS", "1")
+        sb = Softbody(mesh, substeps=6).Start()
+        try:
+            for _ in range(3):
+                sb.step()
+            return sb.get_positions().copy(), sb.get_velocities().copy(), sb.stats()
+        finally:
+            sb.OnDestroy()
+    xa, va, sa = run(True)
+    xb, vb, sb_ = run(False)
+    assert np.array_equal(_bits(xa), _bits(xb)) and np.array_equal(_bits(va), _bits(vb))
+    assert sa["lane_packed_tiles"][0] == sa["n_tiles"][0] == 1000 and sum(sb_["lane_packed_tiles"]) == 0
+    # 8 bytes per lane of a 256-lane workgroup against 4 bytes per slot: a full 512-particle tile 2 KiB instead of 3 KiB
     assert sa["launch_bytes"][0] < sb_["launch_bytes"][0] - 900 * sa["lane_packed_tiles"][0]
 
 
