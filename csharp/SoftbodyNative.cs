@@ -99,8 +99,8 @@ namespace SoftbodyMI355X
     public struct SbTuning
     {
         public uint flags;           // SoftbodyNative.Tune*
-        public int tileLanes, quadLanes, narrowMinTiles, storeThroughMaxTiles, storeThroughLarge, peekMinTiles, ldsPadBytes, winDwords;
-        public int reserved0, reserved1, reserved2, reserved3, reserved4, reserved5, reserved6;
+        public int tileLanes, quadLanes, narrowMinTiles, storeThroughMaxTiles, storeThroughLarge, peekMinTiles, ldsPadBytes, winDwords, prevOffsetBytes;
+        public int reserved0, reserved1, reserved2, reserved3, reserved4, reserved5;
     }
 
     [StructLayout(LayoutKind.Sequential)]

@@ -47,7 +47,10 @@ typedef struct {
     int32_t peek_min_tiles;            /* -1 = default (2 048): position reads peek from this many T0 workgroups on */
     int32_t lds_pad_bytes;             /* unused LDS per workgroup (occupancy experiments) */
     int32_t win_dwords;                /* 0 = default: shrink the LDS constraint window */
-    int32_t reserved[7];               /* must be 0 */
+    int32_t prev_offset_bytes;         /* placement experiment (profiles/r04_placement_modes.txt): the previous-position array starts this many bytes
+                                          into its allocation, i.e. the RELATIVE offset of the two arrays every launch streams side by side moves
+                                          (multiple of 16; default 0) */
+    int32_t reserved[6];               /* must be 0 */
 } sb_tuning;
 void sb_tuning_default(sb_tuning *t);
 int sb_set_tuning(sb_solver *s, const sb_tuning *t);      /* after sb_create, before sb_finalize */

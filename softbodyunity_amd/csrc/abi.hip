@@ -70,6 +70,7 @@ int sb_set_tuning(sb_solver *s, const sb_tuning *t) {
     for (int32_t r : t->reserved) if (r) return fail(SB_ERR_INVALID_ARG, "sb_set_tuning: reserved fields must be 0 (sb_tuning_default)");
     if (t->tile_lanes != 0 && t->tile_lanes != 128 && t->tile_lanes != 256 && t->tile_lanes != 512) return fail(SB_ERR_INVALID_ARG, "sb_set_tuning: tile_lanes must be 0, 128, 256 or 512");
     if (t->quad_lanes != 0 && t->quad_lanes != 256 && t->quad_lanes != 512) return fail(SB_ERR_INVALID_ARG, "sb_set_tuning: quad_lanes must be 0, 256 or 512");
+    if (t->prev_offset_bytes < 0 || (t->prev_offset_bytes & 15)) return fail(SB_ERR_INVALID_ARG, "sb_set_tuning: prev_offset_bytes must be a non-negative multiple of 16");
     if (t->narrow_min_tiles < 0 || t->store_through_max_tiles < -1 || t->peek_min_tiles < -1 || t->lds_pad_bytes < 0 || t->win_dwords < 0 || (t->store_through_large & ~3))
         return fail(SB_ERR_INVALID_ARG, "sb_set_tuning: value out of range");
     s->tune_flags = t->flags;
@@ -85,6 +86,7 @@ int sb_set_tuning(sb_solver *s, const sb_tuning *t) {
     if (t->peek_min_tiles >= 0) s->peek_min_tiles = t->peek_min_tiles;
     s->lds_pad = (size_t)t->lds_pad_bytes;
     s->win_dwords_cap = t->win_dwords;
+    s->prev_offset_bytes = t->prev_offset_bytes;
     return SB_OK;
 }
 

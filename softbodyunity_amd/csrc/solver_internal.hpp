@@ -87,17 +87,18 @@ bool capture_overlap_ok();      // see binding.hip
 template <class T>
 struct DevBuf {
     T *p = nullptr;
+    T *base = nullptr;           // what hipMalloc returned (p = base + lead: placement experiments, sb_tuning.prev_offset_bytes)
     size_t count = 0;
-    void alloc(size_t n, int64_t &acct) {
+    void alloc(size_t n, int64_t &acct, size_t lead_elems = 0) {
         free();
         count = n;
-        if (n) { HIP_CHECK(hipMalloc((void **)&p, n * sizeof(T))); acct += (int64_t)(n * sizeof(T)); }
+        if (n) { HIP_CHECK(hipMalloc((void **)&base, (n + lead_elems) * sizeof(T))); p = base + lead_elems; acct += (int64_t)((n + lead_elems) * sizeof(T)); }
     }
     void upload(const std::vector<T> &h, int64_t &acct) {
         alloc(h.size(), acct);
         if (!h.empty()) HIP_CHECK(hipMemcpy(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice));
     }
-    void free() { if (p) { (void)hipFree(p); p = nullptr; } count = 0; }
+    void free() { if (base) { (void)hipFree(base); } base = nullptr; p = nullptr; count = 0; }
     ~DevBuf() { free(); }
 };
 
@@ -227,6 +228,7 @@ struct sb_solver {
     // Tuning (sb_set_tuning of softbody_debug.h: A/B measurements; the plugin reads no environment variable for any of this)
     uint32_t tune_flags = 0;         // SB_TUNE_* as given; the fields below are what they resolve to
     int win_dwords_cap = 0;          // sb_tuning.win_dwords (0 = the tiling's own window)
+    int prev_offset_bytes = 0;       // sb_tuning.prev_offset_bytes: the previous-position array starts this far into its allocation (placement experiment)
     bool lazy_tick = true;           // !SB_TUNE_NO_LAZY_TICK
     int tile_lanes = 0;              // sb_tuning.tile_lanes = 128|256|512 forces the workgroup width of small tiles (0 = by launch size)
     int quad_lanes = 512;            // sb_tuning.quad_lanes = 256|512: workgroup width of tiles that hold tets / hinges (8 waves: every group of the

@@ -120,7 +120,7 @@ void build_device(sb_solver *s) {
         s->d_wpal.upload(pal, s->dev_bytes);
     }
     s->d_vel.upload(hv, s->dev_bytes);
-    s->d_prev.alloc((size_t)s->n_local * 3, s->dev_bytes);
+    s->d_prev.alloc((size_t)s->n_local * 3, s->dev_bytes, (size_t)s->prev_offset_bytes / sizeof(float));
     HIP_CHECK(hipMemset(s->d_prev.p, 0, (size_t)s->n_local * 3 * sizeof(float)));
     s->d_tp.alloc(1, s->dev_bytes);
     // tilings: re-base this rank's tiles onto compact device arrays

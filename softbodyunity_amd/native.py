@@ -43,7 +43,7 @@ class SbDesc(C.Structure):
 class SbTuning(C.Structure):
     _fields_ = [("flags", C.c_uint32), ("tile_lanes", C.c_int32), ("quad_lanes", C.c_int32), ("narrow_min_tiles", C.c_int32),
                 ("store_through_max_tiles", C.c_int32), ("store_through_large", C.c_int32), ("peek_min_tiles", C.c_int32),
-                ("lds_pad_bytes", C.c_int32), ("win_dwords", C.c_int32), ("reserved", C.c_int32 * 7)]
+                ("lds_pad_bytes", C.c_int32), ("win_dwords", C.c_int32), ("prev_offset_bytes", C.c_int32), ("reserved", C.c_int32 * 6)]
 
 
 class SbExchangeTiming(C.Structure):
@@ -272,7 +272,8 @@ _TUNE_FLAG_ENV = (("SB_NO_MASS_PALETTE", SB_TUNE_NO_MASS_PALETTE), ("SB_NO_UNIFO
                   ("SB_NO_WIDE_SLOTS", SB_TUNE_NO_WIDE_SLOTS))
 _TUNE_INT_ENV = (("SB_TILE_LANES", "tile_lanes"), ("SB_QUAD_LANES", "quad_lanes"), ("SB_NARROW_MIN_TILES", "narrow_min_tiles"),
                  ("SB_STORE_THROUGH_MAX_TILES", "store_through_max_tiles"), ("SB_STORE_THROUGH_LARGE", "store_through_large"),
-                 ("SB_PEEK_MIN_TILES", "peek_min_tiles"), ("SB_LDS_PAD", "lds_pad_bytes"), ("SB_WIN_DWORDS", "win_dwords"))
+                 ("SB_PEEK_MIN_TILES", "peek_min_tiles"), ("SB_LDS_PAD", "lds_pad_bytes"), ("SB_WIN_DWORDS", "win_dwords"),
+                 ("SB_PREV_OFFSET", "prev_offset_bytes"))
 
 
 def tuning_from_env():
