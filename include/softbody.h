@@ -165,7 +165,7 @@ int sb_peer_connect(sb_solver *s, int32_t rank, const uint8_t handle[SB_IPC_HAND
 /* One tick of `substeps` substeps (SPEC.md §2). Asynchronous: work is enqueued on the solver's stream. The last
  * kernel of a tick may be held back and fused with the next tick when dt/substeps/plane are unchanged; every call
  * that reads or writes state (sb_get_velocities, sb_set_state, sb_synchronize, ...) completes it first, so the laziness is
- * not observable. Position reads of a single-rank solver (sb_get_positions, sb_readback_begin) do not even need that: they
+ * not observable. Position reads (sb_get_positions, sb_readback_begin; any rank) do not even need that: they
  * PEEK -- the held-back kernel's constraint rounds and collision run on the tiles in question into a side array, bit for bit
  * what the completed tick would hold, and the tick stays fusable with the next one (sb_stats.readback_peeks). Only where that pays:
  * tilings of at least 2 048 workgroups, whose launches are bandwidth-bound; smaller ones complete the tick as before. */
@@ -182,8 +182,9 @@ int sb_set_state(sb_solver *s, const float *pos_xyz, const float *vel_xyz, int32
  * pull their neighbours along. An id whose inverse mass is not 0 is refused (SB_ERR_INVALID_ARG, nothing is changed). Asynchronous like
  * sb_step (the targets are copied before the call returns). The targets are pending until the next tick starts: when that tick's first
  * kernel also finishes the previous tick (the lazy tick boundary of sb_step) they are applied inside it, so a host that moves its pins
- * every tick keeps the fusion (sb_stats.ticks_fused_kinematic); position reads in between already show them. Single-rank solvers only
- * (world == 1). */
+ * every tick keeps the fusion (sb_stats.ticks_fused_kinematic); position reads in between already show them. A rank of a partitioned solver
+ * (world > 1) is given the same list in its own numbering (the whole list on every rank is fine): every entry is validated, the rank applies
+ * the particles it OWNS and skips the others -- their owners apply them, and the ghost copies arrive with the next exchange. */
 int sb_set_kinematic_positions(sb_solver *s, const int32_t *ids, const float *pos_xyz, int32_t count);
 /* Asynchronous render readback: sb_readback_begin snapshots the positions as of every sb_step issued so far
  * (a small kernel on the compute stream) and starts a D2H copy into plugin-owned pinned memory on a second
@@ -192,7 +193,7 @@ int sb_set_kinematic_positions(sb_solver *s, const int32_t *ids, const float *po
  * until the second sb_readback_begin after it (the plugin keeps three snapshot buffers for at most two pending
  * snapshots, so the buffer handed out last is never the next one filled). sb_set_render_triangles re-allocates the
  * render-set buffers and invalidates pointers returned earlier.
- * Cost between two ticks (world == 1): the tick's held-back last kernel is not forced out; with render_set_only the peek
+ * Cost between two ticks: the tick's held-back last kernel is not forced out; with render_set_only the peek
  * runs only the T0 tiles that hold a render particle (256^3 cube: 5 768 of 32 768 workgroups). */
 int sb_readback_begin(sb_solver *s);
 int sb_readback_end(sb_solver *s, const float **pos_xyz_out);
@@ -201,14 +202,16 @@ int sb_readback_end(sb_solver *s, const float **pos_xyz_out);
  * sb_set_particles. Every later sb_readback_begin then also computes area-weighted vertex normals of the snapshot on
  * the copy stream and brings them to pinned memory; after the matching sb_readback_end, sb_readback_get_normals
  * returns n*3 floats (zero for particles in no triangle), valid as long as that snapshot's positions.
- * Single-rank solvers only (world == 1): a rank of a partitioned solver does not hold its neighbours' particles. */
+ * A rank of a partitioned solver (world > 1) takes the triangles too, but serves POSITIONS only: its render set is the render particles it
+ * owns. Vertex normals need the neighbours' particles at the tick's end, which a rank does not hold: sb_readback_get_normals then returns
+ * SB_ERR_UNSUPPORTED, and the normals of a partitioned body are computed on the gathered snapshot (sb_group_readback_get_normals). */
 int sb_set_render_triangles(sb_solver *s, const int32_t *tri_abc, int32_t m);
 int sb_readback_get_normals(sb_solver *s, const float **normal_xyz_out);
 /* Render-set readback: a volumetric body renders only its surface. With render_set_only != 0 (and render triangles
  * set) a readback brings just the particles the triangles use -- their ids ascending -- instead of all n: the
  * pointers of sb_readback_end and sb_readback_get_normals then address count*3 floats, entry k belonging to particle
  * ids[k] (sb_readback_get_render_set). 256^3 cube: 390 k surface particles = 9 MB per snapshot instead of 201 MB.
- * Not while a readback is pending. */
+ * world > 1: the render particles THIS RANK owns, ids ascending in its numbering. Not while a readback is pending. */
 int sb_set_readback_render_set_only(sb_solver *s, int32_t render_set_only);
 int sb_readback_get_render_set(sb_solver *s, const int32_t **ids_out, int32_t *count_out);
 int sb_get_owner(sb_solver *s, int32_t *owner_rank_out, int32_t n);

@@ -3,7 +3,7 @@
 A GPU box has one device, RCCL refuses two ranks on one device, and at most 6 processes may use the card: the 8-rank
 configurations (BASELINE.json:10, :11) therefore run here as 8 solver handles of one process. Every rank is a complete
 `Softbody(rank=r, world=W)` -- its own plan, tiles with ghost runs, pack / unpack kernels -- driven launch by launch
-through the sb_debug_* hooks in the order `enqueue_substeps` uses (solver.hip), the ghost buffers travelling through
+through the sb_debug_* hooks in the order `tick_program` lists (csrc/schedule.hip), the ghost buffers travelling through
 host memory in the wire layout (peers in increasing rank order, one contiguous segment per peer).
 """
 import ctypes as C

@@ -131,3 +131,50 @@ def test_product_package_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
                 txt = open(os.path.join(dirpath, f)).read()
                 assert "liboracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
+
+
+def test_last_words_survive_a_fatal_signal(tmp_path):
+    # sb_debug_last_words (softbody_debug.h): bench.py --gpus N registers its line as it stands before every further A/B variant; should the
+    # process then die of a fatal signal -- or be told to stop by a launcher tearing the job down -- the plugin's handler writes the line
+    import signal
+    import sys
+    code = r"""
+import ctypes, os, signal, sys
+sys.path.insert(0, %r)
+from softbodyunity_amd import native
+L = native.lib()
+line = b'{"metric": "particle-substeps/sec", "value": 1.0}\n'
+assert L.sb_debug_last_words(1, b"an older line\n", 14, 70) == 0
+assert L.sb_debug_last_words(1, line, len(line), 70) == 0          # the newer registration replaces the older one
+if sys.argv[1] == "clear":
+    assert L.sb_debug_last_words(1, None, 0, 0) == 0
+    os.kill(os.getpid(), signal.SIGTERM)                              # default disposition again: no line
+os.kill(os.getpid(), getattr(signal, sys.argv[1]))
+""" % ROOT
+    for sig in ("SIGSEGV", "SIGABRT", "SIGTERM"):
+        out = subprocess.run([sys.executable, "-c", code, sig], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 70 and out.stdout == '{"metric": "particle-substeps/sec", "value": 1.0}\n', (sig, out.returncode, out.stdout, out.stderr[-500:])
+    out = subprocess.run([sys.executable, "-c", code, "clear"], capture_output=True, text=True, timeout=120)
+    assert out.returncode == -signal.SIGTERM and out.stdout == ""
+
+
+def test_group_entry_points_reject_bad_arguments_without_a_gpu():
+    L = native.lib()
+    g = C.c_void_p()
+    d = native.SbDesc(); L.sb_desc_default(C.byref(d))
+    assert L.sb_group_create(None, None, 1, 0, C.byref(g)) == native.SB_ERR_INVALID_ARG
+    assert L.sb_group_create(C.byref(d), None, 0, 0, C.byref(g)) == native.SB_ERR_INVALID_ARG
+    assert L.sb_group_create(C.byref(d), None, 2, 8, C.byref(g)) == native.SB_ERR_INVALID_ARG and b"flags" in L.sb_last_error()
+    d.halo_schedule = native.SB_SCHEDULE_SERIAL_GRAPH
+    assert L.sb_group_create(C.byref(d), None, 2, native.SB_GROUP_WALK, C.byref(g)) == native.SB_ERR_UNSUPPORTED      # walk mode: eager schedules only
+    assert L.sb_group_step(None, 0.02, 10) == native.SB_ERR_INVALID_ARG and L.sb_group_rank_count(None) == -1
+    assert L.sb_group_destroy(None) == native.SB_ERR_INVALID_ARG
+    t = native.SbTuning(); L.sb_tuning_default(C.byref(t))
+    assert t.store_through_max_tiles == -1 and t.peek_min_tiles == -1 and t.flags == 0
+    assert L.sb_set_tuning(None, C.byref(t)) == native.SB_ERR_INVALID_ARG
+    d.halo_schedule = 0
+    rc = L.sb_group_create(C.byref(d), None, 1, 0, C.byref(g))
+    if rc == native.SB_OK:             # a gfx950 device is present (GPU box)
+        assert L.sb_group_step(g, 0.02, 10) == native.SB_ERR_STATE and L.sb_group_destroy(g) == native.SB_OK
+    else:
+        assert rc == native.SB_ERR_NO_DEVICE

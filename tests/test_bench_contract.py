@@ -149,7 +149,7 @@ def test_traffic_file_entries_match_the_compulsory_model_of_a_host_built_plan():
             tiles = ph["task_end"] - ph["task_begin"]
             # headline layout: 48 B of particle state + ~1 B, 4-byte dictionary-coded slots; heterogeneous layout (bench.py
             # --heterogeneous): + a 4-byte inverse mass per particle, 8-byte slots
-            lane_packed = tiles >= 10240                      # kernels.hip.hpp kLanePack*, solver.hip build_device
+            lane_packed = tiles >= 10240                      # kernel_types.hpp kLanePack*, tables.hip build_device
             stream = (40.0 if het else 16.0) * 128 * tiles if lane_packed else (8.0 if het else 4.0) * slots
             model = (52.0 if het else 49.0) * mesh.n + stream + 128.0 * tiles
             assert abs(ent[slot] / model - 1) <= 0.03, (key, slot, ent[slot], model)

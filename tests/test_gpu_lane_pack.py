@@ -1,4 +1,4 @@
-"""Lane-packed spring slots (kernels.hip.hpp kLanePack*): where every launch of a tiling runs 128-lane workgroups, a register-resident
+"""Lane-packed spring slots (csrc/kernel_types.hpp kLanePack*, kWidePack*): where every launch of a tiling runs 128-lane workgroups, a register-resident
 spring tile stores its slots as one 16-byte word per lane (six 21-bit fields) instead of 4 bytes per slot. Same constraints, same
 order, hence the same bits as the oracle; the validator reads the packed form with the kernel's decoding rules. Small meshes are forced
 onto the narrow launch (SB_NARROW_MIN_TILES=1) so that the packed path runs here; the 256^3 / 192^3 / 512^3 tests run it by default."""
@@ -133,6 +133,33 @@ def test_wide_packed_and_unpacked_builds_agree_and_the_packed_one_is_smaller(mon
     assert sa["lane_packed_tiles"][0] == sa["n_tiles"][0] == 1000 and sum(sb_["lane_packed_tiles"]) == 0
     # 8 bytes per lane of a 256-lane workgroup against 4 bytes per slot: a full 512-particle tile 2 KiB instead of 3 KiB
     assert sa["launch_bytes"][0] < sb_["launch_bytes"][0] - 900 * sa["lane_packed_tiles"][0]
+
+
+@pytest.mark.parametrize("world,narrow", [(2, True), (4, False)])
+def test_packed_slots_on_the_ranks_of_a_partitioned_solver(world, narrow, monkeypatch, oracle_mod):
+    # round 4: a rank of a partitioned solver packs its slots too -- the 16-byte form where its launches are 128 lanes wide (forced here; 256^3 on
+    # 2 ranks by itself), the 8-byte form in the 256-lane regime (a rank's 1 000+ tiles here; 256^3 on 4 or 8 ranks by itself). T1 launches
+    # read their ghosts straight from the receive buffer (fused unpack) with the packed tiles in them. 2 / 4 ranks on the one GPU, the host as the wire.
+    from hosted import HostedRanks
+    if narrow:
+        monkeypatch.setenv("SB_NARROW_MIN_TILES", "1")
+    else:
+        monkeypatch.delenv("SB_NARROW_MIN_TILES", raising=False)
+    mesh = jelly_cube(96 if narrow else 128)
+    with HostedRanks(mesh, world, 4) as H:
+        st = [sb.stats() for sb in H.ranks]
+        assert all(sum(q["lane_packed_tiles"]) > 0 for q in st), [q["lane_packed_tiles"] for q in st]
+        assert all(q["halo_unpack_fused"] == 1 for q in st)
+        if not narrow:
+            assert all(768 < q["n_tiles"][0] < 10240 for q in st)
+        o = make_oracle(oracle_mod, mesh, H.ranks[0].plan())
+        for _ in range(2):
+            H.tick(); o.step(0.02, 4, parallel=True)
+        x, v, ghosts = H.merged_state()
+        assert ghosts > 0 and np.array_equal(_bits(x), _bits(o.x)) and np.array_equal(_bits(v), _bits(o.v))
+        for sb in H.ranks:
+            rep = sb.validate()
+            assert rep["errors"] == [0] * 6, rep
 
 
 def _random_spring_cloud(seed, n, k, rest_levels, uniform_mass):

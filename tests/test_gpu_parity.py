@@ -337,7 +337,7 @@ def test_lazy_tick_boundary_is_invisible(oracle_mod, monkeypatch):
 
 
 def test_tile_packing_is_invisible(oracle_mod, bunny20k, monkeypatch):
-    # under-full tiles share a workgroup (solver.hip build_device); the members keep their own round order, so the
+    # under-full tiles share a workgroup (csrc/tables.hip build_device); the members keep their own round order, so the
     # bits must not depend on the packing -- irregular mesh with all three constraint types, and the lattice rim
     def run(mesh, pack, **kw):
         if pack:

@@ -90,8 +90,10 @@ def main():
         # the compulsory-bytes model of the build it runs (a stale entry fails the bench, it does not slip through)
         import hashlib
         h = hashlib.sha256()
-        for f in ("softbodyunity_amd/csrc/kernels.hip.hpp", "softbodyunity_amd/csrc/solver.hip", "softbodyunity_amd/csrc/plan.cpp"):
-            h.update(open(os.path.join(ROOT, f), "rb").read())
+        csrc = os.path.join(ROOT, "softbodyunity_amd", "csrc")
+        for f in sorted(os.listdir(csrc)):      # every source of the plugin (round 4: solver.hip / kernels.hip.hpp became several units)
+            if f.endswith((".hip", ".hpp", ".cpp")):
+                h.update(open(os.path.join(csrc, f), "rb").read())
         traffic["meta"] = {"round": args.round, "csrc_sha16": h.hexdigest()[:16],
                            "counters": "FETCH_SIZE, WRITE_SIZE (separate rocprofv3 --pmc passes); bytes = 2*F*1024 + W*1024"}
         tj[args.key] = traffic
