@@ -335,9 +335,14 @@ int walk_comm_init(sb_group *g) {
             }
         } catch (...) {
             (void)rccl().GroupEnd();
+            for (sb_solver *s : g->ranks) s->comm = nullptr;      // (whatever the failed group left behind is not a communicator to destroy)
             throw;
         }
-        NCCL_CHECK(rccl().GroupEnd());
+        const ncclResult_t r = rccl().GroupEnd();
+        if (r != ncclSuccess) {
+            for (sb_solver *s : g->ranks) s->comm = nullptr;
+            throw HipError(SB_ERR_RCCL, std::string("ncclGroupEnd (communicators of the group's ranks): ") + rccl().GetErrorString(r));
+        }
         return SB_OK;
     });
 }
