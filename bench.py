@@ -14,8 +14,9 @@ control plane (unique-id broadcast, barriers, max-over-ranks); the ghost exchang
 send/recv inside the plugin on its own HIP stream.
 
 N > 1 (the one run a multi-GPU node makes): the line's `value` is the DEFAULT variant's figure (--transport / --schedule, default RCCL with
-SB_SCHEDULE_AUTO); after it, inside the same launch, every other admitted (transport, schedule) pair is timed on the same inputs with a
-fresh solver -- RCCL serial-eager / overlap-eager / serial-graph / overlap-graph (where sb_runtime_info admits them), the peer-store
+SB_SCHEDULE_AUTO, which measures the two eager schedules over its first ticks -- run here before the warm-up -- and keeps the faster; the
+serialised eager variant is measured FIRST and its line registered as the fallback); inside the same launch every other admitted
+(transport, schedule) pair is timed on the same inputs with a fresh solver -- RCCL serial-eager / overlap-eager / serial-graph / overlap-graph (where sb_runtime_info admits them), the peer-store
 transport eager and captured -- each followed by the golden-checksum check, with per-exchange HIP-event times (pack, transport, exposed
 wait) and per-rank owned / ghost counts: `config.schedule_ab`. A variant that fails is reported there, never fatal; the line as it
 stands is registered with the plugin (sb_debug_last_words) before every further variant and written by a watchdog should one hang, so
@@ -345,6 +346,16 @@ def make_barrier(ctx, sb):
     return barrier
 
 
+def calibration_ticks(sb):
+    """SB_SCHEDULE_AUTO measures the two eager schedules over its first ticks (sb_stats.halo_auto_*): run them BEFORE the warm-up, so that
+    neither the alternating ticks nor the one blocking all-gather of the decision falls into the timed region. They are ordinary ticks (same
+    bits in either schedule) and count towards the golden checksum's tick number."""
+    n = 0
+    while n < 12 and sb.stats()["halo_auto_state"] == 1:
+        sb.step(); n += 1
+    return n
+
+
 def timed_region(ctx, sb, warmup, steps, sampler=None):
     """W untimed ticks, then exactly K ticks between barriers (+ synchronize on both sides); max over the ranks."""
     torch, dist = ctx["torch"], ctx["dist"]
@@ -481,6 +492,13 @@ def run_variant(ctx, name, transport, schedule, steps, warmup, is_default):
         stats = sb.stats()
         rec["schedule"] = SCHEDULE_NAMES.get(stats["halo_schedule"])
         rec["setup_seconds"] = time.time() - t0
+        calib = calibration_ticks(sb)
+        stats = sb.stats()
+        rec["schedule"] = SCHEDULE_NAMES.get(stats["halo_schedule"])
+        if stats["halo_auto_state"] == 2:
+            rec["auto_calibration"] = {"ticks_before_warmup": calib, "timed_ticks": stats["halo_auto_ticks"],
+                                       "ms_per_tick_slowest_rank": {"serial-eager": stats["halo_auto_ms"][0], "overlap-eager": stats["halo_auto_ms"][1]},
+                                       "kept": rec["schedule"], "rule": "overlap-eager only where more than 3 % faster"}
         sampler = None
         if is_default and rank == 0 and not args.no_gpu_state:
             sampler = GpuStateSampler(_pci_bus_id(ctx["torch"], ctx["device"]) if ctx["n_dev"] > 0 else None).start()
@@ -490,7 +508,7 @@ def run_variant(ctx, name, transport, schedule, steps, warmup, is_default):
         rec.update({"steps": steps, "warmup": warmup, "ms_per_step": 1e3 * elapsed / steps, "value": N * args.substeps * steps / elapsed,
                     "tick_ms_hip_events_rank0": ev_ms / steps})
         if not args.no_parity:
-            g, finite = golden_leg(ctx, sb, warmup + steps)
+            g, finite = golden_leg(ctx, sb, calib + warmup + steps)
             rec["golden"] = {"checksum": g["checksum"], "expected": g["expected"], "bitwise": g["bitwise"]}
             rec["finite"] = finite
         else:
@@ -505,7 +523,7 @@ def run_variant(ctx, name, transport, schedule, steps, warmup, is_default):
                           per_exchange_us_rank0=ex["per_exchange_us"])
                 ex.pop("per_exchange_us")
         rec["exchange"] = ex
-        result = dict(sb=sb, stats=stats, elapsed=elapsed, ev_ms=ev_ms, golden=g, finite=finite, gpu_state=gpu_state)
+        result = dict(sb=sb, stats=stats, elapsed=elapsed, ev_ms=ev_ms, golden=g, finite=finite, gpu_state=gpu_state, calib=calib)
     except Exception as e:
         err = f"{type(e).__name__}: {e}"
     ok, errs = all_ok(ctx, result is not None, err)
@@ -519,24 +537,20 @@ def run_variant(ctx, name, transport, schedule, steps, warmup, is_default):
     return rec, result
 
 
-def multi_rank(ctx, real_stdout):
-    """--gpus N > 1: the default variant gives `value`; every other admitted (transport, schedule) pair follows in the same launch."""
-    args, rank, world, dist, native, mesh = ctx["args"], ctx["rank"], ctx["world"], ctx["dist"], ctx["native"], ctx["mesh"]
-    runtime = native.runtime_info()
-    words = LastWords(real_stdout, native) if rank == 0 else None
+def full_variant(ctx, name, transport, schedule, with_sustained, runtime):
+    """One variant measured the way the line's own figure is: timed region + golden leg (run_variant), per-launch event timing, the table
+    validator, per-rank counts, optionally the sustained leg -> (record, line or None on rank != 0 / failure, ok)."""
+    args, rank, world, dist = ctx["args"], ctx["rank"], ctx["world"], ctx["dist"]
     N = args.n ** 3
     M = 3 * args.n * args.n * (args.n - 1)
-    default_name = f"{args.transport}/{args.schedule}"
-    if words:
-        words.arm(4 * args.variant_timeout, "the default variant (set-up included)")
-    rec, res = run_variant(ctx, default_name, args.transport, args.schedule, args.steps, args.warmup, True)
+    rec, res = run_variant(ctx, name, transport, schedule, args.steps, args.warmup, True)
     if res is None:
-        raise SystemExit(f"bench.py: the default variant {default_name} failed: {rec.get('error')}")
+        return rec, None, False
     sb, stats = res["sb"], res["stats"]
     setup_s = time.time() - ctx["t_setup"]
     # per-kernel HIP-event timing on the solver's stream: two extra eager ticks, outside the timed region
     slot_ms, slot_cnt = profiled_ticks(sb, 2)
-    parity = {"ticks": args.warmup + args.steps}
+    parity = {"ticks": res["calib"] + args.warmup + args.steps}
     if res["golden"] is not None:
         parity["golden"] = res["golden"]
     if not args.no_parity:
@@ -550,21 +564,58 @@ def multi_rank(ctx, real_stdout):
                                       "halo_peers": stats["halo_peers"], "halo_particles_sent_per_exchange": stats["halo_particles_t1"],
                                       "halo_particles_recv_per_exchange": stats["halo_particles_recv"], "tiles": stats["n_tiles"],
                                       "lane_packed_tiles": stats["lane_packed_tiles"], "device_bytes": stats["device_bytes"]})
-    sustained = None
-    if not args.no_sustained:
-        sustained = sustained_leg(ctx, sb, rec["ms_per_step"])
+    sustained = sustained_leg(ctx, sb, rec["ms_per_step"]) if with_sustained else None
     out = None
     if rank == 0:
         out = build_line(ctx, sb, stats, res["elapsed"], res["ev_ms"], slot_ms, slot_cnt, parity, finite, res["gpu_state"], runtime, setup_s, False, N, M)
-        out["config"]["halo_transport"] = args.transport
+        out["config"]["halo_transport"] = transport
         if sustained:
             out["sustained_ms_per_step"] = sustained["ms_per_step"]
             out["config"]["sustained"] = sustained
-        out["config"]["schedule_ab"] = {"default": default_name, "variants": [rec], "per_rank": per_rank,
+        out["config"]["schedule_ab"] = {"default": None, "variants": [rec], "per_rank": per_rank,
                                         "note": "every variant: fresh solver, same mesh windows, same warmup/steps protocol (barrier + synchronize on both sides, "
                                                 "max over ranks), then the golden-checksum check; per-exchange times are HIP events of 3 extra eager ticks"}
-        words.stash(out)
     teardown(ctx, sb)
+    return rec, out, True
+
+
+def multi_rank(ctx, real_stdout):
+    """--gpus N > 1: the default variant gives `value`; every other admitted (transport, schedule) pair follows in the same launch."""
+    args, rank, world, dist, native, mesh = ctx["args"], ctx["rank"], ctx["world"], ctx["dist"], ctx["native"], ctx["mesh"]
+    runtime = native.runtime_info()
+    words = LastWords(real_stdout, native) if rank == 0 else None
+    default_name = f"{args.transport}/{args.schedule}"
+    measured = {}
+    # The default rccl/auto MEASURES the two eager schedules on the devices at hand over its first ticks (sb_stats.halo_auto_*), i.e. it runs
+    # ticks of the overlapped schedule, which has never run between two devices. So the serialised eager schedule -- what the default falls
+    # back to anyway -- goes first and its line is registered: whatever the default's calibration then does, ONE line comes out.
+    safe_rec, safe_out = None, None
+    if args.transport == "rccl" and args.schedule == "auto":
+        if words:
+            words.arm(4 * args.variant_timeout, "the serialised eager variant (set-up included)")
+        safe_rec, safe_out, ok = full_variant(ctx, "rccl/serial-eager", "rccl", "serial-eager", False, runtime)
+        if ok:
+            measured["rccl/serial-eager"] = safe_rec
+            if rank == 0:
+                safe_out["config"]["schedule_ab"].update({"default": default_name, "value_from": "rccl/serial-eager: the default variant (rccl/auto: the two eager "
+                                                          "schedules measured over the first ticks, the faster kept) had not completed when this line was registered"})
+                words.stash(safe_out)
+    if words:
+        words.arm(4 * args.variant_timeout, "the default variant (set-up included)")
+    rec, out, ok = full_variant(ctx, default_name, args.transport, args.schedule, not args.no_sustained, runtime)
+    if not ok:
+        if safe_rec is None or "value" not in safe_rec:
+            raise SystemExit(f"bench.py: the default variant {default_name} failed: {rec.get('error')}")
+        out = safe_out      # (rank 0) the serialised eager variant's line stands, the default's failure is recorded beside it
+        if rank == 0:
+            out["config"]["schedule_ab"]["variants"].append(rec)
+    else:
+        measured[default_name] = rec
+        if rank == 0:
+            out["config"]["schedule_ab"]["default"] = default_name
+            if safe_rec is not None:
+                out["config"]["schedule_ab"]["variants"].append(safe_rec)
+            words.stash(out)
     if not args.no_ab:
         # safest first: what only differs in launch order, then captured RCCL calls, last the transport that has never run between two devices
         plan = [("rccl", "serial-eager"), ("rccl", "overlap-eager")]
@@ -573,11 +624,13 @@ def multi_rank(ctx, real_stdout):
         if runtime["capture_overlap_ok"] and not args.no_graph:
             plan.append(("rccl", "overlap-graph"))
         plan += [("peer", "serial-eager")] + ([("peer", "serial-graph")] if not args.no_graph else [])
-        resolved_default = (args.transport, rec.get("schedule"))
+        resolved_default = (args.transport, rec.get("schedule")) if (ok and "auto_calibration" not in rec) else None
         ab_steps = args.ab_steps or args.steps
         for transport, schedule in plan:
             name = f"{transport}/{schedule}"
-            if (transport, schedule) == resolved_default or name == default_name:
+            if name in measured:
+                continue
+            if (transport, schedule) == resolved_default:      # (what an uncalibrated AUTO resolves to is not timed twice)
                 if rank == 0:
                     out["config"]["schedule_ab"]["variants"].append({"name": name, "same_as": default_name})
                 continue
@@ -588,8 +641,8 @@ def multi_rank(ctx, real_stdout):
                 teardown(ctx, vres["sb"])
             if rank == 0:
                 out["config"]["schedule_ab"]["variants"].append(vrec)
-                ok = [v for v in out["config"]["schedule_ab"]["variants"] if "value" in v and (v.get("golden") or {}).get("bitwise") is not False]
-                best = max(ok, key=lambda v: v["value"])
+                good = [v for v in out["config"]["schedule_ab"]["variants"] if "value" in v and (v.get("golden") or {}).get("bitwise") is not False]
+                best = max(good, key=lambda v: v["value"])
                 out["config"]["schedule_ab"]["fastest_verified"] = {"name": best["name"], "ms_per_step": best["ms_per_step"], "value": best["value"]}
                 words.stash(out)
         if words:
@@ -622,6 +675,9 @@ def single_rank(ctx):
     try:
         stats = sb.stats()
         setup_s = time.time() - ctx["t_setup"]
+        calib = calibration_ticks(sb)      # (loopback diagnostic with SB_SCHEDULE_AUTO: the schedule measurement stays out of the timed region)
+        if calib:
+            stats = sb.stats()
         sampler = None
         if not args.no_gpu_state:
             sampler = GpuStateSampler(_pci_bus_id(torch, ctx["device"]) if ctx["n_dev"] > 0 else None).start()
@@ -648,6 +704,8 @@ def single_rank(ctx):
         if loopback:
             out["config"]["halo_transport"] = args.transport
             out["config"]["exchange"] = exchange_leg(ctx, sb)
+            if stats["halo_auto_state"] == 2:
+                out["config"]["auto_calibration"] = {"ticks_before_warmup": calib, "ms_per_tick": {"serial-eager": stats["halo_auto_ms"][0], "overlap-eager": stats["halo_auto_ms"][1]}}
         if not loopback and not args.no_parity:
             parity["small"] = small_parity(total_ticks, args, ctx["device"])
         if not loopback and not args.no_cpu_baseline:

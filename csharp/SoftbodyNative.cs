@@ -50,7 +50,10 @@ namespace SoftbodyMI355X
         public ulong planHash;
         public int haloSchedule, haloUnpackFused;
         public long readbackPeeks, readbackPeekTiles, ticksFused, ticksFusedKinematic;
-        public long lanePackedTilesT0, lanePackedTilesT1;   // workgroups whose spring slots are lane-packed (16 B per lane)   // position reads served by a peek; T0 workgroups of one render-set peek (-1: none set up)
+        public long lanePackedTilesT0, lanePackedTilesT1;
+        public int haloAutoState, haloAutoTicks;          // SB_SCHEDULE_AUTO's calibration: 0 none, 1 measuring, 2 decided; ticks timed
+        public double haloAutoMsSerial, haloAutoMsOverlap; // per tick, slowest rank
+          // workgroups whose spring slots are lane-packed (16 B per lane)   // position reads served by a peek; T0 workgroups of one render-set peek (-1: none set up)
     }
 
     [StructLayout(LayoutKind.Sequential)]

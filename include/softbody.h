@@ -69,10 +69,12 @@ typedef struct sb_solver sb_solver; /* opaque, plugin-owned */
 /* Ghost exchange of a world > 1 solver. */
 #define SB_TRANSPORT_RCCL 0            /* pack -> grouped ncclSend/ncclRecv -> unpack (default) */
 #define SB_TRANSPORT_PEER 1            /* peer-store mailboxes (opt-in; see sb_peer_connect) */
-#define SB_SCHEDULE_AUTO               0   /* = SB_SCHEDULE_SERIAL_EAGER on every rank: nothing is asked of the bound RCCL / HIP runtime beyond plain
-                                              send/recv (sb_runtime_info), and it is the fastest eager schedule measured so far (one-device loopback
-                                              shares); the overlapped and captured schedules are opt-in until measured between devices
-                                              (bench.py --gpus N times every admitted one: config.schedule_ab) */
+#define SB_SCHEDULE_AUTO               0   /* an EAGER schedule (nothing is asked of the bound RCCL / HIP runtime beyond plain send/recv, sb_runtime_info),
+                                              chosen by MEASUREMENT on the devices at hand: SB_SCHEDULE_SERIAL_EAGER, and where the overlapped eager
+                                              schedule applies (RCCL, lattice-type plan) the first six ticks alternate between the two -- the bits are
+                                              the same either way -- under HIP events; then every rank keeps the one whose slowest rank was faster
+                                              (one all-gather; sb_stats.halo_schedule / halo_auto_*). The captured schedules stay opt-in; bench.py
+                                              --gpus N times every admitted one (config.schedule_ab) */
 #define SB_SCHEDULE_SERIAL_EAGER       1
 #define SB_SCHEDULE_SERIAL_GRAPH       2   /* the tick, exchange included, captured in a hipGraph */
 #define SB_SCHEDULE_OVERLAP_EAGER      3   /* exchange on a second stream beside the interior tiles */
@@ -254,7 +256,11 @@ typedef struct {
     int64_t readback_peek_tiles;
     int64_t ticks_fused;                            /* sb_step calls whose first kernel also finished the tick before (lazy tick boundary kept) */
     int64_t ticks_fused_kinematic;                  /* ... of which that kernel also applied kinematic targets (sb_set_kinematic_positions) */
-    int64_t lane_packed_tiles[2];                   /* workgroups per tiling whose spring slots are lane-packed (16 B per lane instead of 4 B per slot) */
+    int64_t lane_packed_tiles[2];                   /* workgroups per tiling whose spring slots are lane-packed (16 B per lane of 128, 8 B per lane of 256, instead of 4 B per slot) */
+    /* SB_SCHEDULE_AUTO's calibration: 0 = none (not applicable or switched off), 1 = still measuring, 2 = decided; the ticks timed and the
+     * per-tick times of the slowest rank, [0] serialised, [1] overlapped, in ms (0 until decided) */
+    int32_t halo_auto_state, halo_auto_ticks;
+    double halo_auto_ms[2];
 } sb_stats;
 int sb_get_stats(sb_solver *s, sb_stats *out);
 

@@ -36,7 +36,9 @@ extern "C" {
 #define SB_TUNE_NO_PACK           (1u << 9)   /* one workgroup per plan tile (no tile packing) */
 #define SB_TUNE_NO_PEEK           (1u << 10)  /* position reads complete the tick instead of peeking */
 #define SB_TUNE_NO_KIN_FUSE       (1u << 11)  /* pending kinematic targets always complete the previous tick first */
-#define SB_TUNE_NO_WIDE_SLOTS     (1u << 12)  /* 256-lane launches stage their slots through LDS (no 12-byte register-direct words) */
+#define SB_TUNE_NO_WIDE_SLOTS     (1u << 12)  /* 256-lane launches stage their slots through LDS (no 8-byte packed words) */
+#define SB_TUNE_AUTO_PREFER_OVERLAP (1u << 13) /* SB_SCHEDULE_AUTO's calibration decides for the overlapped schedule whatever it measured (tests) */
+#define SB_TUNE_NO_AUTO_CALIBRATION (1u << 14) /* SB_SCHEDULE_AUTO = SB_SCHEDULE_SERIAL_EAGER without measuring */
 typedef struct {
     uint32_t flags;                    /* SB_TUNE_* */
     int32_t tile_lanes;                /* 0 = by launch size; 128 | 256 | 512 forces the workgroup width of small spring tiles */

@@ -65,7 +65,7 @@ void sb_tuning_default(sb_tuning *t) {
 int sb_set_tuning(sb_solver *s, const sb_tuning *t) {
     if (!s || !t) return fail(SB_ERR_INVALID_ARG, "sb_set_tuning: null argument");
     if (s->finalized) return fail(SB_ERR_STATE, "sb_set_tuning after sb_finalize");
-    constexpr uint32_t kAll = (SB_TUNE_NO_WIDE_SLOTS << 1) - 1u;
+    constexpr uint32_t kAll = (SB_TUNE_NO_AUTO_CALIBRATION << 1) - 1u;
     if (t->flags & ~kAll) return fail(SB_ERR_INVALID_ARG, "sb_set_tuning: unknown bit in flags");
     for (int32_t r : t->reserved) if (r) return fail(SB_ERR_INVALID_ARG, "sb_set_tuning: reserved fields must be 0 (sb_tuning_default)");
     if (t->tile_lanes != 0 && t->tile_lanes != 128 && t->tile_lanes != 256 && t->tile_lanes != 512) return fail(SB_ERR_INVALID_ARG, "sb_set_tuning: tile_lanes must be 0, 128, 256 or 512");
@@ -278,7 +278,8 @@ int finalize_local(sb_solver *s) {
     // the strength of a link-bandwidth model; no schedule has run between two devices yet, so the model is not evidence: the overlapped
     // and the captured schedules stay opt-in and bench.py --gpus N times every admitted one in the same launch (config.schedule_ab).
     int sched = s->desc.world > 1 ? s->desc.halo_schedule : SB_SCHEDULE_SERIAL_EAGER;
-    if (sched == SB_SCHEDULE_AUTO) sched = SB_SCHEDULE_SERIAL_EAGER;
+    const bool sched_auto = sched == SB_SCHEDULE_AUTO;
+    if (sched_auto) sched = SB_SCHEDULE_SERIAL_EAGER;
     if (s->desc.world > 1 && !no_comm) {
         const bool graph = sched == SB_SCHEDULE_SERIAL_GRAPH || sched == SB_SCHEDULE_OVERLAP_GRAPH;
         if (graph && !s->desc.use_graph) return fail(SB_ERR_INVALID_ARG, "sb_finalize: a captured halo schedule needs use_graph = 1");
@@ -316,6 +317,14 @@ int finalize_local(sb_solver *s) {
         s->overlap_halo = want_overlap && s->desc.world > 1 && (s->comm || s->group_walk) && P.tiling && P.gcolours.empty() && P.t2_layers.empty() && t1_halo;
         if (want_overlap && !s->overlap_halo)      // T2 layers / global colours (irregular mesh) or no T1 halo: the serialised form
             sched = sched == SB_SCHEDULE_OVERLAP_GRAPH ? SB_SCHEDULE_SERIAL_GRAPH : SB_SCHEDULE_SERIAL_EAGER;
+        // SB_SCHEDULE_AUTO, measured rather than modelled: where the overlapped eager schedule applies (RCCL between the ranks of a
+        // lattice-type plan) the first ticks alternate between the two eager schedules -- same bits either way -- under HIP events, and the
+        // ranks then keep the one whose slowest rank was faster (schedule.hip calibrate_*). Not for a group walked by one thread (its
+        // exchanges are issued across the ranks), not with SB_TUNE_NO_AUTO_CALIBRATION.
+        s->calib = sb_solver::AutoSchedule{};
+        if (sched_auto && s->desc.world > 1 && s->comm && !s->peer.enabled && !s->group_walk && P.tiling && P.gcolours.empty() && P.t2_layers.empty() && t1_halo &&
+            !(s->tune_flags & SB_TUNE_NO_AUTO_CALIBRATION))
+            s->calib.state = 1;
     }
     s->schedule = sched;
     s->graph_rccl = sched == SB_SCHEDULE_SERIAL_GRAPH || sched == SB_SCHEDULE_OVERLAP_GRAPH;
@@ -326,7 +335,7 @@ int finalize_local(sb_solver *s) {
     // opt in to the LDS size the largest tile needs
     for (int tl = 0; tl < 3; ++tl)
         if (s->tiling[tl].lds_bytes > 64 * 1024) throw std::runtime_error("internal: tile LDS budget exceeded");
-    if (s->overlap_halo) {
+    if (s->overlap_halo || s->calib.state == 1) {
         // opt-in: on the one measurement available (RCCL loopback on one GPU, 8-rank share of 256^3) splitting the T0
         // launch and running the exchange beside the interior tiles pays only inside a captured graph
         // (an ordinary stream: a highest-priority one -- meant to keep the pack kernel and RCCL's few workgroups from queueing behind
@@ -553,6 +562,9 @@ int sb_get_stats(sb_solver *s, sb_stats *out) {
     out->partition = P.partition;
     out->halo_schedule = s->schedule;
     out->halo_unpack_fused = s->fused_unpack ? 1 : 0;
+    out->halo_auto_state = s->calib.state;
+    out->halo_auto_ticks = s->calib.n[0] + s->calib.n[1];
+    out->halo_auto_ms[0] = s->calib.decided_ms[0]; out->halo_auto_ms[1] = s->calib.decided_ms[1];
     out->readback_peeks = s->n_peeks;
     out->readback_peek_tiles = s->n_peek_tiles;
     out->ticks_fused = s->n_fused;

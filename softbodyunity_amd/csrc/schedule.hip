@@ -557,6 +557,59 @@ void end_tick(sb_solver *s, const TickShape &t) {
     s->deferred_substeps = t.substeps;
 }
 
+// ---- SB_SCHEDULE_AUTO, measured ---------------------------------------------------------------------------------------------------------
+// Both eager schedules project the same constraints in the same order on the same operands -- only WHEN the exchange travels differs -- so a
+// solver may change between them from tick to tick without a bit moving. The calibration uses that: ticks 0 and 1 run one schedule each
+// untimed (first use of the communicator's connections, of the second stream), ticks 2 .. 5 alternate serialised / overlapped between two
+// HIP events on the compute stream, and the next sb_step gathers every rank's two sums (one 16-byte all-gather, the only blocking step) and
+// keeps the overlapped schedule when its slowest rank beat the serialised schedule's slowest rank by more than 3 %. Every rank decides
+// from the same table, hence alike.
+constexpr int kCalibWarmTicks = 2, kCalibTimedTicks = 4;
+void calibrate_before_tick(sb_solver *s) {
+    auto &C = s->calib;
+    const int k = C.tick;
+    if (k < kCalibWarmTicks + kCalibTimedTicks) {
+        s->overlap_halo = (k & 1) != 0;
+        if (k >= kCalibWarmTicks) {
+            const int q = 2 * (k - kCalibWarmTicks);
+            if (!C.ev[q]) { HIP_CHECK(hipEventCreate(&C.ev[q])); HIP_CHECK(hipEventCreate(&C.ev[q + 1])); }
+            HIP_CHECK(hipEventRecord(C.ev[q], s->stream));
+        }
+        return;
+    }
+    // decide
+    HIP_CHECK(hipStreamSynchronize(s->stream));
+    float mine[2] = {0.0f, 0.0f};
+    for (int t = 0; t < kCalibTimedTicks; ++t) {
+        float ms = 0.0f;
+        HIP_CHECK(hipEventElapsedTime(&ms, C.ev[2 * t], C.ev[2 * t + 1]));
+        mine[t & 1] += ms; ++C.n[t & 1];
+    }
+    const int W = s->loopback ? 1 : s->desc.world, me = s->loopback ? 0 : s->desc.rank;
+    std::vector<float> all((size_t)2 * W, 0.0f);
+    {
+        DevBuf<float> d_all; int64_t acct = 0;
+        d_all.alloc((size_t)2 * W, acct);
+        HIP_CHECK(hipMemcpy(d_all.p + 2 * (size_t)me, mine, sizeof(mine), hipMemcpyHostToDevice));
+        NCCL_CHECK(rccl().AllGather(d_all.p + 2 * (size_t)me, d_all.p, sizeof(mine), ncclUint8, s->comm, s->stream));
+        HIP_CHECK(hipStreamSynchronize(s->stream));
+        HIP_CHECK(hipMemcpy(all.data(), d_all.p, all.size() * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    float worst[2] = {0.0f, 0.0f};
+    for (int r = 0; r < W; ++r) for (int q = 0; q < 2; ++q) worst[q] = std::max(worst[q], all[2 * (size_t)r + (size_t)q]);
+    for (int q = 0; q < 2; ++q) C.decided_ms[q] = C.n[q] ? (double)worst[q] / C.n[q] : 0.0;
+    bool overlap = worst[1] < 0.97f * worst[0];
+    if (s->tune_flags & SB_TUNE_AUTO_PREFER_OVERLAP) overlap = true;
+    s->overlap_halo = overlap;
+    s->schedule = overlap ? SB_SCHEDULE_OVERLAP_EAGER : SB_SCHEDULE_SERIAL_EAGER;
+    C.state = 2;
+}
+void calibrate_after_tick(sb_solver *s) {
+    auto &C = s->calib;
+    const int k = C.tick++;
+    if (k >= kCalibWarmTicks && k < kCalibWarmTicks + kCalibTimedTicks) HIP_CHECK(hipEventRecord(C.ev[2 * (k - kCalibWarmTicks) + 1], s->stream));
+}
+
 }  // namespace sbi
 
 extern "C" {
@@ -567,6 +620,8 @@ int sb_step(sb_solver *s, float dt, int32_t substeps) {
     if (!(dt > 0.0f) || substeps <= 0) return fail(SB_ERR_INVALID_ARG, "sb_step: dt and substeps must be positive");
     return guarded([&]() -> int {
         int rc = set_device(s); if (rc) return rc;
+        const bool calibrating = s->calib.state == 1;      // SB_SCHEDULE_AUTO: which eager schedule this tick runs (or: decide now)
+        if (calibrating) calibrate_before_tick(s);
         const TickShape t = begin_tick(s, dt, substeps);
         // world > 1: the exchange inside a captured graph is opt-in (SB_SCHEDULE_*_GRAPH), see DESIGN.md §7
         const bool graph_ok = s->desc.use_graph && (s->desc.world == 1 || s->graph_rccl);     // the overlapped schedule forks onto comm_stream inside the capture
@@ -606,6 +661,7 @@ int sb_step(sb_solver *s, float dt, int32_t substeps) {
             HIP_CHECK(hipGraphLaunch(it->second.exec, s->stream));
         }
         end_tick(s, t);
+        if (calibrating && s->calib.state == 1) calibrate_after_tick(s);
         return SB_OK;
     });
 }

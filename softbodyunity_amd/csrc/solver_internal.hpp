@@ -242,6 +242,15 @@ struct sb_solver {
     bool fused_unpack = false;       // the T1 kernels read ghosts from the receive buffer: no unpack launch behind the slot-1 exchange
     bool graph_rccl = false;         // a multi-rank tick, exchange included, is captured in the hipGraph (SB_SCHEDULE_*_GRAPH)
     std::vector<float> h_stage;
+    // SB_SCHEDULE_AUTO measured on the devices at hand (schedule.hip calibrate_*): ticks 0 / 1 warm the two eager schedules up (first use of
+    // the communicator, of the second stream), ticks 2 .. 5 alternate serialised / overlapped under HIP events, the 7th sb_step decides.
+    struct AutoSchedule {
+        int state = 0;                       // 0 off, 1 calibrating, 2 decided
+        int tick = 0;                        // sb_step calls so far
+        hipEvent_t ev[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // start / end of the four timed ticks
+        int n[2] = {0, 0};                   // ticks timed per schedule
+        double decided_ms[2] = {0, 0};       // per tick, slowest rank: [0] serialised, [1] overlapped
+    } calib;
     bool group_walk = false;         // a rank of a group whose host thread walks the tick across the ranks (group.hip): exchanges are issued there
     bool capturing = false;          // sb_step is recording the tick into a hipGraph right now
     sbi::ExchangeTimer xtimer;       // sb_debug_exchange_timing
@@ -335,6 +344,7 @@ struct sb_solver {
         if (peer.mailbox) (void)hipFree(peer.mailbox);
         if (peer.local) (void)hipFree(peer.local);
         if (peer.h_error) (void)hipHostFree(peer.h_error);
+        for (hipEvent_t e : calib.ev) if (e) (void)hipEventDestroy(e);
         if (ev_boundary) (void)hipEventDestroy(ev_boundary);
         if (ev_halo) (void)hipEventDestroy(ev_halo);
         if (comm_stream) (void)hipStreamDestroy(comm_stream);

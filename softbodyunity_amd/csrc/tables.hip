@@ -542,7 +542,9 @@ void build_device(sb_solver *s) {
             const int32_t n = (int32_t)tiles.size();
             std::vector<std::pair<int32_t, int32_t>> ranges;
             if (tl == 2) ranges = s->t2_layer_range;
-            else if (s->overlap_halo && D.n_boundary > 0 && D.n_boundary < n) {
+            else if ((s->overlap_halo || s->calib.state == 1) && D.n_boundary > 0 && D.n_boundary < n) {
+                // (SB_SCHEDULE_AUTO's calibration runs ticks of BOTH eager schedules on these tables: the boundary / interior pieces must stay
+                // pieces; a whole-tiling launch of the serialised ticks then merely finds its tiles placed for two launches)
                 // (only the overlapped schedule launches the boundary and the interior tiles separately; a launch of the whole
                 // tiling remaps with its own workgroup count, so the placement must be made for that launch)
                 const int32_t cut = tl == 0 ? D.n_boundary : n - D.n_boundary;

@@ -27,7 +27,7 @@ SB_GROUP_WALK = 1
 # sb_tuning.flags (include/softbody_debug.h): A/B measurement switches, same bits for every setting
 (SB_TUNE_NO_MASS_PALETTE, SB_TUNE_NO_UNIFORM_MASS, SB_TUNE_NO_PALETTE, SB_TUNE_NO_WAVE_ITEMS, SB_TUNE_NO_LANE_PACK, SB_TUNE_NO_COST_ORDER,
  SB_TUNE_NO_FUSED_UNPACK, SB_TUNE_PEER_COARSE, SB_TUNE_NO_LAZY_TICK, SB_TUNE_NO_PACK, SB_TUNE_NO_PEEK, SB_TUNE_NO_KIN_FUSE,
- SB_TUNE_NO_WIDE_SLOTS) = (1 << k for k in range(13))
+ SB_TUNE_NO_WIDE_SLOTS, SB_TUNE_AUTO_PREFER_OVERLAP, SB_TUNE_NO_AUTO_CALIBRATION) = (1 << k for k in range(15))
 SB_ERR_INVALID_ARG, SB_ERR_STATE, SB_ERR_NO_DEVICE, SB_ERR_HIP, SB_ERR_RCCL, SB_ERR_NOMEM, SB_ERR_UNSUPPORTED = \
     -1, -2, -3, -4, -5, -6, -7
 
@@ -60,7 +60,8 @@ class SbStats(C.Structure):
                 ("launch_bytes", C.c_int64 * 5), ("partition", C.c_int32), ("halo_peers", C.c_int32),
                 ("partition_cost", C.c_int64), ("partition_cost_max", C.c_int64), ("partition_cost_total", C.c_int64),
                 ("halo_particles_recv", C.c_int64), ("plan_hash", C.c_uint64), ("halo_schedule", C.c_int32),
-                ("halo_unpack_fused", C.c_int32), ("readback_peeks", C.c_int64), ("readback_peek_tiles", C.c_int64), ("ticks_fused", C.c_int64), ("ticks_fused_kinematic", C.c_int64), ("lane_packed_tiles", C.c_int64 * 2)]
+                ("halo_unpack_fused", C.c_int32), ("readback_peeks", C.c_int64), ("readback_peek_tiles", C.c_int64), ("ticks_fused", C.c_int64), ("ticks_fused_kinematic", C.c_int64), ("lane_packed_tiles", C.c_int64 * 2),
+                ("halo_auto_state", C.c_int32), ("halo_auto_ticks", C.c_int32), ("halo_auto_ms", C.c_double * 2)]
 
     def as_dict(self):
         out = {}
@@ -269,7 +270,8 @@ _TUNE_FLAG_ENV = (("SB_NO_MASS_PALETTE", SB_TUNE_NO_MASS_PALETTE), ("SB_NO_UNIFO
                   ("SB_NO_WAVE_ITEMS", SB_TUNE_NO_WAVE_ITEMS), ("SB_NO_LANE_PACK", SB_TUNE_NO_LANE_PACK), ("SB_NO_COST_ORDER", SB_TUNE_NO_COST_ORDER),
                   ("SB_NO_FUSED_UNPACK", SB_TUNE_NO_FUSED_UNPACK), ("SB_PEER_COARSE", SB_TUNE_PEER_COARSE), ("SB_NO_LAZY_TICK", SB_TUNE_NO_LAZY_TICK),
                   ("SB_NO_PACK", SB_TUNE_NO_PACK), ("SB_NO_PEEK", SB_TUNE_NO_PEEK), ("SB_NO_KIN_FUSE", SB_TUNE_NO_KIN_FUSE),
-                  ("SB_NO_WIDE_SLOTS", SB_TUNE_NO_WIDE_SLOTS))
+                  ("SB_NO_WIDE_SLOTS", SB_TUNE_NO_WIDE_SLOTS), ("SB_AUTO_PREFER_OVERLAP", SB_TUNE_AUTO_PREFER_OVERLAP),
+                  ("SB_NO_AUTO_CALIBRATION", SB_TUNE_NO_AUTO_CALIBRATION))
 _TUNE_INT_ENV = (("SB_TILE_LANES", "tile_lanes"), ("SB_QUAD_LANES", "quad_lanes"), ("SB_NARROW_MIN_TILES", "narrow_min_tiles"),
                  ("SB_STORE_THROUGH_MAX_TILES", "store_through_max_tiles"), ("SB_STORE_THROUGH_LARGE", "store_through_large"),
                  ("SB_PEEK_MIN_TILES", "peek_min_tiles"), ("SB_LDS_PAD", "lds_pad_bytes"), ("SB_WIN_DWORDS", "win_dwords"),

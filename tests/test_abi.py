@@ -66,7 +66,7 @@ def test_struct_layouts_match_header():
     assert C.sizeof(native.SbDesc) == 80
     assert C.sizeof(native.SbPlanOpts) == 48 and C.sizeof(native.SbDomain) == 8 + 8 * 8 + 8
     assert C.sizeof(native.SbPhaseInfo) == 48
-    assert C.sizeof(native.SbStats) == 8 * 2 + 8 * 3 + 4 * 2 + 8 * 4 + 8 * 5 + 8 * 3 + 8 * 5 + (4 * 2 + 8 * 3 + 8 + 8 + 4 * 2) + 8 * 6
+    assert C.sizeof(native.SbStats) == 8 * 2 + 8 * 3 + 4 * 2 + 8 * 4 + 8 * 5 + 8 * 3 + 8 * 5 + (4 * 2 + 8 * 3 + 8 + 8 + 4 * 2) + 8 * 6 + 4 * 2 + 8 * 2
     assert C.sizeof(native.SbRuntimeInfo) == 8 * 4 + 2 * 256
 
 

@@ -266,31 +266,66 @@ def test_ranks_that_own_nothing_on_the_device(oracle_mod, partition):
     assert np.array_equal(x.view(np.uint32), ref.x.view(np.uint32)) and np.array_equal(v.view(np.uint32), ref.v.view(np.uint32))
 
 
-def test_auto_schedule_is_the_serialised_eager_one_whatever_the_size():
-    """SB_SCHEDULE_AUTO = SB_SCHEDULE_SERIAL_EAGER on every rank alike (round 3 switched to the overlapped schedule above 1 MiB per peer on
-    a link-bandwidth model; every measurement that exists has the serialised one faster, so the overlapped schedule is opt-in until it
-    has been timed between two devices: bench.py --gpus N, config.schedule_ab). The explicit overlapped schedule gives the same bits
-    (RCCL self-exchange on a size-1 communicator)."""
+def test_auto_schedule_is_measured_on_the_devices_at_hand(monkeypatch):
+    """SB_SCHEDULE_AUTO: the two eager schedules give the same bits, so the first six ticks alternate between them under HIP events (two
+    untimed, four timed) and the seventh sb_step keeps the one whose slowest rank was faster -- one all-gather, the same table on every
+    rank (round 3 chose by a link-bandwidth model and picked the slowest schedule measured; round 4 measures). Here: RCCL self-exchange on
+    a size-1 communicator, where the overlapped schedule only costs (two events + two launches per exchange), so the measurement must
+    keep the serialised one; the switch that prefers the overlapped schedule exercises the other outcome; bits equal the explicit schedules."""
     import hashlib
     from softbodyunity_amd import Softbody, comm_unique_id, native
     from softbodyunity_amd.mesh import jelly_cube
+    mesh = jelly_cube(96)
 
-    def run(mesh, schedule):
+    def run(schedule, ticks=9):
         sb = Softbody(mesh, substeps=6, device=0, rank=0, world=2, unique_id=comm_unique_id(), halo_schedule=schedule,
                       debug_flags=native.SB_DEBUG_LOOPBACK).Start()
         try:
-            st = sb.stats()
-            for _ in range(3):
+            st0 = sb.stats()
+            mid = None
+            for t in range(ticks):
                 sb.step()
+                if t == 3:
+                    mid = sb.stats()
             sb.synchronize()
-            return st["halo_schedule"], 24 * st["halo_particles_t1"], hashlib.sha256(sb.get_positions()[sb.owner() == 0].tobytes()).hexdigest()
+            return st0, mid, sb.stats(), hashlib.sha256(sb.get_positions()[sb.owner() == 0].tobytes()).hexdigest()
         finally:
             sb.OnDestroy()
 
-    small, large = jelly_cube(32), jelly_cube(112)
-    sched, nbytes, _ = run(small, native.SB_SCHEDULE_AUTO)
-    assert sched == native.SB_SCHEDULE_SERIAL_EAGER and nbytes < (1 << 20)
-    sched, nbytes, h_auto = run(large, native.SB_SCHEDULE_AUTO)
-    assert sched == native.SB_SCHEDULE_SERIAL_EAGER and nbytes >= (1 << 20)
-    sched, _, h_overlap = run(large, native.SB_SCHEDULE_OVERLAP_EAGER)
-    assert sched == native.SB_SCHEDULE_OVERLAP_EAGER and h_overlap == h_auto
+    for name in ("SB_AUTO_PREFER_OVERLAP", "SB_NO_AUTO_CALIBRATION"):
+        monkeypatch.delenv(name, raising=False)
+    st0, mid, st, h_auto = run(native.SB_SCHEDULE_AUTO)
+    assert st0["halo_auto_state"] == 1 and mid["halo_auto_state"] == 1 and st["halo_auto_state"] == 2 and st["halo_auto_ticks"] == 4
+    assert st["halo_auto_ms"][0] > 0 and st["halo_auto_ms"][1] > 0
+    # what it measured decides: the overlapped schedule only where it was more than 3 % faster
+    want = native.SB_SCHEDULE_OVERLAP_EAGER if st["halo_auto_ms"][1] < 0.97 * st["halo_auto_ms"][0] else native.SB_SCHEDULE_SERIAL_EAGER
+    assert st["halo_schedule"] == want, st
+    _, _, st_s, h_serial = run(native.SB_SCHEDULE_SERIAL_EAGER)
+    _, _, st_o, h_overlap = run(native.SB_SCHEDULE_OVERLAP_EAGER)
+    assert st_s["halo_auto_state"] == 0 and st_o["halo_auto_state"] == 0 and st_o["halo_schedule"] == native.SB_SCHEDULE_OVERLAP_EAGER
+    assert h_auto == h_serial == h_overlap
+    monkeypatch.setenv("SB_AUTO_PREFER_OVERLAP", "1")
+    _, _, st_p, h_pref = run(native.SB_SCHEDULE_AUTO)
+    assert st_p["halo_auto_state"] == 2 and st_p["halo_schedule"] == native.SB_SCHEDULE_OVERLAP_EAGER and h_pref == h_serial
+    monkeypatch.delenv("SB_AUTO_PREFER_OVERLAP")
+    monkeypatch.setenv("SB_NO_AUTO_CALIBRATION", "1")
+    _, _, st_n, h_none = run(native.SB_SCHEDULE_AUTO)
+    assert st_n["halo_auto_state"] == 0 and st_n["halo_schedule"] == native.SB_SCHEDULE_SERIAL_EAGER and h_none == h_serial
+    monkeypatch.delenv("SB_NO_AUTO_CALIBRATION")
+
+    # in the MIDDLE of the calibration (ticks of both schedules mixed, nothing decided yet) on a tiling of unequal tiles -- small tiles and
+    # rim packs, where launches are cost-ordered: the boundary / interior pieces the overlapped ticks launch must have stayed pieces
+    def run_small(schedule, ticks):
+        sb = Softbody(jelly_cube(32), substeps=8, device=0, rank=0, world=2, tile_particles=64, unique_id=comm_unique_id(), halo_schedule=schedule,
+                      debug_flags=native.SB_DEBUG_LOOPBACK).Start()
+        try:
+            for _ in range(ticks):
+                sb.step()
+            sb.synchronize()
+            return sb.stats()["halo_auto_state"], hashlib.sha256(sb.get_positions()[sb.owner() == 0].tobytes()).hexdigest()
+        finally:
+            sb.OnDestroy()
+    for ticks in (3, 5, 8):
+        state, h_a = run_small(native.SB_SCHEDULE_AUTO, ticks)
+        assert state == (1 if ticks < 7 else 2)
+        assert h_a == run_small(native.SB_SCHEDULE_SERIAL_EAGER, ticks)[1] == run_small(native.SB_SCHEDULE_OVERLAP_EAGER, ticks)[1], ticks
