@@ -60,9 +60,10 @@ int sb_group_set_volume_constraints(sb_group *g, const int32_t *ijkl, const floa
 int sb_group_set_bending_constraints(sb_group *g, const int32_t *ijkl, const float *rest_cs, int32_t m, float compliance);
 int sb_group_set_ground_plane(sb_group *g, float nx, float ny, float nz, float d, int32_t enabled);
 /* Plan, partition, upload on every device (the ranks plan side by side on host threads), connect the transport, verify that the ranks
- * planned consistently (plan hash + pair hashes, as sb_finalize does across processes). With sb_desc.partition = SB_PARTITION_BLOCKS every
- * rank is handed only ITS WINDOW of the mesh (sharded authoring, cut here from the one copy the group holds); otherwise every rank plans the
- * whole mesh (SB_PARTITION_AUTO may then choose RCB for a mesh that fills its box unevenly). */
+ * planned consistently (plan hash + pair hashes, as sb_finalize does across processes). With sb_desc.partition = SB_PARTITION_BLOCKS -- or
+ * SB_PARTITION_AUTO on a mesh of at least 2 M particles that fills its bounding box (a lattice-like body, for which AUTO takes the block grid
+ * anyway) -- every rank is handed only ITS WINDOW of the mesh (sharded authoring, cut here from the one copy the group holds); otherwise every
+ * rank plans the whole mesh (SB_PARTITION_AUTO may then choose RCB for a mesh that fills its box unevenly). */
 int sb_group_finalize(sb_group *g);
 
 /* ---- the hot path (FixedUpdate) ---------------------------------------------------------------------------------------------------------- */

@@ -471,12 +471,18 @@ int sb_group_finalize(sb_group *g) {
     int rc = guarded([&]() -> int {
         // ---- the mesh to every rank: its window under the block partition (sharded authoring), else the whole mesh ----
         sb_domain dom{};
-        g->sharded = W > 1 && g->desc.partition == SB_PARTITION_BLOCKS && g->desc.tile_particles >= 0;
-        if (g->sharded) {
+        // windows (sharded authoring) under the block partition: asked for (SB_PARTITION_BLOCKS), or SB_PARTITION_AUTO on a LARGE mesh that fills
+        // its bounding box (a lattice-like body: the block grid is what AUTO takes for it anyway, and eight whole-mesh plans of 16.8 M
+        // particles are 26 GB of host memory and 8 x 4.9 s of planning against 8 x 0.6 s on windows)
+        constexpr int32_t kAutoShardParticles = 1 << 21;
+        const bool may_shard = W > 1 && g->desc.tile_particles >= 0 && (g->desc.partition == SB_PARTITION_BLOCKS || (g->desc.partition == SB_PARTITION_AUTO && g->n >= kAutoShardParticles));
+        g->sharded = false;
+        if (may_shard) {
             const std::vector<float> &rp = g->rest.empty() ? g->pos : g->rest;
             const int rc0 = sb_domain_from_mesh(rp.data(), g->n, g->dist_ij.data(), (int32_t)g->dist_rest.size(), g->vol_ijkl.data(), (int32_t)g->vol_rest.size(),
                                                 g->bend_ijkl.data(), (int32_t)(g->bend_rest.size() / 2), &dom);
             if (rc0) return rc0;
+            g->sharded = g->desc.partition == SB_PARTITION_BLOCKS || dom.fill >= 1.0;
         }
         g->pinned.assign((size_t)g->n, 0);
         for (int32_t p = 0; p < g->n; ++p) g->pinned[(size_t)p] = g->invm[(size_t)p] == 0.0f;
