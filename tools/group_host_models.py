@@ -29,7 +29,7 @@ for transport, tname, dbg in ((native.SB_TRANSPORT_PEER, "peer", 0), (native.SB_
                           halo_transport=transport, debug_flags=dbg, walk=walk).Start()
         setup = time.perf_counter() - t0
         try:
-            for _ in range(5):
+            for _ in range(8):      # (past the seven ticks in which SB_SCHEDULE_AUTO measures the two eager schedules and decides)
                 g.step()
             g.synchronize()
             call = []
