@@ -97,7 +97,6 @@ struct sb_group {
     std::vector<uint8_t> pinned;                 // [n] inverse mass == 0 (kept for sb_group_set_kinematic_positions)
     // per rank: the rank's numbering -> the caller's (sharded authoring: window index -> whole-mesh id; empty = identity)
     std::vector<std::vector<int32_t>> gid;
-    std::vector<std::vector<int32_t>> local_of_caller;     // built lazily where needed
     // kinematic scratch per rank (ids in the rank's numbering)
     std::vector<std::vector<int32_t>> kin_ids;
     std::vector<std::vector<float>> kin_pos;
@@ -291,22 +290,25 @@ int walk_step(sb_group *g, float dt, int substeps) {
             HIP_CHECK(hipSetDevice(g->device_of(r)));
             shape[(size_t)r] = begin_tick(g->ranks[(size_t)r], dt, substeps);
         }
-        for (int r = 1; r < g->W; ++r)
-            if (shape[(size_t)r].fuse != shape[0].fuse || shape[(size_t)r].defer_last != shape[0].defer_last || shape[(size_t)r].kin != shape[0].kin) {
-                // (a rank without pending kinematic targets keeps its tick fusable where a rank with targets takes them along: the programs
-                // differ only in the KIND of the first kernel, which every rank decides for itself below)
-                if (shape[(size_t)r].fuse != shape[0].fuse || shape[(size_t)r].defer_last != shape[0].defer_last)
-                    throw HipError(SB_ERR_STATE, "sb_group_step: the ranks are not in the same state (was one of them stepped or read on its own through sb_group_get_rank?)");
-            }
-        // every rank has the same program; what a range name or `kin` means is resolved per rank
-        const std::vector<TickStep> prog = tick_program(g->ranks[0], substeps, shape[0].fuse, shape[0].defer_last, true);
-        for (const TickStep &st0 : prog) {
+        // Every rank writes down its own program. They have the same steps in the same order -- the phases are a property of the plan, the
+        // schedule is the same on every rank -- and differ only in what the FIRST tile step is: a rank whose previous tick still holds its
+        // last kernel back starts with the fused mid-tick kernel (with or without kinematic targets: a rank that owns no pin has none), a
+        // rank whose tick was completed by a read (ranks peek from a tile count on: one may have peeked where another flushed) starts with
+        // the tick's plain first kernel. Whether the tick's own last kernel is held back depends on the arguments only, hence agrees.
+        std::vector<std::vector<TickStep>> prog((size_t)g->W);
+        for (int r = 0; r < g->W; ++r) {
+            const TickShape &t = shape[(size_t)r];
+            prog[(size_t)r] = tick_program(g->ranks[(size_t)r], substeps, t.fuse, t.defer_last, t.kin);
+            bool same = prog[(size_t)r].size() == prog[0].size();
+            for (size_t i = 0; same && i < prog[0].size(); ++i) same = prog[(size_t)r][i].kind == prog[0][i].kind && prog[(size_t)r][i].index == prog[0][i].index;
+            if (!same) throw HipError(SB_ERR_STATE, "sb_group_step: the ranks' tick programs differ (different schedules or plans on the ranks of one group?)");
+        }
+        for (size_t i = 0; i < prog[0].size(); ++i) {
+            const TickStep &st0 = prog[0][i];
             if (st0.kind == StepKind::Exchange || st0.kind == StepKind::ForkExchange) { walk_exchange(g, st0); continue; }
             for (int r = 0; r < g->W; ++r) {
-                TickStep st = st0;
-                st.kin = st0.kin && shape[(size_t)r].kin;
                 HIP_CHECK(hipSetDevice(g->device_of(r)));
-                run_step(g->ranks[(size_t)r], st, nullptr);
+                run_step(g->ranks[(size_t)r], prog[(size_t)r][i], nullptr);
             }
         }
         for (int r = 0; r < g->W; ++r) {

@@ -34,7 +34,10 @@ def basic(world, mesh_kind, transport, host):
     kw = dict(substeps=S, tile_particles=tile, distance_compliance=comp[0], volume_compliance=comp[1], bending_compliance=comp[2],
               partition=native.SB_PARTITION_BLOCKS if mesh_kind == "blocks" else native.SB_PARTITION_AUTO)
     if transport == "peer":
-        g = SoftbodyGroup(mesh, [0] * world, halo_transport=native.SB_TRANSPORT_PEER, walk=walk, **kw).Start()
+        tune = None
+        if mesh_kind == "bunny":       # ranks of unequal size: a read between two ticks peeks on the ranks with at least this many tiles and
+            tune = native.SbTuning(); native.lib().sb_tuning_default(C.byref(tune)); tune.peek_min_tiles = 9      # completes the tick on the others
+        g = SoftbodyGroup(mesh, [0] * world, halo_transport=native.SB_TRANSPORT_PEER, walk=walk, tuning=tune, **kw).Start()
         try:
             for t in range(3):
                 g.step()
@@ -56,7 +59,8 @@ def basic(world, mesh_kind, transport, host):
         owned = sum(s["n_particles_owned"] for s in stats)
         ok = ok and ghosts > 0 and owned == mesh.n and all(r["errors"] == [0] * 6 for r in val)
         print(("GROUP OK" if ok else "GROUP MISMATCH"), f"peer world={world} mesh={mesh_kind} host={host} ghosts={ghosts} "
-              f"sharded={mesh_kind == 'blocks'} window_particles={[s['n_particles_local'] for s in stats]}")
+              f"sharded={mesh_kind == 'blocks'} window_particles={[s['n_particles_local'] for s in stats]} "
+              f"T0_tiles={[s['n_tiles'][0] for s in stats]} peeks={[s['readback_peeks'] for s in stats]}")
         return ok
     # RCCL refuses two ranks on one device: every rank a size-1 communicator of its own, every peer the rank itself (SB_DEBUG_LOOPBACK).
     # A self-exchange is not the physics of the partitioned mesh, but it IS the call pattern -- W communicators of one process, and in
