@@ -193,6 +193,9 @@ def parse_args():
     ap.add_argument("--no-ab", action="store_true", help="N > 1: time the default (transport, schedule) only, not every admitted pair (config.schedule_ab)")
     ap.add_argument("--ab-steps", type=int, default=0, help="N > 1: timed ticks of the A/B variants (0 = --steps)")
     ap.add_argument("--variant-timeout", type=float, default=150.0, help="N > 1: seconds one variant may take before the watchdog writes the line as it stands and ends the run")
+    ap.add_argument("--rccl-stand-in", choices=["peer"], default=None,
+                    help="TEST AID for one-GPU boxes, never a measurement: the variants NAMED rccl/* run over the peer-store transport (RCCL refuses two "
+                         "ranks on one device), so that the control flow of the N > 1 launch -- fallback line first, default, A/B block -- executes end to end")
     ap.add_argument("--loopback-world", type=int, default=0,
                     help="diagnostic: run as rank 0 of this many ranks with SB_TEST_LOOPBACK (RCCL self-exchange on one GPU); "
                          "the reported value counts only the particles this rank owns")
@@ -305,7 +308,7 @@ def make_solver(ctx, transport="rccl", schedule="auto", sb_world=None, debug_fla
     """A fresh solver of the workload's mesh for this rank (+ the transport's set-up across the ranks)."""
     from softbodyunity_amd import Softbody, comm_unique_id
     args, rank, world, dist, torch, native = ctx["args"], ctx["rank"], ctx["world"], ctx["dist"], ctx["torch"], ctx["native"]
-    peer = transport == "peer"
+    peer = transport == "peer" or (transport == "rccl" and args.rccl_stand_in == "peer" and world > 1)
     uid = None
     if world > 1 and not peer:       # (the peer transport needs no RCCL communicator: the mailbox handles travel over gloo below)
         buf = torch.zeros(128, dtype=torch.uint8)
@@ -487,7 +490,7 @@ def run_variant(ctx, name, transport, schedule, steps, warmup, is_default):
         return rec, None
     result = None
     try:
-        if transport == "peer":
+        if transport == "peer" or (transport == "rccl" and args.rccl_stand_in == "peer"):
             connect_peers(ctx, sb)
         stats = sb.stats()
         rec["schedule"] = SCHEDULE_NAMES.get(stats["halo_schedule"])
@@ -569,6 +572,8 @@ def full_variant(ctx, name, transport, schedule, with_sustained, runtime):
     if rank == 0:
         out = build_line(ctx, sb, stats, res["elapsed"], res["ev_ms"], slot_ms, slot_cnt, parity, finite, res["gpu_state"], runtime, setup_s, False, N, M)
         out["config"]["halo_transport"] = transport
+        if args.rccl_stand_in:
+            out["config"]["rccl_stand_in"] = f"TEST RUN: the variants named rccl/* ran over the {args.rccl_stand_in} transport (one-GPU box); not a measurement of RCCL"
         if sustained:
             out["sustained_ms_per_step"] = sustained["ms_per_step"]
             out["config"]["sustained"] = sustained

@@ -126,6 +126,34 @@ def test_bench_multi_rank_times_every_admitted_schedule_in_one_launch():
     assert j["config"]["parity"]["golden"]["bitwise"] is True and "cpu_baseline" not in j
 
 
+@pytest.mark.gpu
+def test_bench_multi_rank_default_rccl_auto_control_flow_with_a_stand_in_transport():
+    # What the driver launches on a multi-GPU node is `bench.py --gpus N` with the DEFAULT transport and schedule (rccl/auto), which this box's
+    # one GPU cannot run (RCCL refuses two ranks on a device). The control flow of that launch -- the serialised eager variant first and its
+    # line registered as the fallback, then the default (whose figure is `value`), then every other admitted pair -- must not meet its first
+    # execution there: --rccl-stand-in peer runs the variants NAMED rccl/* over the peer transport (a test aid, flagged in the line).
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    port = 29890 + os.getpid() % 40
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cube-edge", "64", "--steps", "4", "--warmup", "2",
+                          "--sustained-seconds", "0.2", "--rccl-stand-in", "peer"], capture_output=True, text=True, timeout=1200, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    assert "TEST RUN" in j["config"]["rccl_stand_in"] and j["config"]["halo_transport"] == "rccl"
+    ab = j["config"]["schedule_ab"]
+    names = [x["name"] for x in ab["variants"]]
+    assert ab["default"] == "rccl/auto" and names[0] == "rccl/auto" and names[1] == "rccl/serial-eager"      # the default's record first, the fallback's second
+    assert names.count("rccl/serial-eager") == 1 and {"rccl/overlap-eager", "rccl/serial-graph", "peer/serial-eager", "peer/serial-graph"} <= set(names)
+    assert "value_from" not in ab                                                                             # the default completed: the line is its own
+    v = {x["name"]: x for x in ab["variants"]}
+    assert abs(v["rccl/auto"]["value"] - j["value"]) / j["value"] < 1e-9 and j["sustained_ms_per_step"] > 0
+    measured = [x for x in ab["variants"] if "value" in x]
+    assert len(measured) >= 5 and all(x["golden"]["bitwise"] is True for x in measured), [(x["name"], x.get("golden")) for x in measured]
+    assert ab["fastest_verified"]["name"] in names and j["config"]["parity"]["golden"]["bitwise"] is True
+
+
 def test_traffic_file_entries_match_the_compulsory_model_of_a_host_built_plan():
     # profiles/hbm_traffic.json must not go stale: every entry is within 3 % of 49 B per particle + the tile streams
     # (4 B per dictionary-coded slot -- or 16 B (heterogeneous: 40 B) per lane of a 128-lane workgroup where the slots are lane-packed: single-rank spring
