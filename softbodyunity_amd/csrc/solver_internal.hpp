@@ -89,6 +89,11 @@ struct DevBuf {
     T *p = nullptr;
     T *base = nullptr;           // what hipMalloc returned (p = base + lead: placement experiments, sb_tuning.prev_offset_bytes)
     size_t count = 0;
+    DevBuf() = default;
+    DevBuf(const DevBuf &) = delete;                 // owns device memory
+    DevBuf &operator=(const DevBuf &) = delete;
+    DevBuf(DevBuf &&o) noexcept : p(o.p), base(o.base), count(o.count) { o.p = o.base = nullptr; o.count = 0; }
+    DevBuf &operator=(DevBuf &&o) noexcept { if (this != &o) { free(); p = o.p; base = o.base; count = o.count; o.p = o.base = nullptr; o.count = 0; } return *this; }
     void alloc(size_t n, int64_t &acct, size_t lead_elems = 0) {
         free();
         count = n;
