@@ -23,4 +23,4 @@ for k in sorted(acc, key=lambda k: -sum(acc[k])):
     v = acc[k]
     tot += sum(v)
     print(f"| `{k}` | {len(v)} | {len(v) / ticks:.1f} | {sum(v) / len(v) / 1e3:.1f} | {sum(v) / ticks / 1e3:.1f} |")
-print(f"\nsum of kernel time: {tot / ticks / 1e3:.1f} µs per tick over {ticks} ticks (warm-up, timed and the two profiled eager ticks)")
+print(f"\nsum of kernel time: {tot / ticks / 1e3:.1f} µs per tick over {ticks} ticks (warm-up, timed, the two profiled eager ticks and the three exchange-timing ticks)")
