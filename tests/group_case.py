@@ -66,13 +66,16 @@ def basic(world, mesh_kind, transport, host):
     # A self-exchange is not the physics of the partitioned mesh, but it IS the call pattern -- W communicators of one process, and in
     # walk mode every rank's sends and receives inside ONE ncclGroupStart / ncclGroupEnd -- and each rank's result must equal what the
     # same rank gives when stepped on its own through sb_step.
-    sched = native.SB_SCHEDULE_OVERLAP_EAGER if (mesh_kind == "cube" and world == 4) else native.SB_SCHEDULE_SERIAL_EAGER
+    # (cube on 4: the overlapped eager schedule; blocks: SB_SCHEDULE_AUTO, i.e. the first ticks alternate between the two eager schedules under
+    # HIP events on every rank's own thread -- in walk mode AUTO stays the serialised schedule; else the serialised eager schedule)
+    sched = native.SB_SCHEDULE_OVERLAP_EAGER if (mesh_kind == "cube" and world == 4) else (native.SB_SCHEDULE_AUTO if mesh_kind == "blocks" else native.SB_SCHEDULE_SERIAL_EAGER)
+    n_ticks = 9 if mesh_kind == "blocks" else 3
     g = SoftbodyGroup(mesh, [0] * world, halo_transport=native.SB_TRANSPORT_RCCL, halo_schedule=sched, debug_flags=native.SB_DEBUG_LOOPBACK,
                       walk=walk, **kw).Start()
     L = native.lib()
     got = []
     try:
-        for _ in range(3):
+        for _ in range(n_ticks):
             g.step()
         g.synchronize()
         for r in range(world):
@@ -80,7 +83,7 @@ def basic(world, mesh_kind, transport, host):
             out = np.zeros((mesh.n, 3), np.float32)
             native.check(L.sb_get_positions(h, native.ptr(out), mesh.n))
             st = native.SbStats(); native.check(L.sb_get_stats(h, C.byref(st)))
-            got.append((out, st.halo_schedule, st.halo_particles_t1))
+            got.append((out, st.halo_schedule, st.halo_particles_t1, st.halo_auto_state))
     finally:
         g.OnDestroy()
     ok = True
@@ -88,10 +91,14 @@ def basic(world, mesh_kind, transport, host):
         sb = Softbody(mesh, device=0, rank=r, world=world, unique_id=comm_unique_id(), halo_schedule=sched, debug_flags=native.SB_DEBUG_LOOPBACK,
                       halo_transport=native.SB_TRANSPORT_RCCL, **kw).Start()
         try:
-            for _ in range(3):
+            for _ in range(n_ticks):
                 sb.step()
             own = sb.owner() == r
-            ok = ok and np.array_equal(bits(sb.get_positions()[own]), bits(got[r][0][own])) and got[r][1] == sb.stats()["halo_schedule"]
+            ok = ok and np.array_equal(bits(sb.get_positions()[own]), bits(got[r][0][own]))
+            if sched != native.SB_SCHEDULE_AUTO:
+                ok = ok and got[r][1] == sb.stats()["halo_schedule"]
+            else:       # measured on every rank's thread and decided (threads); not measured at all when one thread walks the ranks
+                ok = ok and got[r][3] == (0 if walk else 2)
             ok = ok and np.isfinite(got[r][0][own]).all() and got[r][2] > 0
         finally:
             sb.OnDestroy()

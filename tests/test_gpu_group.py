@@ -29,7 +29,7 @@ def test_one_process_drives_every_rank_through_the_group(world, mesh_kind, host)
 
 
 @pytest.mark.parametrize("host", ["threads", "walk"])
-@pytest.mark.parametrize("world,mesh_kind", [(4, "cube"), (2, "bunny")])
+@pytest.mark.parametrize("world,mesh_kind", [(4, "cube"), (2, "bunny"), (2, "blocks")])
 def test_group_over_rccl_self_exchange(world, mesh_kind, host):
     # W communicators of one process; walk mode: every rank's sends / receives of an exchange inside ONE ncclGroupStart / ncclGroupEnd
     _run("basic", world, mesh_kind, "rccl-loopback", host)
