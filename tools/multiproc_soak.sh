@@ -9,10 +9,10 @@ OUT=$R/gpurun_out/multiproc_soak.txt
 run() { # edge ticks procs extra
   local n=$1 t=$2 p=$3; shift 3
   if [ $p -eq 1 ]; then
-    timeout -k 10 500 python $R/bench.py --n $n --steps $t --warmup 2 --no-cpu-baseline "$@" 2>/dev/null
+    timeout -k 10 500 python $R/bench.py --n $n --steps $t --warmup 2 --no-cpu-baseline --no-sustained "$@" 2>/dev/null
   else
     timeout -k 10 500 python -m torch.distributed.run --nnodes=1 --nproc-per-node $p --master-addr 127.0.0.1 --master-port $((29650 + p)) \
-      $R/bench.py --gpus $p --transport peer --cube-edge $n --steps $t --warmup 2 "$@" 2>/dev/null
+      $R/bench.py --gpus $p --transport peer --no-ab --no-sustained --cube-edge $n --steps $t --warmup 2 "$@" 2>/dev/null
   fi | python -c "
 import json,sys
 j=json.loads([l for l in sys.stdin.read().splitlines() if l.startswith('{')][-1])
