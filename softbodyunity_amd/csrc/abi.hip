@@ -365,7 +365,7 @@ std::vector<uint64_t> agreement_record(const sb_solver *s, bool failed) {
 // its neighbours' first exchange forever). A rank that failed on its own (planning, upload, an incomplete window ...) is named to all.
 // Whole-mesh ranks must hold the identical plan; any two ranks must agree on what they share (ghost lists both ways, programs of the
 // tiles both run) -- the only check a sharded rank, which sees just its window, can make.
-int check_agreement(const std::vector<uint64_t> &all, int W, int me, const char *my_error) {
+int check_agreement(const std::vector<uint64_t> &all, int W, int me) {
     const size_t rec = (size_t)W + 2;
     char msg[400];
     for (int a = 0; a < W; ++a)
@@ -374,7 +374,6 @@ int check_agreement(const std::vector<uint64_t> &all, int W, int me, const char 
             std::snprintf(msg, sizeof msg, "sb_finalize: rank %d failed while planning / uploading (see its own sb_last_error); every rank of the solver gives up with it", a);
             return fail(SB_ERR_STATE, msg);
         }
-    (void)my_error;
     for (int a = 0; a < W; ++a)
         for (int b = a + 1; b < W; ++b) {
             const uint64_t *ra = all.data() + (size_t)a * rec, *rb = all.data() + (size_t)b * rec;
@@ -414,7 +413,7 @@ int finalize_agree(sb_solver *s, int local_rc) {
     });
     if (local_rc) return fail(local_rc, my_error);       // this rank's own failure is what its host sees
     if (rc) return rc;
-    return check_agreement(all, W, s->desc.rank, nullptr);
+    return check_agreement(all, W, s->desc.rank);
 }
 
 // Phase C: the peer transport's mailboxes over the communicator the host already set up (setup time only), then the bookkeeping.

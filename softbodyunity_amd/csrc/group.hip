@@ -522,7 +522,7 @@ int sb_group_finalize(sb_group *g) {
             if (W > 1 && !(g->desc.debug_flags & SB_DEBUG_LOOPBACK)) {
                 std::vector<uint64_t> all;
                 for (int r = 0; r < W; ++r) { const auto rec = agreement_record(g->ranks[(size_t)r], false); all.insert(all.end(), rec.begin(), rec.end()); }
-                if ((rc1 = check_agreement(all, W, -1, nullptr))) return rc1;
+                if ((rc1 = check_agreement(all, W, -1))) return rc1;
             }
             for (int r = 0; r < W; ++r) if ((rc1 = finalize_link(g->ranks[(size_t)r]))) return fail(rc1, "rank " + std::to_string(r) + ": " + last_error_text());
         }

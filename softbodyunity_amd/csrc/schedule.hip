@@ -288,7 +288,7 @@ void launch_tick_kernel(sb_solver *s, int it, int substeps, LaunchTimer *lt, int
     if (lt && D.n_tiles) lt->begin(it == 0 ? 2 + (int)s->gcolours.size() : (it == substeps ? 3 + (int)s->gcolours.size() : tl));
     const int halo_in = s->fused_unpack && tl == 1 ? sbk::kHaloGhosts : sbk::kHaloNone;      // T1 tiles read their ghosts straight from the receive buffer
     if (it == 0) launch_tile<0>(s, D, tile_begin, tile_end);
-    else if (it < substeps && kin) launch_tile<5>(s, D, tile_begin, tile_end);        // (world == 1: the fused first kernel of a tick, with kinematic targets)
+    else if (it < substeps && kin) launch_tile<5>(s, D, tile_begin, tile_end);        // (the fused first kernel of a tick, with kinematic targets: a T0 launch, owned particles only)
     else if (it < substeps) launch_tile<1>(s, D, tile_begin, tile_end, halo_in);
     else launch_tile<2>(s, D, tile_begin, tile_end, halo_in);
     if (lt && D.n_tiles) lt->end();
@@ -459,8 +459,8 @@ void stage_kinematic_for_fusion(sb_solver *s) {
 // While the last kernel K_S of a tick is deferred, the positions the tick ends with are K_S's rounds + collide applied to the state
 // in memory. tile_kernel<4> computes exactly that -- same tiles, same programs, same inputs, hence the same bits -- into d_peek and
 // leaves the state alone, so the next sb_step still fuses K_S with its first kernel (one launch instead of two) and a render
-// readback after every tick no longer costs a whole extra pass over the mesh. world == 1 only (a rank of a partitioned solver would
-// need its ghosts refreshed first).
+// readback after every tick no longer costs a whole extra pass over the mesh. On every rank of a partitioned solver too (round 4): the
+// held-back kernel runs on T0 tiles, which hold owned particles only and have no exchange in front of them.
 bool can_peek(const sb_solver *s) {
     if (!s->peek_enabled || !s->deferred) return false;
     const int tl = s->plan->plan.tiling ? (s->deferred_substeps & 1) : 0;

@@ -420,7 +420,7 @@ void launch_normals(hipStream_t st, const float *snap_xyz, const int32_t *adj_of
 // ---- abi.hip: the phases of sb_finalize (a group runs them itself) ----------------------------------------------------------------------
 int finalize_local(sb_solver *s);                       // plan + tables, this rank alone
 std::vector<uint64_t> agreement_record(const sb_solver *s, bool failed);
-int check_agreement(const std::vector<uint64_t> &all, int W, int me, const char *my_error);
+int check_agreement(const std::vector<uint64_t> &all, int W, int me);
 int finalize_agree(sb_solver *s, int local_rc);         // RCCL all-gather of the agreement records (entered by a failed rank too)
 int finalize_link(sb_solver *s);                        // peer mailboxes over the communicator, bookkeeping
 template <class F>
