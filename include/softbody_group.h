@@ -21,7 +21,8 @@
  *                  devices; a ghost exchange is issued for all ranks together: pack kernels on every rank's stream, then the sends and receives
  *                  of ALL ranks inside ONE ncclGroupStart / ncclGroupEnd (a single thread that posted one rank's receive outside a group would
  *                  wait for a send it has not posted yet), then the unpack kernels (none where the T1 kernels read the receive buffer
- *                  themselves). The communicators are created together inside one ncclGroupStart / ncclGroupEnd. Eager schedules only.
+ *                  themselves). The communicators are created together inside one ncclGroupStart / ncclGroupEnd. Eager schedules only, and
+ *                  SB_SCHEDULE_AUTO is the serialised one here (its measurement of the two eager schedules runs on the ranks' own threads).
  * Transports (sb_desc.halo_transport): SB_TRANSPORT_RCCL as above; SB_TRANSPORT_PEER = the mailbox transport of softbody.h with the mailboxes
  * connected by plain pointer (sb_group_finalize enables peer access between the devices): push and unpack kernels only, nothing on the host.
  * The lazy tick boundary, the peek, kinematic targets and the render readback work as for a single solver; results are bit-identical to a
