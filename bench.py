@@ -196,6 +196,9 @@ def parse_args():
     ap.add_argument("--rccl-stand-in", choices=["peer"], default=None,
                     help="TEST AID for one-GPU boxes, never a measurement: the variants NAMED rccl/* run over the peer-store transport (RCCL refuses two "
                          "ranks on one device), so that the control flow of the N > 1 launch -- fallback line first, default, A/B block -- executes end to end")
+    ap.add_argument("--debug-hang-variant", default=None,
+                    help="TEST AID: the named A/B variant never returns (every rank sleeps), so that the watchdog's path -- write the line as it stands, "
+                         "end the run with a non-zero code -- can be exercised")
     ap.add_argument("--loopback-world", type=int, default=0,
                     help="diagnostic: run as rank 0 of this many ranks with SB_TEST_LOOPBACK (RCCL self-exchange on one GPU); "
                          "the reported value counts only the particles this rank owns")
@@ -478,6 +481,8 @@ def run_variant(ctx, name, transport, schedule, steps, warmup, is_default):
     rec = {"name": name, "transport": transport, "schedule_requested": schedule}
     sb, err = None, ""
     t0 = time.time()
+    if args.debug_hang_variant == name:
+        time.sleep(10 ** 6)
     try:
         sb = make_solver(ctx, transport, schedule)
     except Exception as e:       # refused (SB_ERR_UNSUPPORTED), RCCL could not form the communicator, ...

@@ -154,6 +154,27 @@ def test_bench_multi_rank_default_rccl_auto_control_flow_with_a_stand_in_transpo
     assert ab["fastest_verified"]["name"] in names and j["config"]["parity"]["golden"]["bitwise"] is True
 
 
+@pytest.mark.gpu
+def test_bench_line_survives_a_variant_that_hangs():
+    # A later A/B variant that never returns (a collective one rank never joins, a kernel that never finishes) must not cost the run its line:
+    # rank 0's watchdog writes the line as it stands -- the default's figure, the variants measured so far -- and ends the run with a non-zero
+    # code (which is what makes the launcher tear the other ranks down).
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    port = 29850 + os.getpid() % 40
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--transport", "peer", "--cube-edge", "64", "--steps", "4",
+                          "--warmup", "2", "--no-sustained", "--variant-timeout", "6", "--debug-hang-variant", "peer/serial-graph"],
+                         capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode != 0
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:] + out.stderr[-2000:]
+    j = json.loads(lines[0])
+    ab = j["config"]["schedule_ab"]
+    assert j["value"] > 0 and ab["default"] == "peer/auto" and ab["variants"][0]["golden"]["bitwise"] is True
+    assert "peer/serial-graph" not in [v["name"] for v in ab["variants"] if "value" in v]          # the hanging one never reported
+    assert "exceeded its time limit" in out.stderr
+
+
 def test_traffic_file_entries_match_the_compulsory_model_of_a_host_built_plan():
     # profiles/hbm_traffic.json must not go stale: every entry is within 3 % of 49 B per particle + the tile streams
     # (4 B per dictionary-coded slot -- or 16 B (heterogeneous: 40 B) per lane of a 128-lane workgroup where the slots are lane-packed: single-rank spring
