@@ -49,7 +49,11 @@ typedef struct sb_group sb_group;      /* opaque, plugin-owned */
 /* desc: the settings of EVERY rank (gravity, damping, tile_particles, partition, part_dims, plan_flags, halo_transport, halo_schedule,
  * debug_flags); its device / rank / world fields are ignored. devices: n_devices HIP ordinals, rank r runs on devices[r] (NULL = 0, 1, ...,
  * n_devices - 1); an ordinal may repeat (several ranks on one device: tests). n_devices = 1 is a plain single-device solver behind the same
- * entry points, so a component needs only this header. The ranks' solvers exist from here on (sb_group_get_rank: sb_set_tuning). */
+ * entry points, so a component needs only this header. The ranks' solvers exist from here on (sb_group_get_rank: sb_set_tuning).
+ * Calling convention: calls on ONE group must not overlap in time (a component calls from Unity's main thread; the group's own threads
+ * are an implementation detail behind each call); different groups are independent. A call that fails changes nothing it can avoid
+ * changing, with one exception: after a failed sb_group_finalize (or a failed sb_group_step: a rank's device or transport error) the group
+ * is good for sb_group_destroy only -- its ranks may no longer be in the same tick state. */
 int sb_group_create(const sb_desc *desc, const int32_t *devices, int32_t n_devices, uint32_t flags, sb_group **out);
 int sb_group_destroy(sb_group *g);
 
