@@ -131,6 +131,7 @@ namespace SoftbodyMI355X
         public const int TransportRccl = 0, TransportPeer = 1;
         public const int ScheduleAuto = 0, ScheduleSerialEager = 1, ScheduleSerialGraph = 2, ScheduleOverlapEager = 3, ScheduleOverlapGraph = 4;
         public const uint GroupWalk = 1;       // sb_group_create flags: no plugin threads, the calling thread walks the tick across the ranks
+        public const uint GroupWholeMesh = 2;  // never cut windows: every rank plans the whole mesh (sb_group_finalize)
 
         [DllImport(Lib, CallingConvention = CC)] public static extern void sb_desc_default(ref SbDesc d);
         [DllImport(Lib, CallingConvention = CC)] public static extern int sb_create(ref SbDesc desc, out IntPtr solver);

@@ -42,6 +42,7 @@ extern "C" {
 #endif
 
 #define SB_GROUP_WALK 1u               /* sb_group_create flags: no plugin threads, the calling thread walks the tick across the ranks (see above) */
+#define SB_GROUP_WHOLE_MESH 2u         /* never cut windows: every rank is handed (and plans) the whole mesh, whatever the partition (see sb_group_finalize) */
 
 typedef struct sb_group sb_group;      /* opaque, plugin-owned */
 
@@ -65,10 +66,13 @@ int sb_group_set_volume_constraints(sb_group *g, const int32_t *ijkl, const floa
 int sb_group_set_bending_constraints(sb_group *g, const int32_t *ijkl, const float *rest_cs, int32_t m, float compliance);
 int sb_group_set_ground_plane(sb_group *g, float nx, float ny, float nz, float d, int32_t enabled);
 /* Plan, partition, upload on every device (the ranks plan side by side on host threads), connect the transport, verify that the ranks
- * planned consistently (plan hash + pair hashes, as sb_finalize does across processes). With sb_desc.partition = SB_PARTITION_BLOCKS -- or
- * SB_PARTITION_AUTO on a mesh of at least 2 M particles that fills its bounding box (a lattice-like body, for which AUTO takes the block grid
- * anyway) -- every rank is handed only ITS WINDOW of the mesh (sharded authoring, cut here from the one copy the group holds); otherwise every
- * rank plans the whole mesh (SB_PARTITION_AUTO may then choose RCB for a mesh that fills its box unevenly). */
+ * planned consistently (plan hash + pair hashes, as sb_finalize does across processes).
+ * Sharded authoring: every rank is handed only ITS WINDOW of the mesh (cut here from the one copy the group holds) instead of the whole
+ * mesh where that is known to reproduce the whole-mesh plan -- a LATTICE-LIKE body: distance constraints only, filling its bounding box
+ * (sb_domain.fill = 1) -- and the partition is the block grid: sb_desc.partition = SB_PARTITION_BLOCKS, or SB_PARTITION_AUTO on at least
+ * 2 M particles (for which AUTO takes the block grid anyway; below that, eight whole-mesh plans cost less than they save). Every other mesh
+ * (tets, hinges, a body that fills its box unevenly: their colouring and leftover layers are not local to a window) is planned whole on
+ * every rank, under whatever partition was asked for (SB_PARTITION_AUTO may then choose RCB). SB_GROUP_WHOLE_MESH forces that for any mesh. */
 int sb_group_finalize(sb_group *g);
 
 /* ---- the hot path (FixedUpdate) ---------------------------------------------------------------------------------------------------------- */

@@ -380,7 +380,7 @@ int sb_group_create(const sb_desc *desc, const int32_t *devices, int32_t n_devic
     if (!desc || !out) return fail(SB_ERR_INVALID_ARG, "sb_group_create: null argument");
     *out = nullptr;
     if (n_devices < 1 || n_devices > 64) return fail(SB_ERR_INVALID_ARG, "sb_group_create: n_devices must be 1 .. 64");
-    if (flags & ~SB_GROUP_WALK) return fail(SB_ERR_INVALID_ARG, "sb_group_create: unknown bit in flags");
+    if (flags & ~(SB_GROUP_WALK | SB_GROUP_WHOLE_MESH)) return fail(SB_ERR_INVALID_ARG, "sb_group_create: unknown bit in flags");
     if ((flags & SB_GROUP_WALK) && n_devices > 1) {
         if (desc->halo_schedule == SB_SCHEDULE_SERIAL_GRAPH || desc->halo_schedule == SB_SCHEDULE_OVERLAP_GRAPH)
             return fail(SB_ERR_UNSUPPORTED, "sb_group_create: SB_GROUP_WALK runs the eager schedules only (a capture spanning several devices' streams is not built)");
@@ -473,18 +473,21 @@ int sb_group_finalize(sb_group *g) {
     int rc = guarded([&]() -> int {
         // ---- the mesh to every rank: its window under the block partition (sharded authoring), else the whole mesh ----
         sb_domain dom{};
-        // windows (sharded authoring) under the block partition: asked for (SB_PARTITION_BLOCKS), or SB_PARTITION_AUTO on a LARGE mesh that fills
-        // its bounding box (a lattice-like body: the block grid is what AUTO takes for it anyway, and eight whole-mesh plans of 16.8 M
-        // particles are 26 GB of host memory and 8 x 4.9 s of planning against 8 x 0.6 s on windows)
+        // Windows (sharded authoring) where they are known to reproduce the whole-mesh plan: a lattice-like body (distance constraints only,
+        // filling its bounding box -- colours, tiles and leftovers of such a mesh are local to a window; a tet mesh's or a cloth's are not:
+        // tools/fuzz_parity.py found every such mesh refused by the ranks' agreement check) under the block partition -- asked for
+        // (SB_PARTITION_BLOCKS), or SB_PARTITION_AUTO on a LARGE mesh (the block grid is what AUTO takes for it anyway, and eight whole-mesh
+        // plans of 16.8 M particles are 26 GB of host memory and 8 x 4.9 s of planning against 8 x 0.6 s on windows).
         constexpr int32_t kAutoShardParticles = 1 << 21;
-        const bool may_shard = W > 1 && g->desc.tile_particles >= 0 && (g->desc.partition == SB_PARTITION_BLOCKS || (g->desc.partition == SB_PARTITION_AUTO && g->n >= kAutoShardParticles));
+        const bool may_shard = W > 1 && !(g->flags & SB_GROUP_WHOLE_MESH) && g->desc.tile_particles >= 0 && g->vol_rest.empty() && g->bend_rest.empty() &&
+                               (g->desc.partition == SB_PARTITION_BLOCKS || (g->desc.partition == SB_PARTITION_AUTO && g->n >= kAutoShardParticles));
         g->sharded = false;
         if (may_shard) {
             const std::vector<float> &rp = g->rest.empty() ? g->pos : g->rest;
             const int rc0 = sb_domain_from_mesh(rp.data(), g->n, g->dist_ij.data(), (int32_t)g->dist_rest.size(), g->vol_ijkl.data(), (int32_t)g->vol_rest.size(),
                                                 g->bend_ijkl.data(), (int32_t)(g->bend_rest.size() / 2), &dom);
             if (rc0) return rc0;
-            g->sharded = g->desc.partition == SB_PARTITION_BLOCKS || dom.fill >= 1.0;
+            g->sharded = dom.fill >= 1.0;
         }
         g->pinned.assign((size_t)g->n, 0);
         for (int32_t p = 0; p < g->n; ++p) g->pinned[(size_t)p] = g->invm[(size_t)p] == 0.0f;

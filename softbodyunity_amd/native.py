@@ -24,6 +24,7 @@ SB_TRANSPORT_RCCL, SB_TRANSPORT_PEER = 0, 1
 SB_SCHEDULE_AUTO, SB_SCHEDULE_SERIAL_EAGER, SB_SCHEDULE_SERIAL_GRAPH, SB_SCHEDULE_OVERLAP_EAGER, SB_SCHEDULE_OVERLAP_GRAPH = 0, 1, 2, 3, 4
 SB_DEBUG_NO_COMM, SB_DEBUG_LOOPBACK = 1, 2
 SB_GROUP_WALK = 1
+SB_GROUP_WHOLE_MESH = 2
 # sb_tuning.flags (include/softbody_debug.h): A/B measurement switches, same bits for every setting
 (SB_TUNE_NO_MASS_PALETTE, SB_TUNE_NO_UNIFORM_MASS, SB_TUNE_NO_PALETTE, SB_TUNE_NO_WAVE_ITEMS, SB_TUNE_NO_LANE_PACK, SB_TUNE_NO_COST_ORDER,
  SB_TUNE_NO_FUSED_UNPACK, SB_TUNE_PEER_COARSE, SB_TUNE_NO_LAZY_TICK, SB_TUNE_NO_PACK, SB_TUNE_NO_PEEK, SB_TUNE_NO_KIN_FUSE,

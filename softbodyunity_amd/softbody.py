@@ -283,8 +283,9 @@ class SoftbodyGroup:
     def __init__(self, mesh, devices, substeps=20, fixed_delta_time=0.02, gravity=(0.0, -9.81, 0.0), damping=0.0,
                  distance_compliance=0.0, volume_compliance=0.0, bending_compliance=0.0, part_dims=(0, 0, 0), tile_particles=0,
                  use_graph=True, ground_plane=None, partition=native.SB_PARTITION_AUTO, plan_flags=None,
-                 halo_transport=native.SB_TRANSPORT_RCCL, halo_schedule=native.SB_SCHEDULE_AUTO, debug_flags=0, walk=False, tuning=None):
+                 halo_transport=native.SB_TRANSPORT_RCCL, halo_schedule=native.SB_SCHEDULE_AUTO, debug_flags=0, walk=False, tuning=None, whole_mesh=False):
         self.mesh = mesh
+        self.whole_mesh = bool(whole_mesh)
         self.devices = [int(d) for d in devices]
         self.substeps, self.fixed_delta_time = int(substeps), float(fixed_delta_time)
         self.gravity, self.damping = tuple(float(g) for g in gravity), float(damping)
@@ -311,7 +312,7 @@ class SoftbodyGroup:
         d.halo_transport, d.halo_schedule, d.debug_flags = self.halo_transport, self.halo_schedule, self.debug_flags
         devs = (C.c_int32 * len(self.devices))(*self.devices)
         g = C.c_void_p()
-        check(L.sb_group_create(C.byref(d), devs, len(self.devices), native.SB_GROUP_WALK if self.walk else 0, C.byref(g)))
+        check(L.sb_group_create(C.byref(d), devs, len(self.devices), (native.SB_GROUP_WALK if self.walk else 0) | (native.SB_GROUP_WHOLE_MESH if self.whole_mesh else 0), C.byref(g)))
         self._g = g
         try:
             tune = native.tuning_from_env() if self.tuning is None else self.tuning

@@ -1,0 +1,23 @@
+"""A fixed slice of the randomised differential test (tools/fuzz_parity.py): random meshes, settings, tuning switches, host models (one solver,
+hosted ranks, sb_group_*) and mid-run host actions, every result bitwise against the CPU oracle. The seeds are fixed, so the test is the same
+run every time; the open-ended form is `python tools/fuzz_parity.py --seconds N --seed S` (profiles/r04x_fuzz_parity.txt)."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.gpu
+def test_fixed_slice_of_the_fuzzer_is_bitwise():
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--seed", "0", "--max", "160", "--seconds", "400"],
+                       capture_output=True, text=True, timeout=600)
+    lines = r.stdout.splitlines()
+    summary = [l for l in lines if l.startswith("SUMMARY")]
+    bad = [l for l in lines if l.split(" ", 1)[0] in ("MISMATCH", "ERROR", "CRASH")]
+    assert summary and not bad and r.returncode == 0, "\n".join(bad[:5] + summary + [r.stderr[-800:]])
+    assert "160 scenarios" in summary[0], summary[0]
+    # the slice holds what once failed: a cloth and a tet blob through a group under the block partition (planned whole since: seeds 13, 76)
+    assert any(" seed=13," in l and l.startswith("OK") for l in lines) and any(" seed=76," in l and l.startswith("OK") for l in lines)

@@ -1,0 +1,293 @@
+#!/usr/bin/env python3
+"""Randomised differential test: random meshes, settings, tuning switches, host models and mid-run host actions through the plugin, every
+result compared BITWISE with the CPU oracle walking the plan the plugin published (test infrastructure: the oracle is the checker).
+
+What varies per scenario (all from one seed, printed, so a failure replays with --only SEED):
+  mesh      lattice cube (structural springs; optionally every mass / rest length its own, a pinned top layer), tet blob with volume and
+            bending constraints, cloth sheet with bending constraints
+  settings  substeps, dt, tile size (incl. automatic and no tiling), compliances, damping, ground plane, hipGraph replay
+  tuning    a random subset of the sb_tuning switches and widths (include/softbody_debug.h: "every setting gives the same bits")
+  host      one solver | W ranks hosted in this process with the host as the wire (partition AUTO / BLOCKS / RCB) |
+            sb_group_* over the peer transport on one device (thread per rank or walked by the calling thread)
+  actions   between ticks: a blocking position read (the peek / the flush), kinematic moves of pinned particles, a pipelined render
+            readback -- each mirrored on the oracle
+Every scenario also runs the table validator. usage: python tools/fuzz_parity.py [--seconds 240] [--seed 0] [--only SEED] [--max N]"""
+import argparse
+import ctypes as C
+import os
+import sys
+import time
+import traceback
+
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")        # (several ranks of one process on one device: a hardware queue each, before the first HIP call)
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+import numpy as np                                                      # noqa: E402
+
+from oracle import oracle                                               # noqa: E402  (the checker)
+from helpers import build_plan, make_oracle                             # noqa: E402
+from hosted import HostedRanks                                          # noqa: E402
+from softbodyunity_amd import Softbody, SoftbodyGroup, native           # noqa: E402
+from softbodyunity_amd.mesh import bunny_surrogate, from_triangle_mesh, jelly_cube   # noqa: E402
+
+# switches that change kernel selection or table layout, never results (AUTO_* / PEER_COARSE concern transports that do not run here)
+FLAGS = ["NO_MASS_PALETTE", "NO_UNIFORM_MASS", "NO_PALETTE", "NO_WAVE_ITEMS", "NO_LANE_PACK", "NO_COST_ORDER", "NO_FUSED_UNPACK", "NO_LAZY_TICK",
+         "NO_PACK", "NO_PEEK", "NO_KIN_FUSE", "NO_WIDE_SLOTS"]
+
+
+def bits(a):
+    return np.ascontiguousarray(a).view(np.uint32)
+
+
+def grid_cloth(a, b):
+    xs, ys = np.meshgrid(np.arange(a), np.arange(b), indexing="ij")
+    V = np.stack([xs.ravel(), np.zeros(a * b), ys.ravel()], axis=1).astype(np.float32)
+    F = []
+    for i in range(a - 1):
+        for j in range(b - 1):
+            p, q, r, s = i * b + j, (i + 1) * b + j, (i + 1) * b + j + 1, i * b + j + 1
+            F += [(p, q, r), (p, r, s)]
+    return V, np.array(F, np.int32)
+
+
+def make_scenario(seed):
+    rng = np.random.default_rng(seed)
+    sc = {"seed": seed}
+    kind = rng.choice(["cube", "cube", "tets", "cloth"])
+    sc["kind"] = str(kind)
+    if kind == "cube":
+        n = int(rng.integers(3, 34))
+        het, pin = bool(rng.random() < 0.3), bool(rng.random() < 0.5)
+        mesh = jelly_cube(n, pin_top=pin, heterogeneous=het, seed=int(rng.integers(1, 10 ** 6)))
+        sc["mesh"] = f"cube {n}^3 het={int(het)} pin_top={int(pin)}"
+        comp = (float(rng.choice([0.0, 0.0, 1e-7, 1e-5])), 0.0, 0.0)
+    elif kind == "tets":
+        tv = int(rng.choice([300, 800, 2000, 5000, 12000]))
+        mesh = bunny_surrogate(target_verts=tv, seed=int(rng.integers(1, 10 ** 6)))
+        sc["mesh"] = f"tet blob ~{tv} vertices ({mesh.n} particles, {len(mesh.vol_rest)} tets, {len(mesh.bend_rest)} hinges)"
+        comp = (float(rng.choice([0.0, 1e-7])), float(rng.choice([0.0, 1e-7])), float(rng.choice([1e-5, 1e-4, 1e-3])))
+        if rng.random() < 0.5:       # pins: the particles highest up
+            mesh.inv_mass[mesh.pos[:, 1] > np.quantile(mesh.pos[:, 1], 0.97)] = 0.0
+    else:
+        a, b = int(rng.integers(4, 50)), int(rng.integers(4, 50))
+        V, F = grid_cloth(a, b)
+        mesh, _ = from_triangle_mesh(V, F)
+        mesh.inv_mass[mesh.rest_pos[:, 0] == 0] = 0.0
+        sc["mesh"] = f"cloth {a}x{b} ({mesh.n} particles, {len(mesh.bend_rest)} hinges)"
+        comp = (float(rng.choice([0.0, 1e-7])), 0.0, float(rng.choice([1e-4, 1e-3, 1e-2])))
+    sc["_mesh"] = mesh
+    sc["compliance"] = comp
+    sc["substeps"] = int(rng.choice([1, 2, 3, 4, 5, 6, 8]))
+    sc["ticks"] = int(rng.integers(1, 5))
+    sc["dt"] = float(rng.choice([0.02, 0.01]))
+    sc["tile"] = int(rng.choice([0, 0, 64, 128, 256, 512, -1]))
+    sc["damping"] = float(rng.choice([0.0, 0.0, 0.02, 0.5]))
+    ymin = float(mesh.pos[:, 1].min())
+    sc["plane"] = (0.0, 1.0, 0.0, ymin - float(rng.choice([0.0, 0.05, 0.5]))) if rng.random() < 0.4 else None
+    sc["graph"] = bool(rng.random() < 0.5)
+    # tuning
+    t = {"flags": [f for f in FLAGS if rng.random() < 0.2]}
+    t["tile_lanes"] = int(rng.choice([0, 0, 0, 128, 256, 512]))
+    t["quad_lanes"] = int(rng.choice([0, 0, 256]))
+    t["narrow_min_tiles"] = int(rng.choice([0, 0, 1, 40]))
+    t["store_through_max_tiles"] = int(rng.choice([-1, -1, 0, 10 ** 6]))
+    t["store_through_large"] = int(rng.choice([0, 0, 1, 2, 3]))
+    t["peek_min_tiles"] = int(rng.choice([-1, 0, 0, 4]))
+    t["win_dwords"] = int(rng.choice([0, 0, 1024, 2048]))
+    sc["tuning"] = t
+    # host model
+    host = str(rng.choice(["single", "single", "hosted", "group"]))
+    sc["host"] = host
+    if host != "single":
+        sc["world"] = int(rng.choice([2, 3, 4, 8] if host == "hosted" else [2, 3, 4]))
+        sc["partition"] = str(rng.choice(["auto", "blocks", "rcb"]))
+        sc["walk"] = bool(rng.random() < 0.5)
+        sc["whole_mesh"] = bool(rng.random() < 0.3)
+        if sc["tile"] == -1:
+            sc["tile"] = 0
+    # host actions per tick (single and group): r = blocking read, k = kinematic move, b = pipelined render readback
+    pins = np.nonzero(mesh.inv_mass == 0)[0].astype(np.int32)
+    sc["_pins"] = pins
+    acts = []
+    for _ in range(sc["ticks"]):
+        a = ""
+        if host != "hosted":
+            if rng.random() < 0.35:
+                a += "r"
+            if len(pins) and rng.random() < 0.5:
+                a += "k"
+            if rng.random() < 0.25:
+                a += "b"
+        acts.append(a)
+    sc["actions"] = acts
+    sc["_move"] = rng.uniform(-0.2, 0.2, (sc["ticks"], 3)).astype(np.float32)
+    return sc
+
+
+def describe(sc):
+    return ", ".join(f"{k}={v}" for k, v in sc.items() if not k.startswith("_"))
+
+
+def make_tuning(t):
+    tune = native.SbTuning()
+    native.lib().sb_tuning_default(C.byref(tune))
+    for f in t["flags"]:
+        tune.flags |= getattr(native, "SB_TUNE_" + f)
+    for k in ("tile_lanes", "quad_lanes", "narrow_min_tiles", "store_through_max_tiles", "store_through_large", "peek_min_tiles", "win_dwords"):
+        setattr(tune, k, t[k])
+    return tune
+
+
+PART = {"auto": native.SB_PARTITION_AUTO, "blocks": native.SB_PARTITION_BLOCKS, "rcb": native.SB_PARTITION_RCB}
+
+
+def run(sc):
+    """-> (verdict, detail): verdict in OK / MISMATCH / REFUSED (the plugin declined the combination with a message) / ERROR"""
+    mesh, S, dt, comp = sc["_mesh"], sc["substeps"], sc["dt"], sc["compliance"]
+    kw = dict(substeps=S, fixed_delta_time=dt, tile_particles=sc["tile"], damping=sc["damping"], distance_compliance=comp[0], volume_compliance=comp[1],
+              bending_compliance=comp[2], ground_plane=sc["plane"], use_graph=sc["graph"], tuning=make_tuning(sc["tuning"]))
+    checks = []       # (label, got, want) compared bitwise at the end
+    why = []
+
+    try:
+        if sc["host"] == "hosted":
+            with HostedRanks(mesh, sc["world"], S, dt=dt, partition=PART[sc["partition"]], **{k: v for k, v in kw.items() if k not in ("substeps", "fixed_delta_time")}) as H:
+                for _ in range(sc["ticks"]):
+                    H.tick()
+                x, v, ghosts = H.merged_state()
+                val = [sb.validate() for sb in H.ranks]
+            checks_state = (x, v)
+        elif sc["host"] == "group":
+            g = SoftbodyGroup(mesh, [0] * sc["world"], halo_transport=native.SB_TRANSPORT_PEER, walk=sc["walk"], whole_mesh=sc["whole_mesh"], partition=PART[sc["partition"]], **kw).Start()
+            try:
+                checks_state, val = drive(sc, g, checks, group=True)
+            finally:
+                g.OnDestroy()
+        else:
+            sb = Softbody(mesh, **kw).Start()
+            try:
+                checks_state, val = drive(sc, sb, checks, group=False)
+            finally:
+                sb.OnDestroy()
+    except native.SoftbodyError as e:
+        # (SB_ERR_UNSUPPORTED = the plugin declines a combination by design; anything else a scenario of this generator provokes is a finding)
+        return ("REFUSED" if e.code == native.SB_ERR_UNSUPPORTED else "ERROR"), str(e)[:300]
+    # ---- the oracle, same sequence ----
+    # (a plan of its own from the host-only planner, same mesh and tile size: the published order does not depend on the partition, the
+    # host model or any tuning switch -- which is part of what is being tested)
+    ref_plan = build_plan(mesh, tile_particles=sc["tile"])
+    o = make_oracle(oracle, mesh, ref_plan, damping=sc["damping"], compliance=comp, ground_plane=sc["plane"])
+    k = 0
+    for t in range(sc["ticks"]):
+        acts = sc["actions"][t]
+        if "k" in acts:
+            o.set_kinematic_positions(sc["_pins"], mesh.pos[sc["_pins"]] + sc["_move"][t])
+        if "r" in acts:
+            want = o.x.copy(); label, got = checks[k]; k += 1
+            if not np.array_equal(bits(got), bits(want)):
+                why.append(label)
+        o.step(dt, S)
+        if "b" in acts:
+            want = o.x.copy(); label, got = checks[k]; k += 1
+            if not np.array_equal(bits(got), bits(want)):
+                why.append(label)
+    x, v = checks_state
+    if not np.array_equal(bits(x), bits(o.x)):
+        why.append(f"final positions ({int((bits(x) != bits(o.x)).any(axis=1).sum())} of {mesh.n} particles differ)")
+    if not np.array_equal(bits(v), bits(o.v)):
+        why.append("final velocities")
+    if not all(r["errors"] == [0] * 6 for r in val):
+        why.append(f"table validator: {[r['errors'] for r in val]}")
+    if not np.isfinite(o.x).all():
+        why.append("(the oracle's own state is not finite)")
+    return ("MISMATCH", "; ".join(why)) if why else ("OK", "")
+
+
+def drive(sc, sb, checks, group):
+    mesh = sc["_mesh"]
+    for t in range(sc["ticks"]):
+        acts = sc["actions"][t]
+        if "k" in acts:
+            sb.set_kinematic_positions(sc["_pins"], mesh.pos[sc["_pins"]] + sc["_move"][t])
+        if "r" in acts:
+            checks.append((f"read before tick {t}", sb.get_positions().copy()))
+        sb.step()
+        if "b" in acts:
+            sb.readback_begin()
+            checks.append((f"render readback after tick {t}", np.array(sb.readback_end(), copy=True)))
+    x, v = sb.get_positions().copy(), sb.get_velocities().copy()
+    if group:
+        val = [sb.rank(r).validate() for r in range(sc["world"])]
+    else:
+        val = [sb.validate()]
+    return (x, v), val
+
+
+def child(a):
+    """Scenarios in THIS process until the time is up; one line before and one after each (the parent tells a crash from the missing second)."""
+    t_end = time.time() + a.seconds
+    seeds = [a.only] if a.only is not None else range(a.seed, a.seed + a.max)
+    for seed in seeds:
+        if time.time() > t_end:
+            break
+        sc = make_scenario(seed)
+        print(f"START {seed} {describe(sc)}", flush=True)
+        t0 = time.time()
+        try:
+            verdict, detail = run(sc)
+        except Exception as e:       # a bug of the harness or an assertion of the test infrastructure: report, go on
+            verdict, detail = "ERROR", f"{type(e).__name__}: {e} | {traceback.format_exc().splitlines()[-3:]}"
+        print(f"DONE {seed} {verdict} {time.time() - t0:.1f}s {detail}", flush=True)
+    print("END", flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--only", type=int, default=None)
+    ap.add_argument("--max", type=int, default=10 ** 9)
+    ap.add_argument("--child", action="store_true")
+    a = ap.parse_args()
+    if a.child:
+        return child(a)
+    # the scenarios run in a child process: a crash (the plugin's, or a GPU fault's abort) costs one scenario, not the run
+    import subprocess
+    t_end = time.time() + a.seconds
+    tally, n, seed = {}, 0, (a.only if a.only is not None else a.seed)
+    last = seed + (1 if a.only is not None else a.max)
+    while seed < last and time.time() < t_end:
+        cmd = [sys.executable, "-X", "faulthandler", os.path.abspath(__file__), "--child", "--seed", str(seed), "--max", str(last - seed),
+               "--seconds", str(max(1.0, t_end - time.time()))]
+        p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+        started, desc, ended = None, "", False
+        for line in p.stdout:
+            line = line.rstrip("\n")
+            if line.startswith("START "):
+                _, sd, desc = line.split(" ", 2); started = int(sd)
+            elif line.startswith("DONE "):
+                _, sd, verdict, secs, *rest = line.split(" ", 4)
+                detail = rest[0] if rest else ""
+                tally[verdict] = tally.get(verdict, 0) + 1; n += 1
+                print(f"{verdict:8s} {secs:>6s}  {desc}" + (f"\n         -> {detail}" if detail else ""), flush=True)
+                seed = int(sd) + 1; started = None
+            elif line == "END":
+                ended = True
+        err = p.stderr.read()
+        rc = p.wait()
+        if started is not None:      # died inside a scenario
+            tally["CRASH"] = tally.get("CRASH", 0) + 1; n += 1
+            print(f"CRASH    rc={rc}  {desc}\n         -> {err[-1500:]}", flush=True)
+            seed = started + 1
+        elif ended:
+            break
+        elif rc != 0:
+            print(f"fuzz_parity: the child ended with rc={rc} outside a scenario: {err[-800:]}", flush=True)
+            break
+    print(f"SUMMARY {n} scenarios: " + ", ".join(f"{k} {v}" for k, v in sorted(tally.items())), flush=True)
+    return 1 if (tally.get("MISMATCH", 0) or tally.get("ERROR", 0) or tally.get("CRASH", 0)) else 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
