@@ -9,8 +9,9 @@ What varies per scenario (all from one seed, printed, so a failure replays with 
   tuning    a random subset of the sb_tuning switches and widths (include/softbody_debug.h: "every setting gives the same bits")
   host      one solver | W ranks hosted in this process with the host as the wire (partition AUTO / BLOCKS / RCB) |
             sb_group_* over the peer transport on one device (thread per rank or walked by the calling thread)
-  actions   between ticks: a blocking position read (the peek / the flush), kinematic moves of pinned particles, a pipelined render
-            readback -- each mirrored on the oracle
+  actions   between ticks: set_state, the ground plane moved or switched, kinematic moves of pinned particles, a blocking position read (the
+            peek / the flush), a tick with its own dt and substeps, a pipelined render readback (whole array, with GPU normals, render set
+            only) -- each mirrored on the oracle
 Every scenario also runs the table validator. usage: python tools/fuzz_parity.py [--seconds 240] [--seed 0] [--only SEED] [--max N]"""
 import argparse
 import ctypes as C
@@ -30,6 +31,7 @@ from helpers import build_plan, make_oracle                             # noqa: 
 from hosted import HostedRanks                                          # noqa: E402
 from softbodyunity_amd import Softbody, SoftbodyGroup, native           # noqa: E402
 from softbodyunity_amd.mesh import bunny_surrogate, from_triangle_mesh, jelly_cube   # noqa: E402
+from readback_bench import surface_triangles                            # noqa: E402
 
 # switches that change kernel selection or table layout, never results (AUTO_* / PEER_COARSE concern transports that do not run here)
 FLAGS = ["NO_MASS_PALETTE", "NO_UNIFORM_MASS", "NO_PALETTE", "NO_WAVE_ITEMS", "NO_LANE_PACK", "NO_COST_ORDER", "NO_FUSED_UNPACK", "NO_LAZY_TICK",
@@ -59,8 +61,10 @@ def make_scenario(seed):
     if kind == "cube":
         n = int(rng.integers(3, 34))
         het, pin = bool(rng.random() < 0.3), bool(rng.random() < 0.5)
-        mesh = jelly_cube(n, pin_top=pin, heterogeneous=het, seed=int(rng.integers(1, 10 ** 6)))
-        sc["mesh"] = f"cube {n}^3 het={int(het)} pin_top={int(pin)}"
+        full = bool(n <= 12 and rng.random() < 0.25)       # 26-neighbour stencil: many colours, global colours, leftover layers
+        mesh = jelly_cube(n, pin_top=pin, heterogeneous=het, seed=int(rng.integers(1, 10 ** 6)), stencil="full" if full else "structural")
+        sc["mesh"] = f"cube {n}^3 het={int(het)} pin_top={int(pin)} stencil={'full' if full else 'structural'}"
+        sc["_tri"] = surface_triangles(n)
         comp = (float(rng.choice([0.0, 0.0, 1e-7, 1e-5])), 0.0, 0.0)
     elif kind == "tets":
         tv = int(rng.choice([300, 800, 2000, 5000, 12000]))
@@ -72,7 +76,8 @@ def make_scenario(seed):
     else:
         a, b = int(rng.integers(4, 50)), int(rng.integers(4, 50))
         V, F = grid_cloth(a, b)
-        mesh, _ = from_triangle_mesh(V, F)
+        mesh, pov = from_triangle_mesh(V, F)
+        sc["_tri"] = np.ascontiguousarray(pov[F], dtype=np.int32)
         mesh.inv_mass[mesh.rest_pos[:, 0] == 0] = 0.0
         sc["mesh"] = f"cloth {a}x{b} ({mesh.n} particles, {len(mesh.bend_rest)} hinges)"
         comp = (float(rng.choice([0.0, 1e-7])), 0.0, float(rng.choice([1e-4, 1e-3, 1e-2])))
@@ -106,22 +111,39 @@ def make_scenario(seed):
         sc["whole_mesh"] = bool(rng.random() < 0.3)
         if sc["tile"] == -1:
             sc["tile"] = 0
-    # host actions per tick (single and group): r = blocking read, k = kinematic move, b = pipelined render readback
+    # host actions per tick, in this order around the tick's step:
+    #   s = set_state (fresh positions and velocities), g = ground plane moved / switched, k = kinematic move, r = blocking read,
+    #   [the step, with this tick's own dt and substeps where the scenario varies them], b = pipelined render readback (n: with normals)
+    # hosted ranks (the host is the wire, launch by launch) take s and the per-tick dt / substeps only
     pins = np.nonzero(mesh.inv_mass == 0)[0].astype(np.int32)
     sc["_pins"] = pins
-    acts = []
+    vary = rng.random() < 0.3
+    sc["render"] = "none"
+    if host != "hosted" and "_tri" in sc and rng.random() < 0.5:
+        sc["render"] = str(rng.choice(["triangles", "render-set-only"]))
+    acts, per_tick = [], []
     for _ in range(sc["ticks"]):
         a = ""
+        if rng.random() < 0.12:
+            a += "s"
         if host != "hosted":
-            if rng.random() < 0.35:
-                a += "r"
+            if rng.random() < 0.12:
+                a += "g"
             if len(pins) and rng.random() < 0.5:
                 a += "k"
-            if rng.random() < 0.25:
-                a += "b"
+            if rng.random() < 0.35:
+                a += "r"
+            if rng.random() < 0.3:
+                a += "n" if sc["render"] != "none" else "b"
         acts.append(a)
+        per_tick.append((float(rng.choice([0.02, 0.01, 0.005])), int(rng.choice([1, 2, 3, 5, 7]))) if vary else (sc["dt"], sc["substeps"]))
     sc["actions"] = acts
+    sc["per_tick"] = per_tick if vary else "fixed"
+    sc["_per_tick"] = per_tick
     sc["_move"] = rng.uniform(-0.2, 0.2, (sc["ticks"], 3)).astype(np.float32)
+    sc["_state"] = [(mesh.pos + rng.uniform(-0.03, 0.03, mesh.pos.shape).astype(np.float32), rng.uniform(-0.5, 0.5, mesh.pos.shape).astype(np.float32))
+                    if "s" in a else None for a in acts]
+    sc["_planes"] = [(0.0, 1.0, 0.0, ymin - float(rng.choice([0.0, 0.1, 0.3])), int(rng.random() < 0.8)) if "g" in a else None for a in acts]
     return sc
 
 
@@ -153,7 +175,11 @@ def run(sc):
     try:
         if sc["host"] == "hosted":
             with HostedRanks(mesh, sc["world"], S, dt=dt, partition=PART[sc["partition"]], **{k: v for k, v in kw.items() if k not in ("substeps", "fixed_delta_time")}) as H:
-                for _ in range(sc["ticks"]):
+                for t in range(sc["ticks"]):
+                    if "s" in sc["actions"][t]:
+                        for sb in H.ranks:
+                            sb.set_state(*sc["_state"][t])
+                    H.dt, H.S = sc["_per_tick"][t]
                     H.tick()
                 x, v, ghosts = H.merged_state()
                 val = [sb.validate() for sb in H.ranks]
@@ -179,19 +205,32 @@ def run(sc):
     ref_plan = build_plan(mesh, tile_particles=sc["tile"])
     o = make_oracle(oracle, mesh, ref_plan, damping=sc["damping"], compliance=comp, ground_plane=sc["plane"])
     k = 0
+    tri = sc.get("_tri")
+
+    def compare(want):
+        nonlocal k
+        label, got = checks[k]; k += 1
+        if got.shape != want.shape or not np.array_equal(bits(got), bits(want)):
+            why.append(label)
+
     for t in range(sc["ticks"]):
         acts = sc["actions"][t]
+        if "s" in acts:
+            o.x[:] = sc["_state"][t][0]; o.v[:] = sc["_state"][t][1]
+        if "g" in acts:
+            pl = sc["_planes"][t]
+            o.set_ground_plane(pl[:3], pl[3], bool(pl[4]))
         if "k" in acts:
             o.set_kinematic_positions(sc["_pins"], mesh.pos[sc["_pins"]] + sc["_move"][t])
         if "r" in acts:
-            want = o.x.copy(); label, got = checks[k]; k += 1
-            if not np.array_equal(bits(got), bits(want)):
-                why.append(label)
-        o.step(dt, S)
-        if "b" in acts:
-            want = o.x.copy(); label, got = checks[k]; k += 1
-            if not np.array_equal(bits(got), bits(want)):
-                why.append(label)
+            compare(o.x.copy())
+        o.step(*sc["_per_tick"][t])
+        if "b" in acts or "n" in acts:
+            rs = np.unique(tri) if (sc["render"] == "render-set-only") else None
+            compare(o.x.copy() if rs is None else o.x[rs].copy())
+            if "n" in acts:
+                nrm = oracle.vertex_normals(o.x, tri)
+                compare(nrm if rs is None else nrm[rs])
     x, v = checks_state
     if not np.array_equal(bits(x), bits(o.x)):
         why.append(f"final positions ({int((bits(x) != bits(o.x)).any(axis=1).sum())} of {mesh.n} particles differ)")
@@ -206,16 +245,31 @@ def run(sc):
 
 def drive(sc, sb, checks, group):
     mesh = sc["_mesh"]
+    L = native.lib()
+    if sc["render"] != "none":
+        sb.set_render_triangles(sc["_tri"])
+        if sc["render"] == "render-set-only":
+            sb.set_readback_render_set_only(True)
     for t in range(sc["ticks"]):
         acts = sc["actions"][t]
+        if "s" in acts:
+            sb.set_state(*sc["_state"][t])
+        if "g" in acts:
+            pl = sc["_planes"][t]
+            native.check((L.sb_group_set_ground_plane if group else L.sb_set_ground_plane)(sb._g if group else sb._h, *[float(c) for c in pl[:4]], int(pl[4])))
         if "k" in acts:
             sb.set_kinematic_positions(sc["_pins"], mesh.pos[sc["_pins"]] + sc["_move"][t])
         if "r" in acts:
             checks.append((f"read before tick {t}", sb.get_positions().copy()))
-        sb.step()
-        if "b" in acts:
+        sb.step(*sc["_per_tick"][t])
+        if "b" in acts or "n" in acts:
             sb.readback_begin()
-            checks.append((f"render readback after tick {t}", np.array(sb.readback_end(), copy=True)))
+            if "n" in acts:
+                pos, nrm = sb.readback_end(normals=True)
+                checks.append((f"render readback after tick {t}", np.array(pos, copy=True)))
+                checks.append((f"render normals after tick {t}", np.array(nrm, copy=True)))
+            else:
+                checks.append((f"render readback after tick {t}", np.array(sb.readback_end(), copy=True)))
     x, v = sb.get_positions().copy(), sb.get_velocities().copy()
     if group:
         val = [sb.rank(r).validate() for r in range(sc["world"])]
