@@ -21,3 +21,15 @@ def test_fixed_slice_of_the_fuzzer_is_bitwise():
     assert "160 scenarios" in summary[0], summary[0]
     # the slice holds what once failed: a cloth and a tet blob through a group under the block partition (planned whole since: seeds 13, 76)
     assert any(" seed=13," in l and l.startswith("OK") for l in lines) and any(" seed=76," in l and l.startswith("OK") for l in lines)
+
+
+@pytest.mark.gpu
+def test_fixed_slice_of_the_schedule_fuzzer_is_bitwise():
+    """tools/fuzz_schedules.py: one rank with a self-exchange, every drawn (transport, schedule) pair against the serialised eager schedule."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_schedules.py"), "--seed", "0", "--max", "10", "--seconds", "300"],
+                       capture_output=True, text=True, timeout=600)
+    lines = r.stdout.splitlines()
+    summary = [l for l in lines if l.startswith("SUMMARY")]
+    bad = [l for l in lines if l.split(" ", 1)[0] in ("MISMATCH", "ERROR", "CRASH")]
+    assert summary and not bad and r.returncode == 0, "\n".join(bad[:5] + summary + [r.stderr[-800:]])
+    assert "10 scenarios" in summary[0], summary[0]

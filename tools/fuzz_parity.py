@@ -278,7 +278,7 @@ def drive(sc, sb, checks, group):
     return (x, v), val
 
 
-def child(a):
+def child(a, make_scenario, run):
     """Scenarios in THIS process until the time is up; one line before and one after each (the parent tells a crash from the missing second)."""
     t_end = time.time() + a.seconds
     seeds = [a.only] if a.only is not None else range(a.seed, a.seed + a.max)
@@ -296,7 +296,9 @@ def child(a):
     print("END", flush=True)
 
 
-def main():
+def main(make_scenario=make_scenario, run=run, script=None):
+    """(tools/fuzz_schedules.py runs its own generator through the same parent / child harness)"""
+    script = os.path.abspath(script or __file__)
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)
     ap.add_argument("--seed", type=int, default=0)
@@ -305,14 +307,14 @@ def main():
     ap.add_argument("--child", action="store_true")
     a = ap.parse_args()
     if a.child:
-        return child(a)
+        return child(a, make_scenario, run)
     # the scenarios run in a child process: a crash (the plugin's, or a GPU fault's abort) costs one scenario, not the run
     import subprocess
     t_end = time.time() + a.seconds
     tally, n, seed = {}, 0, (a.only if a.only is not None else a.seed)
     last = seed + (1 if a.only is not None else a.max)
     while seed < last and time.time() < t_end:
-        cmd = [sys.executable, "-X", "faulthandler", os.path.abspath(__file__), "--child", "--seed", str(seed), "--max", str(last - seed),
+        cmd = [sys.executable, "-X", "faulthandler", script, "--child", "--seed", str(seed), "--max", str(last - seed),
                "--seconds", str(max(1.0, t_end - time.time()))]
         p = subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
         started, desc, ended = None, "", False
