@@ -19,9 +19,10 @@ def test_fixed_slice_of_the_fuzzer_is_bitwise():
     bad = [l for l in lines if l.split(" ", 1)[0] in ("MISMATCH", "ERROR", "CRASH")]
     assert summary and not bad and r.returncode == 0, "\n".join(bad[:5] + summary + [r.stderr[-800:]])
     assert "160 scenarios" in summary[0], summary[0]
-    # the slice holds what once failed: a cloth and a tet blob through a group under the block partition (planned whole since: seeds 13, 76)
-    assert any(" seed=13," in l and l.startswith("OK") for l in lines) and any(" seed=76," in l and l.startswith("OK") for l in lines)
-
+    # the slice holds what once failed -- a cloth or a tet blob through a group under the block partition (planned whole since) -- and the odd meshes
+    ok = [l for l in lines if l.startswith("OK")]
+    assert any(("kind=tets" in l or "kind=cloth" in l) and "host=group" in l and "partition=blocks" in l for l in ok)
+    assert sum("kind=odd" in l for l in ok) >= 10
 
 @pytest.mark.gpu
 def test_fixed_slice_of_the_schedule_fuzzer_is_bitwise():
