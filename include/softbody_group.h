@@ -72,7 +72,10 @@ int sb_group_set_ground_plane(sb_group *g, float nx, float ny, float nz, float d
  * (sb_domain.fill = 1) -- and the partition is the block grid: sb_desc.partition = SB_PARTITION_BLOCKS, or SB_PARTITION_AUTO on at least
  * 2 M particles (for which AUTO takes the block grid anyway; below that, eight whole-mesh plans cost less than they save). Every other mesh
  * (tets, hinges, a body that fills its box unevenly: their colouring and leftover layers are not local to a window) is planned whole on
- * every rank, under whatever partition was asked for (SB_PARTITION_AUTO may then choose RCB). SB_GROUP_WHOLE_MESH forces that for any mesh. */
+ * every rank, under whatever partition was asked for (SB_PARTITION_AUTO may then choose RCB). SB_GROUP_WHOLE_MESH forces that for any mesh.
+ * The rule is a filter, not the guarantee: the ranks' plans are compared before anything is uploaded, and where windows did NOT reproduce the
+ * whole-mesh plan (e.g. particles on a line joined by nearest-neighbour springs pass the filter) every rank is handed the whole mesh and
+ * plans again -- sb_group_finalize succeeds either way, only slower. */
 int sb_group_finalize(sb_group *g);
 
 /* ---- the hot path (FixedUpdate) ---------------------------------------------------------------------------------------------------------- */

@@ -264,10 +264,25 @@ int sb_domain_window(const sb_domain *domain, const sb_plan_opts *opts, double l
 
 namespace sbi {
 
-// Phase A of sb_finalize: everything a rank does ALONE -- resolve the schedule, plan, build and upload the device tables. No
-// collective, no look at a neighbour. Throws / returns an error code like any guarded body; the caller decides what a failure
-// means for the other ranks (finalize_agree).
+// Phase A of sb_finalize: everything a rank does ALONE -- resolve the schedule and plan (finalize_plan: host work only), then build and
+// upload the device tables (finalize_device). No collective, no look at a neighbour. Throws / returns an error code like any guarded
+// body; the caller decides what a failure means for the other ranks (finalize_agree). The group host (group.hip) runs the two halves
+// apart: it compares the ranks' plans between them, and plans again from the whole mesh where windows did not reproduce it.
 int finalize_local(sb_solver *s) {
+    const int rc = finalize_plan(s);
+    return rc ? rc : finalize_device(s);
+}
+
+// A rank handed a window goes back to the state before authoring (the group host: the windows' plans did not fit together).
+void reset_authoring(sb_solver *s) {
+    s->sharded = false;
+    std::vector<int32_t>().swap(s->global_id);
+    s->domain = sb_domain{};
+    s->plan.reset();
+    s->plan_hash = 0;
+}
+
+int finalize_plan(sb_solver *s) {
     // SB_DEBUG_NO_COMM: the hosted-halo test hooks (sb_debug_*) drive world > 1 without any transport
     const bool no_comm = (s->desc.debug_flags & SB_DEBUG_NO_COMM) != 0;
     int rc = set_device(s); if (rc) return rc;
@@ -328,10 +343,16 @@ int finalize_local(sb_solver *s) {
     }
     s->schedule = sched;
     s->graph_rccl = sched == SB_SCHEDULE_SERIAL_GRAPH || sched == SB_SCHEDULE_OVERLAP_GRAPH;
+    if (timing) std::fprintf(stderr, "[finalize] plan %.1f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count());
+    return SB_OK;
+}
+
+int finalize_device(sb_solver *s) {
+    int rc = set_device(s); if (rc) return rc;
+    const auto t1 = std::chrono::steady_clock::now();
     build_device(s);
-    if (timing)
-        std::fprintf(stderr, "[finalize] plan %.1f ms, build_device + upload %.1f ms\n", std::chrono::duration<double, std::milli>(t1 - t0).count(),
-                     std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
+    if (std::getenv("SB_PLAN_TIMING") != nullptr)       // (printing only)
+        std::fprintf(stderr, "[finalize] build_device + upload %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count());
     // opt in to the LDS size the largest tile needs
     for (int tl = 0; tl < 3; ++tl)
         if (s->tiling[tl].lds_bytes > 64 * 1024) throw std::runtime_error("internal: tile LDS budget exceeded");

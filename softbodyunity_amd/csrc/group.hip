@@ -505,30 +505,46 @@ int sb_group_finalize(sb_group *g) {
                 if ((rc1 = g->for_ranks([&](int r) { return sb_comm_init(g->ranks[(size_t)r], ids[(size_t)(loopback ? r : 0)].data()); }))) return rc1;
             }
         }
-        // ---- plan + tables on every device, then agreement ----
-        if (!walk_mode(g)) {
-            // a thread per rank: exactly what separate processes do (the agreement all-gather of sb_finalize runs across the threads)
-            if ((rc1 = g->for_ranks([&](int r) { return sb_finalize(g->ranks[(size_t)r]); }))) return rc1;
-        } else {
-            // one thread: the ranks plan side by side on helper threads, the agreement records are compared right here
+        // ---- plan on every rank (host work, side by side), agreement, tables on every device ----
+        // All ranks live in this process: their plans are compared right here (the records sb_finalize all-gathers across processes).
+        // Windows that do not reproduce the whole-mesh plan -- the fill / constraint-type rule above lets through e.g. a cloud of particles on
+        // a line joined by nearest-neighbour springs -- are found by exactly that comparison: the ranks are then handed the whole mesh and plan again.
+        // (ranks' own threads where the group has them, else helper threads)
+        auto on_every_rank = [&](const std::function<int(int)> &f) -> int {
+            if (g->threads) return g->for_ranks(f);
             std::vector<int> lrc((size_t)W, 0);
             std::vector<std::string> lerr((size_t)W);
             {
                 std::vector<std::thread> th;
                 for (int r = 0; r < W; ++r) th.emplace_back([&, r] {
-                    lrc[(size_t)r] = guarded([&]() -> int { return finalize_local(g->ranks[(size_t)r]); });
+                    lrc[(size_t)r] = guarded([&]() -> int { return f(r); });
                     if (lrc[(size_t)r]) lerr[(size_t)r] = last_error_text();
                 });
                 for (auto &t : th) t.join();
             }
             for (int r = 0; r < W; ++r) if (lrc[(size_t)r]) return fail(lrc[(size_t)r], "rank " + std::to_string(r) + ": " + lerr[(size_t)r]);
+            return SB_OK;
+        };
+        auto plan_and_compare = [&]() -> int {
+            int rcp = on_every_rank([&](int r) { return guarded([&]() -> int { return finalize_plan(g->ranks[(size_t)r]); }); });
+            if (rcp) return rcp;
             if (W > 1 && !(g->desc.debug_flags & SB_DEBUG_LOOPBACK)) {
                 std::vector<uint64_t> all;
                 for (int r = 0; r < W; ++r) { const auto rec = agreement_record(g->ranks[(size_t)r], false); all.insert(all.end(), rec.begin(), rec.end()); }
-                if ((rc1 = check_agreement(all, W, -1))) return rc1;
+                return check_agreement(all, W, -1);
             }
-            for (int r = 0; r < W; ++r) if ((rc1 = finalize_link(g->ranks[(size_t)r]))) return fail(rc1, "rank " + std::to_string(r) + ": " + last_error_text());
+            return SB_OK;
+        };
+        rc1 = plan_and_compare();
+        if (rc1 == SB_ERR_STATE && g->sharded) {
+            g->sharded = false;
+            for (int r = 0; r < W; ++r) { reset_authoring(g->ranks[(size_t)r]); g->gid[(size_t)r].clear(); }
+            if ((rc1 = g->for_ranks([&](int r) { return guarded([&]() -> int { return author_rank(g, r, nullptr); }); }))) return rc1;
+            rc1 = plan_and_compare();
         }
+        if (rc1) return rc1;
+        if ((rc1 = on_every_rank([&](int r) { return guarded([&]() -> int { return finalize_device(g->ranks[(size_t)r]); }); }))) return rc1;
+        if ((rc1 = on_every_rank([&](int r) { return finalize_link(g->ranks[(size_t)r]); }))) return rc1;
         // ---- peer transport inside one process: the mailboxes by plain pointer ----
         if (peer && !(g->desc.debug_flags & SB_DEBUG_LOOPBACK)) {
             for (int a = 0; a < W; ++a)

@@ -418,7 +418,10 @@ void launch_normals(hipStream_t st, const float *snap_xyz, const int32_t *adj_of
                     const int32_t *subset, float *subset_pos_xyz);
 
 // ---- abi.hip: the phases of sb_finalize (a group runs them itself) ----------------------------------------------------------------------
-int finalize_local(sb_solver *s);                       // plan + tables, this rank alone
+int finalize_local(sb_solver *s);                       // plan + tables, this rank alone (= finalize_plan, then finalize_device)
+int finalize_plan(sb_solver *s);                        //   host work only: schedule, plan, plan hash
+int finalize_device(sb_solver *s);                      //   device tables, streams
+void reset_authoring(sb_solver *s);                     // forget a window (sb_set_domain) and the plan made from it
 std::vector<uint64_t> agreement_record(const sb_solver *s, bool failed);
 int check_agreement(const std::vector<uint64_t> &all, int W, int me);
 int finalize_agree(sb_solver *s, int local_rc);         // RCCL all-gather of the agreement records (entered by a failed rank too)

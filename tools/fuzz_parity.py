@@ -136,6 +136,7 @@ def make_scenario(seed):
         if sc["tile"] == -1:
             sc["tile"] = 0
     # host actions per tick, in this order around the tick's step:
+    #   x = ONE INVALID CALL (bad_call: must be refused with an error code and leave every later result untouched),
     #   s = set_state (fresh positions and velocities), g = ground plane moved / switched, k = kinematic move, r = blocking read,
     #   [the step, with this tick's own dt and substeps where the scenario varies them], b = pipelined render readback (n: with normals)
     # hosted ranks (the host is the wire, launch by launch) take s and the per-tick dt / substeps only
@@ -159,11 +160,14 @@ def make_scenario(seed):
                 a += "r"
             if rng.random() < 0.3:
                 a += "n" if sc["render"] != "none" else "b"
+            if rng.random() < 0.2:
+                a += "x"
         acts.append(a)
         per_tick.append((float(rng.choice([0.02, 0.01, 0.005])), int(rng.choice([1, 2, 3, 5, 7]))) if vary else (sc["dt"], sc["substeps"]))
     sc["actions"] = acts
     sc["per_tick"] = per_tick if vary else "fixed"
     sc["_per_tick"] = per_tick
+    sc["_bad"] = [int(rng.integers(0, 1 << 30)) for _ in acts]
     sc["_move"] = rng.uniform(-0.2, 0.2, (sc["ticks"], 3)).astype(np.float32)
     sc["_state"] = [(mesh.pos + rng.uniform(-0.03, 0.03, mesh.pos.shape).astype(np.float32), rng.uniform(-0.5, 0.5, mesh.pos.shape).astype(np.float32))
                     if "s" in a else None for a in acts]
@@ -237,6 +241,9 @@ def run(sc):
         if not same(got, want):
             why.append(label)
 
+    for label, got in [c for c in checks if c[1] is None]:
+        why.append(label)
+    checks[:] = [c for c in checks if c[1] is not None]
     for t in range(sc["ticks"]):
         acts = sc["actions"][t]
         if "s" in acts:
@@ -268,6 +275,47 @@ def run(sc):
     return ("MISMATCH", "; ".join(why)) if why else ("OK", "the oracle overflowed: non-finite in the same places, bitwise elsewhere" if overflow else "")
 
 
+def bad_call(sc, sb, group, which):
+    """One call a host must not make, chosen by `which`; -> None when the plugin refused it with an error code, else what went wrong."""
+    L, mesh, n = native.lib(), sc["_mesh"], sc["_mesh"].n
+    h = sb._g if group else sb._h
+    f = (lambda name: getattr(L, ("sb_group_" if group else "sb_") + name))
+    buf = np.zeros((n + 1, 3), np.float32)
+    free = np.nonzero(mesh.inv_mass != 0)[0].astype(np.int32)
+    pins = sc["_pins"]
+    one = np.zeros((1, 3), np.float32)
+    nan3 = np.full((1, 3), np.nan, np.float32)
+    p = native.ptr
+    calls = [
+        ("step with dt = 0", lambda: f("step")(h, 0.0, 3)),
+        ("step with dt = NaN", lambda: f("step")(h, float("nan"), 3)),
+        ("step with 0 substeps", lambda: f("step")(h, 0.02, 0)),
+        ("step with -1 substeps", lambda: f("step")(h, 0.02, -1)),
+        ("get_positions with n + 1", lambda: f("get_positions")(h, p(buf), n + 1)),
+        ("get_positions into NULL", lambda: f("get_positions")(h, None, n)),
+        ("get_velocities with n - 1", lambda: f("get_velocities")(h, p(buf), n - 1)),
+        ("set_state with n + 1", lambda: f("set_state")(h, p(buf), p(buf), n + 1)),
+        ("set_state with NULL velocities", lambda: f("set_state")(h, p(buf), None, n)),
+        ("set_particles after finalize", lambda: f("set_particles")(h, p(buf), p(buf), p(np.ones(n, np.float32)), n)),
+        ("readback_end without a begin", lambda: f("readback_end")(h, C.byref(C.POINTER(C.c_float)()))),
+        ("render triangles out of range", lambda: f("set_render_triangles")(h, np.array([0, 1, n], np.int32).ctypes.data_as(C.POINTER(C.c_int32)), 1)),
+        ("kinematic target: id out of range", lambda: f("set_kinematic_positions")(h, p(np.array([n], np.int32)), p(one), 1)),
+        ("kinematic target: negative count", lambda: f("set_kinematic_positions")(h, p(np.array([0], np.int32)), p(one), -1)),
+    ]
+    if len(free):
+        calls.append(("kinematic target on a free particle", lambda: f("set_kinematic_positions")(h, p(free[:1].copy()), p(one), 1)))
+    if len(pins):
+        calls.append(("kinematic target NaN", lambda: f("set_kinematic_positions")(h, p(pins[:1].copy()), p(nan3), 1)))
+        calls.append(("kinematic target: an id twice", lambda: f("set_kinematic_positions")(h, p(np.array([pins[0], pins[0]], np.int32)), p(np.zeros((2, 3), np.float32)), 2)))
+    if not group:
+        tune = native.SbTuning(); L.sb_tuning_default(C.byref(tune))
+        calls.append(("set_tuning after finalize", lambda: L.sb_set_tuning(h, C.byref(tune))))
+        calls.append(("finalize twice", lambda: L.sb_finalize(h)))
+    name, fn = calls[which % len(calls)]
+    rc = fn()
+    return None if rc < 0 else f"invalid call accepted (rc {rc}): {name}"
+
+
 def drive(sc, sb, checks, group):
     mesh = sc["_mesh"]
     L = native.lib()
@@ -277,6 +325,10 @@ def drive(sc, sb, checks, group):
             sb.set_readback_render_set_only(True)
     for t in range(sc["ticks"]):
         acts = sc["actions"][t]
+        if "x" in acts:
+            bad = bad_call(sc, sb, group, sc["_bad"][t])
+            if bad:
+                checks.append((bad, None))
         if "s" in acts:
             sb.set_state(*sc["_state"][t])
         if "g" in acts:
