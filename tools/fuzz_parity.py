@@ -83,7 +83,7 @@ def make_scenario(seed):
         sc["mesh"] = f"odd: {o['shape']} n={o['n']} springs={o['springs']} tets={o['tets']} hinges={o['hinges']}"
         comp = (float(rng.choice([0.0, 1e-6])), float(rng.choice([0.0, 1e-6])), float(rng.choice([0.0, 1e-4])))
     elif kind == "cube":
-        n = int(rng.integers(3, 34))
+        n = int(rng.integers(3, 34)) if rng.random() < 0.9 else int(rng.integers(40, 73))      # (the larger ones reach the 8-byte wide-packed slots: > 768 tiles)
         het, pin = bool(rng.random() < 0.3), bool(rng.random() < 0.5)
         full = bool(n <= 12 and rng.random() < 0.25)       # 26-neighbour stencil: many colours, global colours, leftover layers
         mesh = jelly_cube(n, pin_top=pin, heterogeneous=het, seed=int(rng.integers(1, 10 ** 6)), stencil="full" if full else "structural")
