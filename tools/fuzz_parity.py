@@ -86,7 +86,9 @@ def make_scenario(seed):
         n = int(rng.integers(3, 34)) if rng.random() < 0.9 else int(rng.integers(40, 73))      # (the larger ones reach the 8-byte wide-packed slots: > 768 tiles)
         het, pin = bool(rng.random() < 0.3), bool(rng.random() < 0.5)
         full = bool(n <= 12 and rng.random() < 0.25)       # 26-neighbour stencil: many colours, global colours, leftover layers
-        mesh = jelly_cube(n, pin_top=pin, heterogeneous=het, seed=int(rng.integers(1, 10 ** 6)), stencil="full" if full else "structural")
+        cube_seed = int(rng.integers(1, 10 ** 6))
+        mesh = jelly_cube(n, pin_top=pin, heterogeneous=het, seed=cube_seed, stencil="full" if full else "structural")
+        sc["_cube"] = (n, het, pin, cube_seed)
         sc["mesh"] = f"cube {n}^3 het={int(het)} pin_top={int(pin)} stencil={'full' if full else 'structural'}"
         sc["_tri"] = surface_triangles(n)
         comp = (float(rng.choice([0.0, 0.0, 1e-7, 1e-5])), 0.0, 0.0)
