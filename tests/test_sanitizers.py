@@ -37,3 +37,27 @@ def test_oracle_under_asan_ubsan(tmp_path):
     env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1", OMP_NUM_THREADS="2")
     out = subprocess.run([exe], capture_output=True, text=True, env=env, timeout=600)
     assert out.returncode == 0 and "SANITIZE OK" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
+
+
+def test_planner_on_the_fuzz_corpus_under_asan_ubsan(tmp_path):
+    """The degenerate meshes of tools/fuzz_plan.py (a point, a line, no constraints, complete graphs, NaN ...) through plan.cpp under ASan + UBSan."""
+    import sys
+    import numpy as np
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import fuzz_plan
+    corpus = tmp_path / "corpus.bin"
+    with open(corpus, "wb") as f:
+        for seed in range(250):
+            sc = fuzz_plan.make_scenario(seed)
+            m = sc["_mesh"]
+            np.array([m.n, len(m.dist_rest), len(m.vol_rest), len(m.bend_rest), sc["world"], sc["tile"], sc["partition"]], np.int32).tofile(f)
+            np.ascontiguousarray(m.rest_pos, np.float32).tofile(f)
+            for a in (m.dist_ij, m.vol_ijkl, m.bend_ijkl):
+                np.ascontiguousarray(a, np.int32).tofile(f)
+    exe = str(tmp_path / "plan_corpus_san")
+    csrc = os.path.join(ROOT, "softbodyunity_amd", "csrc")
+    subprocess.check_call(["g++", "-std=c++17", "-Wall", "-pthread", *SAN, "-I", csrc, os.path.join(ROOT, "tests", "sanitize", "plan_corpus_san.cpp"),
+                           os.path.join(csrc, "plan.cpp"), "-o", exe])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1", SB_PLAN_THREADS="4")
+    out = subprocess.run([exe, str(corpus)], capture_output=True, text=True, env=env, timeout=900)
+    assert out.returncode == 0 and "SANITIZE OK entries 250" in out.stdout, out.stdout[-2000:] + out.stderr[-4000:]
