@@ -192,6 +192,7 @@ def parse_args():
                     help="halo schedule of the DEFAULT variant for N > 1 (sb_desc.halo_schedule); auto = serial-eager")
     ap.add_argument("--no-ab", action="store_true", help="N > 1: time the default (transport, schedule) only, not every admitted pair (config.schedule_ab)")
     ap.add_argument("--ab-steps", type=int, default=0, help="N > 1: timed ticks of the A/B variants (0 = --steps)")
+    ap.add_argument("--debug-golden-mismatch-variant", default="", help=argparse.SUPPRESS)
     ap.add_argument("--variant-timeout", type=float, default=150.0, help="N > 1: seconds one variant may take before the watchdog writes the line as it stands and ends the run")
     ap.add_argument("--rccl-stand-in", choices=["peer"], default=None,
                     help="TEST AID for one-GPU boxes, never a measurement: the variants NAMED rccl/* run over the peer-store transport (RCCL refuses two "
@@ -517,6 +518,8 @@ def run_variant(ctx, name, transport, schedule, steps, warmup, is_default):
                     "tick_ms_hip_events_rank0": ev_ms / steps})
         if not args.no_parity:
             g, finite = golden_leg(ctx, sb, calib + warmup + steps)
+            if args.debug_golden_mismatch_variant == name and g["bitwise"] is True:       # (test hook: what a variant with wrong bits looks like to the run)
+                g = dict(g, checksum="0x" + "0" * 16, bitwise=False)
             rec["golden"] = {"checksum": g["checksum"], "expected": g["expected"], "bitwise": g["bitwise"]}
             rec["finite"] = finite
         else:
@@ -613,12 +616,18 @@ def multi_rank(ctx, real_stdout):
     if words:
         words.arm(4 * args.variant_timeout, "the default variant (set-up included)")
     rec, out, ok = full_variant(ctx, default_name, args.transport, args.schedule, not args.no_sustained, runtime)
+    # A default whose state does not end on the golden checksum is a FAILED variant, whatever it timed: with a verified serialised eager line
+    # in hand that line stands (every rank sees the same gathered checksum, so all take the same branch).
+    if ok and (rec.get("golden") or {}).get("bitwise") is False and safe_rec is not None and (safe_rec.get("golden") or {}).get("bitwise") is True:
+        rec["error"] = f"the run did not end on the golden checksum ({rec['golden']['checksum']} against {rec['golden']['expected']}): not used for `value`"
+        ok = False
     if not ok:
         if safe_rec is None or "value" not in safe_rec:
             raise SystemExit(f"bench.py: the default variant {default_name} failed: {rec.get('error')}")
         out = safe_out      # (rank 0) the serialised eager variant's line stands, the default's failure is recorded beside it
         if rank == 0:
             out["config"]["schedule_ab"]["variants"].append(rec)
+            out["config"]["schedule_ab"]["value_from"] = f"rccl/serial-eager: the default variant ({default_name}) FAILED, see its record in `variants`"
     else:
         measured[default_name] = rec
         if rank == 0:

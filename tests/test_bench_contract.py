@@ -155,6 +155,27 @@ def test_bench_multi_rank_default_rccl_auto_control_flow_with_a_stand_in_transpo
 
 
 @pytest.mark.gpu
+def test_bench_default_that_misses_the_golden_checksum_gives_way_to_the_verified_serialised_line():
+    # The default rccl/auto runs ticks of the overlapped schedule while it calibrates -- a schedule that has never run between two devices. Should
+    # its state NOT end on the golden checksum there, its figure must not become `value`: the serialised eager variant measured first (and
+    # verified) stands, the default is recorded as failed. (--debug-golden-mismatch-variant plants the mismatch.)
+    env = dict(os.environ, GPU_MAX_HW_QUEUES="8")
+    port = 29810 + os.getpid() % 40
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                          "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--cube-edge", "64", "--steps", "4", "--warmup", "2",
+                          "--no-sustained", "--no-ab", "--rccl-stand-in", "peer", "--debug-golden-mismatch-variant", "rccl/auto"],
+                         capture_output=True, text=True, timeout=1200, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, out.stdout[-2000:]
+    j = json.loads(lines[0])
+    ab = j["config"]["schedule_ab"]
+    v = {x["name"]: x for x in ab["variants"]}
+    assert "FAILED" in ab["value_from"] and "golden checksum" in v["rccl/auto"]["error"]
+    assert abs(v["rccl/serial-eager"]["value"] - j["value"]) / j["value"] < 1e-9 and j["config"]["parity"]["golden"]["bitwise"] is True
+
+
+@pytest.mark.gpu
 def test_bench_line_survives_a_variant_that_hangs():
     # A later A/B variant that never returns (a collective one rank never joins, a kernel that never finishes) must not cost the run its line:
     # rank 0's watchdog writes the line as it stands -- the default's figure, the variants measured so far -- and ends the run with a non-zero
