@@ -48,7 +48,8 @@ def scenario(seed, world):
     if sc["tile"] == -1:
         sc["tile"] = 0
     sc["render"] = "none"
-    sc["actions"] = [a.replace("b", "").replace("n", "") for a in sc["actions"]]
+    sc["actions"] = [a.replace("b", "").replace("n", "").replace("p", "") for a in sc["actions"]]
+    sc["pipelined"] = False
     m = sc["mesh"]
     sc["window"] = bool(sc["kind"] == "cube" and "stencil=structural" in m and sc["tile"] > 0 and sc["partition"] != "rcb" and rng.random() < 0.5)
     for k in ("walk", "whole_mesh"):

@@ -166,6 +166,11 @@ def make_scenario(seed):
                 a += "x"
         acts.append(a)
         per_tick.append((float(rng.choice([0.02, 0.01, 0.005])), int(rng.choice([1, 2, 3, 5, 7]))) if vary else (sc["dt"], sc["substeps"]))
+    # pipelined readbacks: begin after a tick, end one or two ticks LATER (at most two pending, oldest first) -- the snapshot must be the
+    # state at ITS begin whatever the host did since (set_state, moves, ticks)
+    sc["pipelined"] = bool(host != "hosted" and sc["render"] == "none" and rng.random() < 0.4)
+    if sc["pipelined"]:
+        acts = [a.replace("b", "p") for a in acts]
     sc["actions"] = acts
     sc["per_tick"] = per_tick if vary else "fixed"
     sc["_per_tick"] = per_tick
@@ -235,6 +240,7 @@ def run(sc):
     ref_plan = build_plan(mesh, tile_particles=sc["tile"])
     o = make_oracle(oracle, mesh, ref_plan, damping=sc["damping"], compliance=comp, ground_plane=sc["plane"])
     k = 0
+    opend = []
     tri = sc.get("_tri")
 
     def compare(want):
@@ -258,12 +264,18 @@ def run(sc):
         if "r" in acts:
             compare(o.x.copy())
         o.step(*sc["_per_tick"][t])
+        if "p" in acts:
+            if len(opend) == 2:
+                compare(opend.pop(0))
+            opend.append(o.x.copy())
         if "b" in acts or "n" in acts:
             rs = np.unique(tri) if (sc["render"] == "render-set-only") else None
             compare(o.x.copy() if rs is None else o.x[rs].copy())
             if "n" in acts:
                 nrm = oracle.vertex_normals(o.x, tri)
                 compare(nrm if rs is None else nrm[rs])
+    while opend:
+        compare(opend.pop(0))
     x, v = checks_state
     if not same(x, o.x):
         why.append(f"final positions ({int((bits(x) != bits(o.x)).any(axis=1).sum())} of {mesh.n} particles differ)")
@@ -299,7 +311,9 @@ def bad_call(sc, sb, group, which):
         ("set_state with n + 1", lambda: f("set_state")(h, p(buf), p(buf), n + 1)),
         ("set_state with NULL velocities", lambda: f("set_state")(h, p(buf), None, n)),
         ("set_particles after finalize", lambda: f("set_particles")(h, p(buf), p(buf), p(np.ones(n, np.float32)), n)),
+    ] + ([] if sc.get("pipelined") else [       # (with pipelined readbacks one may be pending: the call would be valid)
         ("readback_end without a begin", lambda: f("readback_end")(h, C.byref(C.POINTER(C.c_float)()))),
+    ]) + [
         ("render triangles out of range", lambda: f("set_render_triangles")(h, np.array([0, 1, n], np.int32).ctypes.data_as(C.POINTER(C.c_int32)), 1)),
         ("kinematic target: id out of range", lambda: f("set_kinematic_positions")(h, p(np.array([n], np.int32)), p(one), 1)),
         ("kinematic target: negative count", lambda: f("set_kinematic_positions")(h, p(np.array([0], np.int32)), p(one), -1)),
@@ -325,6 +339,7 @@ def drive(sc, sb, checks, group):
         sb.set_render_triangles(sc["_tri"])
         if sc["render"] == "render-set-only":
             sb.set_readback_render_set_only(True)
+    pend = []
     for t in range(sc["ticks"]):
         acts = sc["actions"][t]
         if "x" in acts:
@@ -341,6 +356,10 @@ def drive(sc, sb, checks, group):
         if "r" in acts:
             checks.append((f"read before tick {t}", sb.get_positions().copy()))
         sb.step(*sc["_per_tick"][t])
+        if "p" in acts:
+            if len(pend) == 2:
+                checks.append((f"pipelined readback begun after tick {pend.pop(0)}", np.array(sb.readback_end(), copy=True)))
+            sb.readback_begin(); pend.append(t)
         if "b" in acts or "n" in acts:
             sb.readback_begin()
             if "n" in acts:
@@ -349,6 +368,8 @@ def drive(sc, sb, checks, group):
                 checks.append((f"render normals after tick {t}", np.array(nrm, copy=True)))
             else:
                 checks.append((f"render readback after tick {t}", np.array(sb.readback_end(), copy=True)))
+    while pend:
+        checks.append((f"pipelined readback begun after tick {pend.pop(0)}", np.array(sb.readback_end(), copy=True)))
     x, v = sb.get_positions().copy(), sb.get_velocities().copy()
     if group:
         val = [sb.rank(r).validate() for r in range(sc["world"])]
