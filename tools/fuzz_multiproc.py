@@ -66,7 +66,7 @@ def run_rank(sc, rank, world):
         mesh = jelly_cube_window(n, rank, world, (0, 0, 0), sc["tile"], pin_top=pin, heterogeneous=het, seed=cube_seed)
         gid = mesh.global_id.astype(np.int64)
     sb = Softbody(mesh, substeps=sc["substeps"], fixed_delta_time=sc["dt"], tile_particles=sc["tile"], damping=sc["damping"], distance_compliance=comp[0],
-                  volume_compliance=comp[1], bending_compliance=comp[2], ground_plane=sc["plane"], use_graph=sc["graph"], tuning=fz.make_tuning(sc["tuning"]),
+                  volume_compliance=comp[1], bending_compliance=comp[2], ground_plane=sc["plane"], use_graph=sc["graph"], tuning=fz.make_tuning(sc["tuning"]), gravity=sc["gravity"],
                   device=0, rank=rank, world=world, partition=native.SB_PARTITION_BLOCKS if sc["window"] else fz.PART[sc["partition"]],
                   halo_transport=native.SB_TRANSPORT_PEER,
                   halo_schedule=native.SB_SCHEDULE_SERIAL_GRAPH if sc["schedule"] == "serial-graph" else native.SB_SCHEDULE_SERIAL_EAGER)
@@ -141,7 +141,7 @@ def check(sc, parts):
             why.append(f"table validator {p['val']}")
     if not np.all(cover == 1):
         return ["the ranks' owned sets do not partition the particles"]
-    o = make_oracle(oracle, mesh, build_plan(mesh, tile_particles=sc["tile"]), damping=sc["damping"], compliance=sc["compliance"], ground_plane=sc["plane"])
+    o = make_oracle(oracle, mesh, build_plan(mesh, tile_particles=sc["tile"]), gravity=sc["gravity"], damping=sc["damping"], compliance=sc["compliance"], ground_plane=sc["plane"])
     k = 0
     for t in range(sc["ticks"]):
         acts = sc["actions"][t]

@@ -111,8 +111,9 @@ def make_scenario(seed):
     sc["compliance"] = comp
     sc["substeps"] = int(rng.choice([1, 2, 3, 4, 5, 6, 8]))
     sc["ticks"] = int(rng.integers(1, 5))
-    sc["dt"] = float(rng.choice([0.02, 0.01]))
-    sc["tile"] = int(rng.choice([0, 0, 64, 128, 256, 512, -1]))
+    sc["dt"] = float(rng.choice([0.02, 0.01])) if rng.random() < 0.9 else float(rng.choice([0.1, 0.001, 1.0 / 60.0]))
+    sc["tile"] = int(rng.choice([0, 0, 64, 128, 256, 512, -1])) if rng.random() < 0.85 else int(rng.choice([16, 48, 100, 300, 700, 1000]))
+    sc["gravity"] = (0.0, -9.81, 0.0) if rng.random() < 0.7 else tuple(float(c) for c in rng.choice([(0.0, 0.0, 0.0), (3.0, -4.0, 1.5), (0.0, 9.81, 0.0), (0.0, -100.0, 0.0)]))
     sc["damping"] = float(rng.choice([0.0, 0.0, 0.02, 0.5]))
     ymin = float(mesh.pos[:, 1].min())
     sc["plane"] = (0.0, 1.0, 0.0, ymin - float(rng.choice([0.0, 0.05, 0.5]))) if rng.random() < 0.4 else None
@@ -203,7 +204,7 @@ def run(sc):
     """-> (verdict, detail): verdict in OK / MISMATCH / REFUSED (the plugin declined the combination with a message) / ERROR"""
     mesh, S, dt, comp = sc["_mesh"], sc["substeps"], sc["dt"], sc["compliance"]
     kw = dict(substeps=S, fixed_delta_time=dt, tile_particles=sc["tile"], damping=sc["damping"], distance_compliance=comp[0], volume_compliance=comp[1],
-              bending_compliance=comp[2], ground_plane=sc["plane"], use_graph=sc["graph"], tuning=make_tuning(sc["tuning"]))
+              bending_compliance=comp[2], ground_plane=sc["plane"], use_graph=sc["graph"], tuning=make_tuning(sc["tuning"]), gravity=sc["gravity"])
     checks = []       # (label, got, want) compared bitwise at the end
     why = []
 
@@ -238,7 +239,7 @@ def run(sc):
     # (a plan of its own from the host-only planner, same mesh and tile size: the published order does not depend on the partition, the
     # host model or any tuning switch -- which is part of what is being tested)
     ref_plan = build_plan(mesh, tile_particles=sc["tile"])
-    o = make_oracle(oracle, mesh, ref_plan, damping=sc["damping"], compliance=comp, ground_plane=sc["plane"])
+    o = make_oracle(oracle, mesh, ref_plan, gravity=sc["gravity"], damping=sc["damping"], compliance=comp, ground_plane=sc["plane"])
     k = 0
     opend = []
     tri = sc.get("_tri")
