@@ -95,6 +95,8 @@ def run_rank(sc, rank, world):
         own = sb.owner() == rank
         whole = sc["_mesh"]
         pins_local = np.nonzero((mesh.inv_mass == 0) & own)[0].astype(np.int32)
+        # (a host need not sort the pins by owner: a rank skips the ids it does not own -- half of the scenarios hand EVERY pin the rank can see)
+        pins_given = np.nonzero(mesh.inv_mass == 0)[0].astype(np.int32) if sc["seed"] % 2 else pins_local
         reads, bad = [], []
         for t in range(sc["ticks"]):
             acts = sc["actions"][t]
@@ -107,8 +109,8 @@ def run_rank(sc, rank, world):
             if "g" in acts:
                 pl = sc["_planes"][t]
                 native.check(L.sb_set_ground_plane(sb._h, *[float(c) for c in pl[:4]], int(pl[4])))
-            if "k" in acts and len(pins_local):
-                sb.set_kinematic_positions(pins_local, whole.pos[gid[pins_local]] + sc["_move"][t])
+            if "k" in acts and len(pins_given):
+                sb.set_kinematic_positions(pins_given, whole.pos[gid[pins_given]] + sc["_move"][t])
             if "r" in acts:
                 reads.append(sb.get_positions()[own].copy())
             sb.step(*sc["_per_tick"][t])
