@@ -48,7 +48,7 @@ def scenario(seed, world):
     if sc["tile"] == -1:
         sc["tile"] = 0
     sc["render"] = "none"
-    sc["actions"] = [a.replace("b", "").replace("n", "").replace("p", "") for a in sc["actions"]]
+    sc["actions"] = [a.replace("n", "b").replace("p", "b") for a in sc["actions"]]      # (a rank's render readback: the particles it owns, no triangles here)
     sc["pipelined"] = False
     m = sc["mesh"]
     sc["window"] = bool(sc["kind"] == "cube" and "stencil=structural" in m and sc["tile"] > 0 and sc["partition"] != "rcb" and rng.random() < 0.5)
@@ -114,6 +114,9 @@ def run_rank(sc, rank, world):
             if "r" in acts:
                 reads.append(sb.get_positions()[own].copy())
             sb.step(*sc["_per_tick"][t])
+            if "b" in acts:
+                sb.readback_begin()
+                reads.append(np.array(sb.readback_end(), copy=True)[own])
         x, v = sb.get_positions()[own].copy(), sb.get_velocities()[own].copy()
         result = dict(reads=reads, x=x, v=v, ids=gid[own], val=sb.validate()["errors"], bad=bad,
                       ghosts=sb.stats()["n_particles_local"] - sb.stats()["n_particles_owned"], peeks=sb.stats()["readback_peeks"])
@@ -160,6 +163,11 @@ def check(sc, parts):
                     why.append(f"rank {r}: read before tick {t}")
             k += 1
         o.step(*sc["_per_tick"][t])
+        if "b" in acts:
+            for r, p in enumerate(parts):
+                if not fz.same(p["reads"][k], o.x[p["ids"]]):
+                    why.append(f"rank {r}: render readback after tick {t}")
+            k += 1
     for r, p in enumerate(parts):
         if not fz.same(p["x"], o.x[p["ids"]]):
             why.append(f"rank {r}: final positions")
