@@ -132,7 +132,7 @@ def make_scenario(seed):
     host = str(rng.choice(["single", "single", "hosted", "group"]))
     sc["host"] = host
     if host != "single":
-        sc["world"] = int(rng.choice([2, 3, 4, 8] if host == "hosted" else [2, 3, 4]))
+        sc["world"] = int(rng.choice([2, 3, 4, 8, 2, 3, 4, 8, 5, 6, 7, 12, 16] if host == "hosted" else [2, 3, 4, 2, 3, 4, 5, 6, 8]))      # (more ranks than cells happens: empty ranks)
         sc["partition"] = str(rng.choice(["auto", "blocks", "rcb"]))
         sc["walk"] = bool(rng.random() < 0.5)
         sc["whole_mesh"] = bool(rng.random() < 0.3)
