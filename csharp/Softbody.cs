@@ -47,6 +47,8 @@ namespace SoftbodyMI355X
         [SerializeField] int haloTransport = SoftbodyNative.TransportRccl;
         [Tooltip("Hand every GPU only its block of a lattice-like mesh (block partition) instead of letting every GPU plan the whole mesh.")]
         [SerializeField] bool blockPartition = false;
+        [Tooltip("Never cut windows: every GPU is handed and plans the whole mesh, whatever the partition (the plugin decides by itself otherwise and verifies its choice).")]
+        [SerializeField] bool wholeMeshOnEveryGpu = false;
         [Tooltip("Target particles per LDS tile; 0 = automatic (512, or 256 when the mesh has volume or bending constraints).")]
         [SerializeField] int tileParticles = 0;
         [Tooltip("Render from the previous tick's snapshot: the D2H copy and the normals (computed on the GPU) overlap the next tick.")]
@@ -118,7 +120,7 @@ namespace SoftbodyMI355X
             d.partition = blockPartition ? SoftbodyNative.PartitionBlocks : SoftbodyNative.PartitionAuto;
             var devices = new int[Math.Max(deviceCount, 1)];
             for (int r = 0; r < devices.Length; ++r) devices[r] = device + r;
-            SoftbodyNative.Check(SoftbodyNative.sb_group_create(ref d, devices, devices.Length, 0, out handle), "sb_group_create");
+            SoftbodyNative.Check(SoftbodyNative.sb_group_create(ref d, devices, devices.Length, wholeMeshOnEveryGpu ? SoftbodyNative.GroupWholeMesh : 0u, out handle), "sb_group_create");
 
             // Vector3 is a blittable sequential struct of 3 floats: Vector3[] pins directly to float xyz
             Pin(positions, p => Pin(velocities, v => Pin(inverseMass, w =>
