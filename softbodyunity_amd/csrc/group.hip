@@ -475,7 +475,7 @@ int sb_group_finalize(sb_group *g) {
         sb_domain dom{};
         // Windows (sharded authoring) where they are known to reproduce the whole-mesh plan: a lattice-like body (distance constraints only,
         // filling its bounding box -- colours, tiles and leftovers of such a mesh are local to a window; a tet mesh's or a cloth's are not:
-        // tools/fuzz_parity.py found every such mesh refused by the ranks' agreement check) under the block partition -- asked for
+        // tests/fuzz/fuzz_parity.py found every such mesh refused by the ranks' agreement check) under the block partition -- asked for
         // (SB_PARTITION_BLOCKS), or SB_PARTITION_AUTO on a LARGE mesh (the block grid is what AUTO takes for it anyway, and eight whole-mesh
         // plans of 16.8 M particles are 26 GB of host memory and 8 x 4.9 s of planning against 8 x 0.6 s on windows).
         constexpr int32_t kAutoShardParticles = 1 << 21;

@@ -10,7 +10,7 @@ switches, the halo schedule (serialised eager / captured), and between ticks: se
 blocking reads (a rank peeks or flushes by its own tile count), one invalid call.
 
 usage (GPU box): GPU_MAX_HW_QUEUES=16 python -m torch.distributed.run --nnodes=1 --nproc-per-node W --master-addr 127.0.0.1 --master-port P \\
-                 tools/fuzz_multiproc.py [--seconds 200] [--seed 0] [--max N]"""
+                 tests/fuzz/fuzz_multiproc.py [--seconds 200] [--seed 0] [--max N]"""
 import argparse
 import ctypes as C
 import os
@@ -18,8 +18,8 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
 
 import numpy as np                                                      # noqa: E402
 import torch                                                            # noqa: E402

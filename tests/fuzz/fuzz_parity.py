@@ -12,7 +12,7 @@ What varies per scenario (all from one seed, printed, so a failure replays with 
   actions   between ticks: set_state, the ground plane moved or switched, kinematic moves of pinned particles, a blocking position read (the
             peek / the flush), a tick with its own dt and substeps, a pipelined render readback (whole array, with GPU normals, render set
             only) -- each mirrored on the oracle
-Every scenario also runs the table validator. usage: python tools/fuzz_parity.py [--seconds 240] [--seed 0] [--only SEED] [--max N]"""
+Every scenario also runs the table validator. usage: python tests/fuzz/fuzz_parity.py [--seconds 240] [--seed 0] [--only SEED] [--max N]"""
 import argparse
 import ctypes as C
 import os
@@ -21,8 +21,8 @@ import time
 import traceback
 
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")        # (several ranks of one process on one device: a hardware queue each, before the first HIP call)
-ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools"))
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
 
 import numpy as np                                                      # noqa: E402
 
@@ -34,7 +34,7 @@ from softbodyunity_amd.mesh import bunny_surrogate, from_triangle_mesh, jelly_cu
 from readback_bench import surface_triangles                            # noqa: E402
 
 # switches that change kernel selection or table layout, never results (AUTO_* / PEER_COARSE concern transports that do not run here)
-ODD = os.environ.get("FUZZ_ODD", "1") != "0"     # include the degenerate meshes of tools/fuzz_plan.py
+ODD = os.environ.get("FUZZ_ODD", "1") != "0"     # include the degenerate meshes of tests/fuzz/fuzz_plan.py
 FLAGS = ["NO_MASS_PALETTE", "NO_UNIFORM_MASS", "NO_PALETTE", "NO_WAVE_ITEMS", "NO_LANE_PACK", "NO_COST_ORDER", "NO_FUSED_UNPACK", "NO_LAZY_TICK",
          "NO_PACK", "NO_PEEK", "NO_KIN_FUSE", "NO_WIDE_SLOTS"]
 
@@ -70,7 +70,7 @@ def make_scenario(seed):
     sc = {"seed": seed}
     kind = rng.choice(["cube", "cube", "tets", "cloth"] + (["odd"] if ODD else []))
     sc["kind"] = str(kind)
-    if kind == "odd":       # meshes nobody would author on purpose (tools/fuzz_plan.py: a point, a line, a plane, a chain, a complete graph, a hub,
+    if kind == "odd":       # meshes nobody would author on purpose (tests/fuzz/fuzz_plan.py: a point, a line, a plane, a chain, a complete graph, a hub,
         import fuzz_plan    # isolated particles, no constraints, one or two particles, duplicate constraints, extreme scales)
         while True:
             o = fuzz_plan.make_scenario(int(rng.integers(0, 2 ** 31)))
@@ -402,7 +402,7 @@ def child(a, make_scenario, run):
 
 
 def main(make_scenario=make_scenario, run=run, script=None):
-    """(tools/fuzz_schedules.py runs its own generator through the same parent / child harness)"""
+    """(tests/fuzz/fuzz_schedules.py runs its own generator through the same parent / child harness)"""
     script = os.path.abspath(script or __file__)
     ap = argparse.ArgumentParser()
     ap.add_argument("--seconds", type=float, default=240.0)

@@ -4,12 +4,12 @@ line or a plane, isolated particles, no constraints at all, duplicate constraint
 extreme coordinates, NaN / infinite positions, more ranks than particles, every tile size and partition. The planner must either refuse with a
 message (SoftbodyError) or return a plan that passes the invariants the GPU execution relies on (tests/test_plan.py _check_plan: every parity's
 order a permutation, groups are matchings, tasks of a phase touch disjoint particles) and whose ranks' halo lists fit together -- never crash,
-never hang. usage: python tools/fuzz_plan.py [--seconds 120] [--seed 0] [--only SEED] [--max N]"""
+never hang. usage: python tests/fuzz/fuzz_plan.py [--seconds 120] [--seed 0] [--only SEED] [--max N]"""
 import os
 import sys
 
-ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests"))
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz")); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import fuzz_parity as fz                                                # noqa: E402  (parent / child harness)
 
 import numpy as np                                                      # noqa: E402

@@ -1,17 +1,17 @@
 #!/usr/bin/env python3
 """Randomised equivalence test of the halo schedules and transports on ONE rank of a partitioned solver with a self-exchange
 (SB_DEBUG_LOOPBACK: every peer is the rank itself -- RCCL refuses two ranks on one device). A self-exchange is not the physics of the
-partitioned mesh (there the oracle is the checker: tools/fuzz_parity.py, hosted ranks and sb_group_*), but it IS every launch, pack, send /
+partitioned mesh (there the oracle is the checker: tests/fuzz/fuzz_parity.py, hosted ranks and sb_group_*), but it IS every launch, pack, send /
 receive, unpack, event and graph of a rank's tick, and every (transport, schedule) pair must leave the SAME BITS as the serialised eager
 schedule over RCCL -- reads and kinematic moves between ticks, ticks with their own dt and substeps, SB_SCHEDULE_AUTO's calibration
 (which alternates the two eager schedules over its first ticks) included.
-usage: python tools/fuzz_schedules.py [--seconds 240] [--seed 0] [--only SEED] [--max N]"""
+usage: python tests/fuzz/fuzz_schedules.py [--seconds 240] [--seed 0] [--only SEED] [--max N]"""
 import ctypes as C
 import os
 import sys
 
-ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.join(ROOT, "tools"))
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.join(ROOT, "tools")); sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz"))
 import fuzz_parity as fz                                                # noqa: E402  (harness: parent / child runner, describe)
 
 import numpy as np                                                      # noqa: E402

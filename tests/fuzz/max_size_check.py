@@ -2,7 +2,7 @@
 """The largest lattice the int32 ABI is expected to carry comfortably on one GPU: an n^3 jelly cube (default 512^3 = 134 M particles,
 402 M springs) through the plugin, ONE tick of 20 substeps, against the CPU oracle on the same mesh bit for bit (the oracle walks
 402 M constraints x 20 substeps: about a minute on the GPU box's host cores), then a short timing run.
-usage (GPU box): python tools/max_size_check.py [n | bunny:<vertices>] [ticks timed] [noparity] [het]
+usage (GPU box): python tests/fuzz/max_size_check.py [n | bunny:<vertices>] [ticks timed] [noparity] [het]
 Checker script: the oracle is used as the checker only (tests/helpers.py), nothing here is product code."""
 import json
 import os
@@ -12,7 +12,7 @@ import time
 
 import numpy as np
 
-ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from softbodyunity_amd import Softbody, jelly_cube  # noqa: E402
 from oracle import oracle  # noqa: E402

@@ -133,6 +133,18 @@ def test_product_package_never_imports_the_oracle():
                 assert "liboracle" not in txt and "from oracle" not in txt and "import oracle" not in txt, f
 
 
+def test_only_tests_smoke_and_the_cpu_baseline_leg_touch_the_oracle():
+    # tools/ (measurement and A/B scripts) never use the checker: the scripts that do -- the fuzzers, the size checks -- live under tests/fuzz/
+    for f in os.listdir(os.path.join(ROOT, "tools")):
+        if f.endswith((".py", ".sh")):
+            txt = open(os.path.join(ROOT, "tools", f)).read()
+            assert "from oracle" not in txt and "import oracle" not in txt and "liboracle" not in txt, f
+    # bench.py: one place (_oracle_tools), reached from the parity / cpu_baseline legs after the timed region
+    txt = open(os.path.join(ROOT, "bench.py")).read()
+    import re
+    assert len(re.findall(r"^\s*(?:from oracle\b|import oracle\b)", txt, re.M)) == 1 and "def _oracle_tools" in txt
+
+
 def test_last_words_survive_a_fatal_signal(tmp_path):
     # sb_debug_last_words (softbody_debug.h): bench.py --gpus N registers its line as it stands before every further A/B variant; should the
     # process then die of a fatal signal -- or be told to stop by a launcher tearing the job down -- the plugin's handler writes the line

@@ -1,6 +1,6 @@
-"""A fixed slice of the randomised differential test (tools/fuzz_parity.py): random meshes, settings, tuning switches, host models (one solver,
+"""A fixed slice of the randomised differential test (tests/fuzz/fuzz_parity.py): random meshes, settings, tuning switches, host models (one solver,
 hosted ranks, sb_group_*) and mid-run host actions, every result bitwise against the CPU oracle. The seeds are fixed, so the test is the same
-run every time; the open-ended form is `python tools/fuzz_parity.py --seconds N --seed S` (profiles/r04x_fuzz_parity.txt)."""
+run every time; the open-ended form is `python tests/fuzz/fuzz_parity.py --seconds N --seed S` (profiles/r04x_fuzz_parity.txt)."""
 import os
 import subprocess
 import sys
@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 @pytest.mark.gpu
 def test_fixed_slice_of_the_fuzzer_is_bitwise():
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_parity.py"), "--seed", "0", "--max", "160", "--seconds", "400"],
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_parity.py"), "--seed", "0", "--max", "160", "--seconds", "400"],
                        capture_output=True, text=True, timeout=600)
     lines = r.stdout.splitlines()
     summary = [l for l in lines if l.startswith("SUMMARY")]
@@ -26,8 +26,8 @@ def test_fixed_slice_of_the_fuzzer_is_bitwise():
 
 @pytest.mark.gpu
 def test_fixed_slice_of_the_schedule_fuzzer_is_bitwise():
-    """tools/fuzz_schedules.py: one rank with a self-exchange, every drawn (transport, schedule) pair against the serialised eager schedule."""
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "fuzz_schedules.py"), "--seed", "0", "--max", "10", "--seconds", "300"],
+    """tests/fuzz/fuzz_schedules.py: one rank with a self-exchange, every drawn (transport, schedule) pair against the serialised eager schedule."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_schedules.py"), "--seed", "0", "--max", "10", "--seconds", "300"],
                        capture_output=True, text=True, timeout=600)
     lines = r.stdout.splitlines()
     summary = [l for l in lines if l.startswith("SUMMARY")]

@@ -324,11 +324,11 @@ def test_more_ranks_than_cells_leaves_ranks_empty_but_the_result_whole(oracle_mo
 
 
 def test_fixed_slice_of_the_planner_fuzzer():
-    """tools/fuzz_plan.py: degenerate meshes (a point, a line, a plane, a chain, a complete graph, a hub, isolated particles, no constraints, one or
+    """tests/fuzz/fuzz_plan.py: degenerate meshes (a point, a line, a plane, a chain, a complete graph, a hub, isolated particles, no constraints, one or
     two particles, duplicates, extreme scales, NaN / inf) x world x tile x partition: refused with a message or a plan that passes the invariants."""
     import os, subprocess, sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    r = subprocess.run([sys.executable, os.path.join(root, "tools", "fuzz_plan.py"), "--seed", "0", "--max", "400", "--seconds", "120"],
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz", "fuzz_plan.py"), "--seed", "0", "--max", "400", "--seconds", "120"],
                        capture_output=True, text=True, timeout=300)
     lines = r.stdout.splitlines()
     summary = [l for l in lines if l.startswith("SUMMARY")]

@@ -40,10 +40,10 @@ def test_oracle_under_asan_ubsan(tmp_path):
 
 
 def test_planner_on_the_fuzz_corpus_under_asan_ubsan(tmp_path):
-    """The degenerate meshes of tools/fuzz_plan.py (a point, a line, no constraints, complete graphs, NaN ...) through plan.cpp under ASan + UBSan."""
+    """The degenerate meshes of tests/fuzz/fuzz_plan.py (a point, a line, no constraints, complete graphs, NaN ...) through plan.cpp under ASan + UBSan."""
     import sys
     import numpy as np
-    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "fuzz")); sys.path.insert(0, os.path.join(ROOT, "tools"))
     import fuzz_plan
     corpus = tmp_path / "corpus.bin"
     with open(corpus, "wb") as f:
