@@ -371,10 +371,18 @@ int finalize_device(sb_solver *s) {
 
 // What a rank tells the others about its plan: [status, plan hash, pair hash with rank 0 .. W-1]; status bit 0 = sharded authoring,
 // bit 1 = this rank FAILED before it got here (the hashes are then 0).
+// The SHAPE of the tick program every rank must share: a rank whose WINDOW holds none of the leftover constraints plans no T2 layer
+// (or one global colour less) -- fewer launches, fewer exchanges, fewer halo slots -- while its pair hashes still agree with its
+// neighbours' (tests/fuzz/fuzz_parity.py seed 2005569: particles on a line, four windows, one of them with a leftover layer).
+uint32_t plan_shape(const sb_solver *s) {
+    const sbp::Plan &P = s->plan->plan;
+    return 1u + (P.tiling ? 1u : 0u) + 4u * (uint32_t)std::min<size_t>(P.t2_layers.size(), 0xfffu) + 0x4000u * (uint32_t)std::min<size_t>(P.gcolours.size(), 0xffffu);
+}
+
 std::vector<uint64_t> agreement_record(const sb_solver *s, bool failed) {
     const int W = s->desc.world;
     std::vector<uint64_t> mine((size_t)W + 2, 0);
-    mine[0] = (s->sharded ? 1u : 0u) | (failed ? 2u : 0u);
+    mine[0] = (s->sharded ? 1u : 0u) | (failed ? 2u : 0u) | (failed ? 0u : (uint64_t)plan_shape(s) << 8);
     if (!failed) {
         mine[1] = s->plan_hash;
         for (int r = 0; r < W; ++r) mine[2 + (size_t)r] = s->plan->local.pair_hash[(size_t)r];
@@ -398,6 +406,12 @@ int check_agreement(const std::vector<uint64_t> &all, int W, int me) {
     for (int a = 0; a < W; ++a)
         for (int b = a + 1; b < W; ++b) {
             const uint64_t *ra = all.data() + (size_t)a * rec, *rb = all.data() + (size_t)b * rec;
+            if ((ra[0] >> 8) != (rb[0] >> 8)) {
+                std::snprintf(msg, sizeof msg, "sb_finalize: ranks %d and %d planned tick programs of different shape (leftover layers / global colours: %llx vs %llx): "
+                              "a window that does not reproduce the whole-mesh plan (sharded authoring is for lattice-like meshes) or different meshes on the ranks",
+                              a, b, (unsigned long long)(ra[0] >> 8), (unsigned long long)(rb[0] >> 8));
+                return fail(SB_ERR_STATE, msg);
+            }
             if (!(ra[0] & 1u) && !(rb[0] & 1u) && ra[1] != rb[1]) {
                 std::snprintf(msg, sizeof msg, "sb_finalize: ranks %d and %d planned different schedules (plan hash %016llx vs %016llx): "
                               "every rank must pass the same mesh, tile_particles, partition and plan_flags", a, b,

@@ -56,6 +56,11 @@ void peer_link(sb_solver *s) {
                 const uint64_t their_pair = (uint64_t)hw[4 + 2 * (size_t)me] | ((uint64_t)hw[5 + 2 * (size_t)me] << 32);
                 const uint64_t my_pair = s->plan->local.pair_hash[(size_t)r];
                 char msg[320];
+                if (hw[3] != plan_shape(s)) {       // (first: the layout of the neighbour's mailbox follows its number of halo slots)
+                    std::snprintf(msg, sizeof msg, "peer transport: ranks %d and %d planned tick programs of different shape (leftover layers / global colours: %x vs %x): "
+                                  "a window that does not reproduce the whole-mesh plan, or different meshes on the ranks", me, r, plan_shape(s), hw[3]);
+                    throw HipError(SB_ERR_STATE, msg);
+                }
                 if (!s->sharded && !hw[2] && their_plan != s->plan_hash) {
                     std::snprintf(msg, sizeof msg, "peer transport: rank %d planned a different schedule than rank %d (plan hash %016llx vs %016llx): every rank "
                                   "must pass the same mesh, tile_particles, partition and plan_flags", r, me, (unsigned long long)their_plan, (unsigned long long)s->plan_hash);

@@ -423,6 +423,7 @@ int finalize_plan(sb_solver *s);                        //   host work only: sch
 int finalize_device(sb_solver *s);                      //   device tables, streams
 void reset_authoring(sb_solver *s);                     // forget a window (sb_set_domain) and the plan made from it
 std::vector<uint64_t> agreement_record(const sb_solver *s, bool failed);
+uint32_t plan_shape(const sb_solver *s);                // the tick program's shape: tiling on / off, leftover (T2) layers, global colours (= halo slots)
 int check_agreement(const std::vector<uint64_t> &all, int W, int me);
 int finalize_agree(sb_solver *s, int local_rc);         // RCCL all-gather of the agreement records (entered by a failed rank too)
 int finalize_link(sb_solver *s);                        // peer mailboxes over the communicator, bookkeeping

@@ -666,6 +666,7 @@ void build_device(sb_solver *s) {
         std::vector<uint32_t> header(PS.data_off_words, 0u);
         header[0] = (uint32_t)s->plan_hash; header[1] = (uint32_t)(s->plan_hash >> 32);      // compared by the neighbours (peer_link)
         header[2] = s->sharded ? 1u : 0u;
+        header[3] = plan_shape(s);                    // compared by the neighbours too: the mailbox LAYOUT follows the number of halo slots
         for (int r = 0; r < W; ++r) { const uint64_t ph = L.pair_hash[(size_t)r]; header[4 + 2 * (size_t)r] = (uint32_t)ph; header[5 + 2 * (size_t)r] = (uint32_t)(ph >> 32); }
         PS.my_off.assign((size_t)PS.n_slots, std::vector<uint32_t>((size_t)W, 0u));
         size_t words = PS.data_off_words;

@@ -25,6 +25,16 @@ def test_fixed_slice_of_the_fuzzer_is_bitwise():
     assert sum("kind=odd" in l for l in ok) >= 10
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [2005569])
+def test_seeds_that_once_failed(seed):
+    """2005569: particles on a line through sb_group_* on 4 ranks under the block partition -- the windows' pair hashes agree, yet ONE window holds
+    a leftover (T2) layer and the others none: tick programs of different shape (the mailbox layout follows the number of halo slots). The
+    agreement now carries the shape; the group falls back to the whole mesh."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_parity.py"), "--only", str(seed)], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "SUMMARY 1 scenarios: OK 1" in r.stdout, r.stdout[-1500:] + r.stderr[-500:]
+
+
+@pytest.mark.gpu
 def test_fixed_slice_of_the_schedule_fuzzer_is_bitwise():
     """tests/fuzz/fuzz_schedules.py: one rank with a self-exchange, every drawn (transport, schedule) pair against the serialised eager schedule."""
     r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "fuzz", "fuzz_schedules.py"), "--seed", "0", "--max", "10", "--seconds", "300"],
