@@ -3,7 +3,7 @@
 over), every rank a partitioned oracle walking ITS window's local program in the kernel order of one tick (tests/helpers.py run_tick: T0 / T1
 tile kernels, ghost refresh before every T1 kernel through the ranks' own send / receive lists), halo by memcpy -- the state after one tick of
 20 substeps must equal the golden checksum of the UNPARTITIONED oracle (tests/golden/state_checksums.json). No GPU; test infrastructure (the
-oracle is the checker of the plan here). ~5 minutes, ~6 GB. usage: python tests/fuzz/windows_256_run.py [n=256] [world=8] [ticks=1]"""
+oracle is the checker of the plan here). ~5 minutes, ~6 GB. usage: python tests/fuzz/windows_256_run.py [n=256] [world=8] [ticks=1] [het]"""
 import json
 import os
 import sys
@@ -20,9 +20,10 @@ from softbodyunity_amd.verify import add_checksums, state_checksum      # noqa: 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 256
 W = int(sys.argv[2]) if len(sys.argv) > 2 else 8
 ticks = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+het = len(sys.argv) > 4 and sys.argv[4] == "het"      # every particle its own mass, every spring its own rest length
 tile, S, dt = 512, 20, 0.02
 t0 = time.time()
-ranks = [WindowRankSim(oracle, jelly_cube_window(n, r, W, (0, 0, 0), tile), r, W, (0, 0, 0), tile) for r in range(W)]
+ranks = [WindowRankSim(oracle, jelly_cube_window(n, r, W, (0, 0, 0), tile, heterogeneous=het), r, W, (0, 0, 0), tile) for r in range(W)]
 print(f"{W} windows of {n}^3 planned: {[int(R.owned.sum()) for R in ranks]} owned particles, {time.time() - t0:.1f} s", flush=True)
 
 
@@ -43,7 +44,7 @@ def exchange(slot, with_prev):
             R.o.xprev[ids] = prev
 
 
-golden = json.load(open(os.path.join(ROOT, "tests", "golden", "state_checksums.json"))).get(f"cube{n}_s{S}_tile{tile}")
+golden = json.load(open(os.path.join(ROOT, "tests", "golden", "state_checksums.json"))).get(f"cube{n}{'het' if het else ''}_s{S}_tile{tile}")
 ok = True
 for t in range(1, ticks + 1):
     s = ranks[0].o.scalars(dt, S)
