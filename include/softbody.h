@@ -122,8 +122,8 @@ int sb_set_ground_plane(sb_solver *s, float nx, float ny, float nz, float d, int
  * position lies in the box sb_domain_window returns for it (its block of cells plus two cells of margin), the constraints among
  * them, in the order of the whole mesh -- instead of the whole mesh on every rank. sb_domain is the frame all ranks agree on:
  * every window is cut from the one grid made from it, so the ranks' tiles, ghost lists and shared-tile programs fit together
- * exactly as when every rank plans the whole mesh -- for LATTICE-LIKE meshes: colours and leftover layers of an irregular mesh are not
- * local to a window (sb_finalize verifies pair by pair what two ranks share, and that all ranks planned tick programs of the same
+ * exactly as when every rank plans the whole mesh -- where that plan is LATTICE-TYPE (two tilings, no leftover layer, no global colour:
+ * lattices at the usual tile sizes): colours and leftover layers are not local to a window (sb_finalize verifies pair by pair what two ranks share, and that all ranks planned tick programs of the same
  * shape; a mismatch is SB_ERR_STATE on every rank). A whole-mesh host never needs this. */
 typedef struct {
     int64_t n_global;                 /* particles of the whole mesh */

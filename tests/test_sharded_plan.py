@@ -153,3 +153,17 @@ def test_partitioned_run_on_windows_equals_the_unpartitioned_oracle(oracle_mod, 
     for R in ranks:
         x[R.gid[R.owned]] = R.o.x[R.owned]; v[R.gid[R.owned]] = R.o.v[R.owned]
     assert np.array_equal(x.view(np.uint32), ref.x.view(np.uint32)) and np.array_equal(v.view(np.uint32), ref.v.view(np.uint32))
+
+
+def test_fixed_slice_of_the_window_fuzzer():
+    """tests/fuzz/fuzz_windows.py: random lattice boxes (full, with holes, L-shaped), worlds, rank grids, tile sizes -- wherever the whole-mesh plan
+    is lattice-type (no leftover layers, no global colours) every rank's WINDOW plan must reproduce it (owned sets, pair hashes, shape)."""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "fuzz", "fuzz_windows.py"), "--seed", "0", "--max", "150", "--seconds", "200"],
+                       capture_output=True, text=True, timeout=400)
+    lines = r.stdout.splitlines()
+    summary = [l for l in lines if l.startswith("SUMMARY")]
+    bad = [l for l in lines if l.split(" ", 1)[0] in ("MISMATCH", "ERROR", "CRASH")]
+    assert summary and not bad and r.returncode == 0, "\n".join(bad[:5] + summary + [r.stderr[-800:]])
+    assert "150 scenarios" in summary[0] and sum(l.startswith("OK") for l in lines) >= 120, summary[0]
